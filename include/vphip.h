@@ -1,0 +1,164 @@
+/*
+ * vphip.h -- C ABI of libvphip.so, the MI355X (gfx950) implementation of the reference's
+ * voxelize -> CSG -> JFA hot path.
+ *
+ * The reference (bigmat18/cuda-mesh-voxelization) has no FFI layer: its boundary is the vplib
+ * C++ template API.  Each entry point below names the reference interface it stands behind;
+ * the C++ mirror of that API (cuda_mesh_voxelization_amd/vplib/) and the Python harness call
+ * nothing but these functions.  All citations are file:line under the reference repo.
+ *
+ * Conventions
+ *   - Every function returns 0 on success, otherwise a non-zero code (hipError_t value, or
+ *     VP_ERR_* below) and stores a message retrievable with vp_last_error().  Nothing throws,
+ *     nothing calls exit(): the C++ mirror turns a non-zero code into the reference's
+ *     print-and-exit behaviour (vplib/src/debug_utils.h:43-50).
+ *   - Pointers named d_* are device pointers (any hipMalloc'd / torch-owned memory of the
+ *     context's device); h_* are host pointers.  The caller owns every buffer.
+ *   - Work is enqueued on the context's stream and is asynchronous unless stated otherwise.
+ *   - Grid layout is the reference's (vplib/src/grid/voxels_grid.h:116-129,
+ *     vplib/src/grid/grid.h:89-92): voxel (x,y,z) is bit (x + y*n + z*n*n) of a little-endian
+ *     uint32 word array, LSB first; dense fields (sdf) are x-fastest float arrays.
+ *   - A vp_frame may describe a Z-slab [z0,z1) of the global n^3 grid: buffers then hold only
+ *     those planes (plane z0 first).  z0 = 0, z1 = n is the whole grid.
+ */
+#ifndef VPHIP_H
+#define VPHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VP_ABI_VERSION 1
+
+enum {
+    VP_OK = 0,
+    VP_ERR_INVALID = 10001,     /* bad argument (null pointer, unsupported n, finite fill, ...) */
+    VP_ERR_UNSUPPORTED = 10002, /* valid request this build cannot serve */
+    VP_ERR_NOMEM = 10003
+};
+
+/* vplib/src/proc_utils.h:7-9  enum class Types {SEQUENTIAL, NAIVE, TILED, OPENMP}: the GPU values */
+enum { VP_ALGO_NAIVE = 1, VP_ALGO_TILED = 2 };
+
+/* vplib/src/csg/csg.h:10-12  enum class Op {VOID, UNION, INTERSECTION, DIFFERENCE} */
+enum { VP_OP_VOID = 0, VP_OP_UNION = 1, VP_OP_INTERSECTION = 2, VP_OP_DIFFERENCE = 3 };
+
+/* Grid frame: what VoxelsGrid carries besides its words (voxels_grid.h:39-43,160-169),
+ * plus the Z-slab this buffer holds. */
+typedef struct vp_frame {
+    uint32_t n;           /* voxels per side of the GLOBAL grid (n % 32 == 0, 32 <= n <= 1024) */
+    float    voxel_size;
+    float    origin[3];
+    uint32_t z0, z1;      /* planes held: z0 <= z < z1; multiples of 8 */
+} vp_frame;
+
+typedef struct vp_ctx vp_ctx;
+
+/* ---- context ------------------------------------------------------------------------------
+ * Replaces `cudaSetDevice(0)` + default stream + per-call cudaMalloc/cudaFree of the reference
+ * (apps/cli/main.cpp:22-23, vplib/src/cuda_ptr.h:15-93).  The context owns a stream and a
+ * grow-only workspace so that steady-state calls allocate nothing. */
+int vp_ctx_create(int device, vp_ctx** out);
+int vp_ctx_destroy(vp_ctx* ctx);
+/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
+int vp_ctx_set_stream(vp_ctx* ctx, void* hip_stream);
+int vp_ctx_sync(vp_ctx* ctx);
+const char* vp_last_error(void);
+int vp_abi_version(void);
+
+/* ---- device memory (CudaPtr<T> equivalent, vplib/src/cuda_ptr.h:24-93) --------------------- */
+int vp_malloc(vp_ctx* ctx, size_t bytes, void** d_out);
+int vp_free(vp_ctx* ctx, void* d_ptr);
+int vp_memset(vp_ctx* ctx, void* d_ptr, int byte_value, size_t bytes);           /* async */
+int vp_upload(vp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);        /* blocking */
+int vp_download(vp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);      /* blocking */
+
+/* words in the buffer of a frame: n*n*(z1-z0)/32 */
+size_t vp_grid_words(const vp_frame* f);
+/* voxels in the buffer of a frame: n*n*(z1-z0) */
+size_t vp_grid_voxels(const vp_frame* f);
+
+/* ---- voxelize -----------------------------------------------------------------------------
+ * Stands behind VOX::Compute<Types::NAIVE|TILED,T>(HostVoxelsGrid<T>&, const Mesh&)
+ * (vplib/src/vox/vox.h:107-111, vox/naive.cu:86-122, vox/tiled.cu:488-576); the result is the
+ * bitmask of VOX::Compute<Types::SEQUENTIAL> (vox/sequential.cpp:6-63).
+ *   d_xyz   nverts x 3 float  (Mesh::Coords, mesh.h:133-170)
+ *   d_tri   ntris x 3 uint32  (Mesh::FacesCoords; ntris = indices/3 as in sequential.cpp:16)
+ *   accumulate = 0: d_words is overwritten (GPU variants of the reference replace the grid,
+ *                   vox/tiled.cu:572-575); 1: XOR into the existing words (sequential semantics).
+ * Synchronises the stream once internally (work-queue size read-back) when algo = TILED. */
+int vp_voxelize(vp_ctx* ctx, const vp_frame* f, uint32_t* d_words,
+                const float* d_xyz, size_t nverts, const uint32_t* d_tri, size_t ntris,
+                int algo, int accumulate);
+
+/* ---- CSG ----------------------------------------------------------------------------------
+ * Stands behind CSG::Compute<Types::NAIVE,T,func>(grid1, grid2, Op) (vplib/src/csg/csg.h:35-36,
+ * csg/naive.cu:26-64): d_a[i] = d_a[i] op d_b[i] with the functors of csg.h:14-30. */
+int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int op);
+
+/* ---- JFA ----------------------------------------------------------------------------------
+ * Stands behind JFA::Compute<Types::NAIVE|TILED,T>(HostVoxelsGrid<T>&, HostGrid<float>&)
+ * (vplib/src/jfa/jfa.h:42-43, jfa/naive.cu:121-180, jfa/tiled.cu:244-337); results are those of
+ * the sequential path (jfa/sequential.cpp:7-127): signed SQUARED distance, +inside, -outside.
+ *
+ * State between passes is one uint32 per voxel: the packed coordinates of the nearest seed
+ * found so far (x | y<<10 | z<<20, 0xFFFFFFFF = none) instead of the reference's float sdf +
+ * float3 position; distances are recomputed from it with the reference's expressions.
+ *
+ * vp_jfa runs init + all passes + finalize on one device for a whole-grid frame.
+ *   fill_unset  value the caller pre-filled the sdf with (apps/cli/main.cpp:200 uses -INFINITY);
+ *               must be +-infinity (a finite fill is undefined behaviour in the reference).
+ *   d_work      scratch of vp_jfa_workspace_bytes(f) bytes (two id volumes).
+ *   algo        VP_ALGO_NAIVE: direct kernel; VP_ALGO_TILED: LDS-table kernel.  Same results. */
+size_t vp_jfa_workspace_bytes(const vp_frame* f);
+int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
+           float* d_sdf, void* d_work, size_t work_bytes, int algo);
+
+/* The three stages separately, for Z-slab sharding (halo exchange happens between calls).
+ * Halo pointers may be NULL where the slab touches the global boundary.
+ *   init:  d_plane_below / d_plane_above = bitmask plane z0-1 / z1 (n*n/32 words each).
+ *   pass:  step k; d_minus holds id planes [z0-k, min(z0, z1-k)), d_plus holds
+ *          [max(z1, z0+k), z1+k), each clipped to the global grid but indexed from the unclipped
+ *          start (plane p of d_minus is global plane z0-k+p).
+ *   finalize: ids -> float sdf for the slab. */
+int vp_jfa_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words,
+                const uint32_t* d_plane_below, const uint32_t* d_plane_above, uint32_t* d_ids);
+int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const uint32_t* d_in,
+                const uint32_t* d_minus, const uint32_t* d_plus, uint32_t* d_out, int algo);
+int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const uint32_t* d_ids,
+                    float fill_unset, float* d_sdf);
+
+/* "Surface" output (README.md:9): the border-voxel mask that JFA seeds
+ * from (jfa/sequential.cpp:24-64), as a bitmask with the grid's layout. */
+int vp_surface(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words,
+               const uint32_t* d_plane_below, const uint32_t* d_plane_above, uint32_t* d_border_words);
+
+/* ---- host-in / host-out conveniences (the reference's Compute() calling convention) -------
+ * Upload, run, download, synchronise -- what every reference Compute<NAIVE|TILED> does
+ * (vox/tiled.cu:504-575, csg/naive.cu:38-63, jfa/tiled.cu:254-336).  Whole-grid frames only. */
+int vp_voxelize_host(vp_ctx* ctx, const vp_frame* f, uint32_t* h_words,
+                     const float* h_xyz, size_t nverts, const uint32_t* h_tri, size_t ntris, int algo);
+int vp_csg_host(vp_ctx* ctx, uint32_t* h_a, const uint32_t* h_b, size_t nwords, int op);
+int vp_jfa_host(vp_ctx* ctx, const vp_frame* f, const uint32_t* h_words, float fill_unset,
+                float* h_sdf, int algo);
+
+/* ---- per-kernel timing (PROFILING_SCOPE equivalent for device time, vplib/src/profiling.h:8-33)
+ * When enabled, every kernel launch is bracketed by hipEvents on the context's stream. */
+enum {
+    VP_K_VOX_SETUP = 0, VP_K_VOX_SCAN, VP_K_VOX_SCATTER, VP_K_VOX_TILE, VP_K_VOX_NAIVE,
+    VP_K_VOX_FILL, VP_K_CSG, VP_K_JFA_INIT, VP_K_JFA_PASS, VP_K_JFA_FINAL, VP_K_SURFACE,
+    VP_K_COUNT
+};
+int vp_prof_enable(vp_ctx* ctx, int on);
+int vp_prof_reset(vp_ctx* ctx);
+/* Synchronises the stream, folds pending events in, returns total ms and launch count. */
+int vp_prof_get(vp_ctx* ctx, int kernel, double* total_ms, uint64_t* launches);
+const char* vp_prof_name(int kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPHIP_H */

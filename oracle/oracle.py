@@ -1,0 +1,138 @@
+"""ctypes loader for the CPU oracle (oracle/libvporacle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvporacle.so")
+
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "vp_oracle.c")
+    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libvporacle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.vpo_bounding_box.restype = ctypes.c_float
+        L.vpo_bounding_box.argtypes = [_f32p, ctypes.c_size_t, _f32p]
+        L.vpo_frame.restype = None
+        L.vpo_frame.argtypes = [_f32p, ctypes.c_size_t, ctypes.c_uint, _f32p, _f32p]
+        L.vpo_voxelize.restype = None
+        L.vpo_voxelize.argtypes = [_u32p, ctypes.c_uint, ctypes.c_float, _f32p, _f32p, _u32p, ctypes.c_size_t]
+        L.vpo_csg.restype = None
+        L.vpo_csg.argtypes = [_u32p, _u32p, ctypes.c_size_t, ctypes.c_int]
+        L.vpo_jfa.restype = ctypes.c_int
+        L.vpo_jfa.argtypes = [_u32p, ctypes.c_uint, ctypes.c_float, _f32p, _f32p, ctypes.c_int]
+        L.vpo_threads.restype = ctypes.c_int
+        L.vpo_fnv1a64.restype = ctypes.c_uint64
+        L.vpo_fnv1a64.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.vpo_popcount.restype = ctypes.c_uint64
+        L.vpo_popcount.argtypes = [_u32p, ctypes.c_size_t]
+        L.vpo_sdf_stats.restype = None
+        L.vpo_sdf_stats.argtypes = [_f32p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),
+                                    ctypes.POINTER(ctypes.c_double), _f32p]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _pf(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _pu(a):
+    return a.ctypes.data_as(_u32p)
+
+
+def nwords(n: int) -> int:
+    return (n * n * n + 31) // 32
+
+
+def frame(meshes_xyz, n: int):
+    allv = _f32(np.concatenate([np.asarray(m, np.float32).reshape(-1, 3) for m in meshes_xyz], 0))
+    origin = np.zeros(3, np.float32)
+    vs = ctypes.c_float()
+    lib().vpo_frame(_pf(allv), allv.shape[0], n, _pf(origin), ctypes.byref(vs))
+    return origin, np.float32(vs.value)
+
+
+def voxelize(xyz, tri, n: int, voxel_size, origin, words=None):
+    """Sequential voxelization; XOR-accumulates into `words` (fresh zero grid when None)."""
+    xyz = _f32(xyz)
+    tri = _u32(tri)
+    origin = _f32(origin)
+    if words is None:
+        words = np.zeros(nwords(n), np.uint32)
+    assert words.dtype == np.uint32 and words.flags.c_contiguous and words.size == nwords(n)
+    lib().vpo_voxelize(_pu(words), n, float(voxel_size), _pf(origin), _pf(xyz), _pu(tri), tri.shape[0])
+    return words
+
+
+def csg(a, b, op: int):
+    assert a.dtype == np.uint32 and b.dtype == np.uint32 and a.size == b.size
+    b = _u32(b)
+    lib().vpo_csg(_pu(a), _pu(b), a.size, op)
+    return a
+
+
+def jfa(words, n: int, voxel_size, origin, fill=-np.inf, max_passes: int = -1):
+    """Sequential JFA; returns float32 [n^3] signed squared distances (x fastest)."""
+    words = _u32(words)
+    origin = _f32(origin)
+    sdf = np.full(n * n * n, fill, np.float32)
+    rc = lib().vpo_jfa(_pu(words), n, float(voxel_size), _pf(origin), _pf(sdf), max_passes)
+    if rc != 0:
+        raise MemoryError("vpo_jfa allocation failed")
+    return sdf
+
+
+def threads() -> int:
+    return int(lib().vpo_threads())
+
+
+def fnv(a) -> str:
+    a = np.ascontiguousarray(a)
+    return "%016x" % lib().vpo_fnv1a64(a.ctypes.data_as(ctypes.c_void_p), a.nbytes)
+
+
+def popcount(words) -> int:
+    words = _u32(words)
+    return int(lib().vpo_popcount(_pu(words), words.size))
+
+
+def sdf_stats(sdf):
+    sdf = _f32(sdf)
+    counts = (ctypes.c_uint64 * 3)()
+    sums = (ctypes.c_double * 2)()
+    mm = (ctypes.c_float * 2)()
+    lib().vpo_sdf_stats(_pf(sdf), sdf.size, counts, sums, mm)
+    return {"zeros": int(counts[0]), "pinf": int(counts[1]), "ninf": int(counts[2]),
+            "sum_pos": float(sums[0]), "sum_neg": float(sums[1]), "min": float(mm[0]), "max": float(mm[1])}
