@@ -1,0 +1,225 @@
+"""ctypes binding of libvphip.so (include/vphip.h) -- the only way the Python harness reaches
+the HIP kernels.  There is no fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libvphip.so")
+
+ALGO_NAIVE, ALGO_TILED = 1, 2
+OP_VOID, OP_UNION, OP_INTERSECTION, OP_DIFFERENCE = 0, 1, 2, 3
+
+KERNELS = ["vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
+           "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface"]
+
+# every symbol include/vphip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_stream", "vp_ctx_sync", "vp_last_error", "vp_abi_version",
+    "vp_malloc", "vp_free", "vp_memset", "vp_upload", "vp_download", "vp_grid_words", "vp_grid_voxels",
+    "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa", "vp_jfa_init", "vp_jfa_pass",
+    "vp_jfa_finalize", "vp_surface", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
+    "vp_prof_enable", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
+]
+
+
+class VPError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libvphip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Frame(ctypes.Structure):
+    """vp_frame: global grid side n, voxel size, origin, Z-slab [z0, z1)."""
+    _fields_ = [("n", ctypes.c_uint32), ("voxel_size", ctypes.c_float), ("origin", ctypes.c_float * 3),
+                ("z0", ctypes.c_uint32), ("z1", ctypes.c_uint32)]
+
+    @classmethod
+    def make(cls, n, voxel_size, origin, z0=0, z1=None):
+        f = cls()
+        f.n = int(n)
+        f.voxel_size = float(voxel_size)
+        f.origin[0], f.origin[1], f.origin[2] = float(origin[0]), float(origin[1]), float(origin[2])
+        f.z0 = int(z0)
+        f.z1 = int(n if z1 is None else z1)
+        return f
+
+    @property
+    def nz(self):
+        return self.z1 - self.z0
+
+    @property
+    def words(self):
+        return self.n * self.n * self.nz // 32
+
+    @property
+    def voxels(self):
+        return self.n * self.n * self.nz
+
+    def slab(self, z0, z1):
+        return Frame.make(self.n, self.voxel_size, self.origin, z0, z1)
+
+
+_lib = None
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+
+def lib():
+    """Load libvphip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libvphip.so is missing at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    fp = ctypes.POINTER(Frame)
+    sig = {
+        "vp_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+        "vp_ctx_destroy": (ctypes.c_int, [_vp]),
+        "vp_ctx_set_stream": (ctypes.c_int, [_vp, _vp]),
+        "vp_ctx_sync": (ctypes.c_int, [_vp]),
+        "vp_last_error": (ctypes.c_char_p, []),
+        "vp_abi_version": (ctypes.c_int, []),
+        "vp_malloc": (ctypes.c_int, [_vp, _sz, ctypes.POINTER(_vp)]),
+        "vp_free": (ctypes.c_int, [_vp, _vp]),
+        "vp_memset": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _sz]),
+        "vp_upload": (ctypes.c_int, [_vp, _vp, _vp, _sz]),
+        "vp_download": (ctypes.c_int, [_vp, _vp, _vp, _sz]),
+        "vp_grid_words": (_sz, [fp]),
+        "vp_grid_voxels": (_sz, [fp]),
+        "vp_voxelize": (ctypes.c_int, [_vp, fp, _vp, _vp, _sz, _vp, _sz, ctypes.c_int, ctypes.c_int]),
+        "vp_csg": (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int]),
+        "vp_jfa_workspace_bytes": (_sz, [fp]),
+        "vp_jfa": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_float, _vp, _vp, _sz, ctypes.c_int]),
+        "vp_jfa_init": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
+        "vp_jfa_pass": (ctypes.c_int, [_vp, fp, ctypes.c_uint32, _vp, _vp, _vp, _vp, ctypes.c_int]),
+        "vp_jfa_finalize": (ctypes.c_int, [_vp, fp, _vp, _vp, ctypes.c_float, _vp]),
+        "vp_surface": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
+        "vp_voxelize_host": (ctypes.c_int, [_vp, fp, _vp, _vp, _sz, _vp, _sz, ctypes.c_int]),
+        "vp_csg_host": (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int]),
+        "vp_jfa_host": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_float, _vp, ctypes.c_int]),
+        "vp_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
+        "vp_prof_reset": (ctypes.c_int, [_vp]),
+        "vp_prof_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
+        "vp_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise VPError(rc, (lib().vp_last_error() or b"").decode("utf-8", "replace"))
+
+
+class Context:
+    """vp_ctx wrapper.  Device pointers are plain ints (e.g. torch.Tensor.data_ptr())."""
+
+    def __init__(self, device: int = 0):
+        self._h = _vp()
+        check(lib().vp_ctx_create(device, ctypes.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().vp_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing
+    def set_stream(self, hip_stream):
+        check(lib().vp_ctx_set_stream(self._h, _vp(hip_stream) if hip_stream else None))
+
+    def sync(self):
+        check(lib().vp_ctx_sync(self._h))
+
+    def malloc(self, nbytes: int) -> int:
+        p = _vp()
+        check(lib().vp_malloc(self._h, nbytes, ctypes.byref(p)))
+        return p.value
+
+    def free(self, ptr: int):
+        check(lib().vp_free(self._h, _vp(ptr)))
+
+    def memset(self, ptr: int, value: int, nbytes: int):
+        check(lib().vp_memset(self._h, _vp(ptr), value, nbytes))
+
+    def upload(self, dptr: int, host_array):
+        check(lib().vp_upload(self._h, _vp(dptr), host_array.ctypes.data_as(_vp), host_array.nbytes))
+
+    def download(self, host_array, dptr: int):
+        check(lib().vp_download(self._h, host_array.ctypes.data_as(_vp), _vp(dptr), host_array.nbytes))
+
+    # -- device-resident stages
+    def voxelize(self, frame: Frame, d_words: int, d_xyz: int, nverts: int, d_tri: int, ntris: int,
+                 algo: int = ALGO_TILED, accumulate: bool = False):
+        check(lib().vp_voxelize(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_xyz), nverts, _vp(d_tri), ntris,
+                                algo, 1 if accumulate else 0))
+
+    def csg(self, d_a: int, d_b: int, nwords: int, op: int):
+        check(lib().vp_csg(self._h, _vp(d_a), _vp(d_b), nwords, op))
+
+    def jfa_workspace_bytes(self, frame: Frame) -> int:
+        return int(lib().vp_jfa_workspace_bytes(ctypes.byref(frame)))
+
+    def jfa(self, frame: Frame, d_words: int, fill: float, d_sdf: int, d_work: int, work_bytes: int,
+            algo: int = ALGO_TILED):
+        check(lib().vp_jfa(self._h, ctypes.byref(frame), _vp(d_words), fill, _vp(d_sdf), _vp(d_work), work_bytes, algo))
+
+    def jfa_init(self, frame: Frame, d_words: int, d_below, d_above, d_ids: int):
+        check(lib().vp_jfa_init(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_below or None),
+                                _vp(d_above or None), _vp(d_ids)))
+
+    def jfa_pass(self, frame: Frame, k: int, d_in: int, d_minus, d_plus, d_out: int, algo: int = ALGO_TILED):
+        check(lib().vp_jfa_pass(self._h, ctypes.byref(frame), k, _vp(d_in), _vp(d_minus or None),
+                                _vp(d_plus or None), _vp(d_out), algo))
+
+    def jfa_finalize(self, frame: Frame, d_words: int, d_ids: int, fill: float, d_sdf: int):
+        check(lib().vp_jfa_finalize(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_ids), fill, _vp(d_sdf)))
+
+    def surface(self, frame: Frame, d_words: int, d_below, d_above, d_border: int):
+        check(lib().vp_surface(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_below or None),
+                               _vp(d_above or None), _vp(d_border)))
+
+    # -- host-in / host-out (numpy arrays), the reference's Compute() convention
+    def voxelize_host(self, frame: Frame, h_words, h_xyz, h_tri, algo: int = ALGO_TILED):
+        check(lib().vp_voxelize_host(self._h, ctypes.byref(frame), h_words.ctypes.data_as(_vp),
+                                     h_xyz.ctypes.data_as(_vp), h_xyz.shape[0], h_tri.ctypes.data_as(_vp),
+                                     h_tri.shape[0], algo))
+
+    def csg_host(self, h_a, h_b, op: int):
+        check(lib().vp_csg_host(self._h, h_a.ctypes.data_as(_vp), h_b.ctypes.data_as(_vp), h_a.size, op))
+
+    def jfa_host(self, frame: Frame, h_words, fill: float, h_sdf, algo: int = ALGO_TILED):
+        check(lib().vp_jfa_host(self._h, ctypes.byref(frame), h_words.ctypes.data_as(_vp), fill,
+                                h_sdf.ctypes.data_as(_vp), algo))
+
+    # -- per-kernel device timing
+    def prof_enable(self, on: bool = True):
+        check(lib().vp_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(lib().vp_prof_reset(self._h))
+
+    def prof(self):
+        out = {}
+        for i, name in enumerate(KERNELS):
+            ms = ctypes.c_double()
+            n = ctypes.c_uint64()
+            check(lib().vp_prof_get(self._h, i, ctypes.byref(ms), ctypes.byref(n)))
+            if n.value:
+                out[name] = {"ms": ms.value, "launches": int(n.value)}
+        return out

@@ -1,0 +1,371 @@
+// capi.hip -- the extern "C" surface of libvphip.so (declared in include/vphip.h):
+// context / stream / workspace management, argument validation, per-kernel hipEvent timing and
+// the host-in/host-out conveniences that reproduce the reference's Compute() calling convention.
+#include "vp_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace vp {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+    // same information as the reference's gpuAssert line (vplib/src/debug_utils.h:43-50)
+    snprintf(g_err, sizeof(g_err), "[%s:%d] HIP Assert: %s (%s)", file, line, hipGetErrorString(e), what);
+    return (int)e;
+}
+
+int reserve(vp_ctx* ctx, Buffer& b, size_t bytes)
+{
+    if (bytes <= b.bytes) return 0;
+    VP_HIP(hipStreamSynchronize(ctx->stream));
+    if (b.ptr) VP_HIP(hipFree(b.ptr));
+    b.ptr = nullptr; b.bytes = 0;
+    const size_t want = bytes + bytes / 4;                        // head-room: fewer regrows
+    VP_HIP(hipMalloc(&b.ptr, want));
+    b.bytes = want;
+    return 0;
+}
+
+ProfScope::ProfScope(vp_ctx* c, int k) : ctx(c), kernel(k)
+{
+    if (!ctx->prof_on) return;
+    auto take = [&]() -> hipEvent_t {
+        if (!ctx->prof_pool.empty()) { hipEvent_t e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    };
+    a = take(); b = take();
+    if (a) (void)hipEventRecord(a, ctx->stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (!ctx->prof_on || !a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof_pending.push_back({kernel, a, b});
+}
+
+static int prof_fold(vp_ctx* ctx)
+{
+    if (ctx->prof_pending.empty()) return 0;
+    VP_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& s : ctx->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            ctx->prof_ms[s.kernel] += ms;
+            ctx->prof_n[s.kernel] += 1;
+        }
+        ctx->prof_pool.push_back(s.a);
+        ctx->prof_pool.push_back(s.b);
+    }
+    ctx->prof_pending.clear();
+    return 0;
+}
+
+static int check_frame(const vp_frame* f, const char* who, bool whole)
+{
+    if (!f) return set_error(VP_ERR_INVALID, "%s: null frame", who);
+    if (f->n < 32 || f->n > 1024 || (f->n % 32) != 0)
+        return set_error(VP_ERR_UNSUPPORTED, "%s: n=%u unsupported (need 32 <= n <= 1024, n %% 32 == 0)", who, f->n);
+    if (!(f->z0 < f->z1) || f->z1 > f->n || (f->z0 % 8) != 0 || (f->z1 % 8) != 0)
+        return set_error(VP_ERR_INVALID, "%s: bad slab [%u,%u) for n=%u (multiples of 8 required)", who, f->z0, f->z1, f->n);
+    if (whole && !(f->z0 == 0 && f->z1 == f->n))
+        return set_error(VP_ERR_INVALID, "%s: whole-grid frame required", who);
+    if (!(f->voxel_size > 0.0f) || !std::isfinite(f->voxel_size))
+        return set_error(VP_ERR_INVALID, "%s: voxel_size must be positive and finite", who);
+    return 0;
+}
+
+static const char* kNames[VP_K_COUNT] = {
+    "vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
+    "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface"
+};
+
+}  // namespace vp
+
+using namespace vp;
+
+extern "C" {
+
+int vp_abi_version(void) { return VP_ABI_VERSION; }
+
+const char* vp_last_error(void) { return g_err; }
+
+int vp_ctx_create(int device, vp_ctx** out)
+{
+    if (!out) return set_error(VP_ERR_INVALID, "vp_ctx_create: null out");
+    *out = nullptr;
+    int count = 0;
+    VP_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count)
+        return set_error(VP_ERR_INVALID, "vp_ctx_create: device %d not present (%d visible)", device, count);
+    VP_HIP(hipSetDevice(device));
+    vp_ctx* c = new (std::nothrow) vp_ctx();
+    if (!c) return set_error(VP_ERR_NOMEM, "vp_ctx_create: out of host memory");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+int vp_ctx_destroy(vp_ctx* ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    Buffer* bufs[] = { &ctx->rec, &ctx->tile_cnt, &ctx->tile_off, &ctx->tile_cur, &ctx->pairs, &ctx->scratch };
+    for (Buffer* b : bufs) if (b->ptr) (void)hipFree(b->ptr);
+    for (auto& s : ctx->prof_pending) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return 0;
+}
+
+int vp_ctx_set_stream(vp_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return set_error(VP_ERR_INVALID, "vp_ctx_set_stream: null ctx");
+    VP_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return 0;
+}
+
+int vp_ctx_sync(vp_ctx* ctx)
+{
+    if (!ctx) return set_error(VP_ERR_INVALID, "vp_ctx_sync: null ctx");
+    VP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int vp_malloc(vp_ctx* ctx, size_t bytes, void** d_out)
+{
+    if (!ctx || !d_out) return set_error(VP_ERR_INVALID, "vp_malloc: null argument");
+    VP_HIP(hipSetDevice(ctx->device));
+    VP_HIP(hipMalloc(d_out, bytes ? bytes : 1));
+    return 0;
+}
+
+int vp_free(vp_ctx* ctx, void* d_ptr)
+{
+    if (!ctx) return set_error(VP_ERR_INVALID, "vp_free: null ctx");
+    if (d_ptr) { VP_HIP(hipStreamSynchronize(ctx->stream)); VP_HIP(hipFree(d_ptr)); }
+    return 0;
+}
+
+int vp_memset(vp_ctx* ctx, void* d_ptr, int byte_value, size_t bytes)
+{
+    if (!ctx || (!d_ptr && bytes)) return set_error(VP_ERR_INVALID, "vp_memset: null argument");
+    if (bytes) VP_HIP(hipMemsetAsync(d_ptr, byte_value, bytes, ctx->stream));
+    return 0;
+}
+
+int vp_upload(vp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!ctx || ((!d_dst || !h_src) && bytes)) return set_error(VP_ERR_INVALID, "vp_upload: null argument");
+    if (bytes) {
+        VP_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        VP_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+int vp_download(vp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!ctx || ((!h_dst || !d_src) && bytes)) return set_error(VP_ERR_INVALID, "vp_download: null argument");
+    if (bytes) {
+        VP_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        VP_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+size_t vp_grid_words(const vp_frame* f) { return f ? (size_t)f->n * f->n * (f->z1 - f->z0) / 32 : 0; }
+size_t vp_grid_voxels(const vp_frame* f) { return f ? (size_t)f->n * f->n * (f->z1 - f->z0) : 0; }
+
+int vp_voxelize(vp_ctx* ctx, const vp_frame* f, uint32_t* d_words, const float* d_xyz, size_t nverts,
+                const uint32_t* d_tri, size_t ntris, int algo, int accumulate)
+{
+    if (!ctx || !d_words) return set_error(VP_ERR_INVALID, "vp_voxelize: null argument");
+    VP_TRY(check_frame(f, "vp_voxelize", false));
+    if (ntris && (!d_xyz || !d_tri || !nverts)) return set_error(VP_ERR_INVALID, "vp_voxelize: null mesh arrays");
+    if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_voxelize: algo %d", algo);
+    if (ntris > 0xFFFFFFFFull / 3) return set_error(VP_ERR_UNSUPPORTED, "vp_voxelize: too many triangles");
+    return launch_voxelize(ctx, make_frame(f), d_words, d_xyz, nverts, d_tri, ntris, algo, accumulate ? 1 : 0);
+}
+
+int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int op)
+{
+    if (!ctx || ((!d_a || !d_b) && nwords)) return set_error(VP_ERR_INVALID, "vp_csg: null argument");
+    if (op < VP_OP_VOID || op > VP_OP_DIFFERENCE) return set_error(VP_ERR_INVALID, "vp_csg: unknown op %d", op);
+    return launch_csg(ctx, d_a, d_b, nwords, op);
+}
+
+size_t vp_jfa_workspace_bytes(const vp_frame* f) { return f ? 2 * vp_grid_voxels(f) * sizeof(uint32_t) : 0; }
+
+static int check_fill(float fill, const char* who)
+{
+    if (!std::isinf(fill)) return set_error(VP_ERR_INVALID, "%s: fill_unset must be +-infinity", who);
+    return 0;
+}
+
+int vp_jfa_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const uint32_t* d_plane_below,
+                const uint32_t* d_plane_above, uint32_t* d_ids)
+{
+    if (!ctx || !d_words || !d_ids) return set_error(VP_ERR_INVALID, "vp_jfa_init: null argument");
+    VP_TRY(check_frame(f, "vp_jfa_init", false));
+    return launch_jfa_init(ctx, make_frame(f), d_words, d_plane_below, d_plane_above, d_ids, nullptr);
+}
+
+int vp_surface(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const uint32_t* d_plane_below,
+               const uint32_t* d_plane_above, uint32_t* d_border_words)
+{
+    if (!ctx || !d_words || !d_border_words) return set_error(VP_ERR_INVALID, "vp_surface: null argument");
+    VP_TRY(check_frame(f, "vp_surface", false));
+    return launch_jfa_init(ctx, make_frame(f), d_words, d_plane_below, d_plane_above, nullptr, d_border_words);
+}
+
+int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
+                const uint32_t* d_plus, uint32_t* d_out, int algo)
+{
+    if (!ctx || !d_in || !d_out || d_in == d_out) return set_error(VP_ERR_INVALID, "vp_jfa_pass: bad buffers");
+    VP_TRY(check_frame(f, "vp_jfa_pass", false));
+    if (k == 0 || k >= f->n) return set_error(VP_ERR_INVALID, "vp_jfa_pass: step %u out of range", k);
+    if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_jfa_pass: algo %d", algo);
+    // halos are mandatory wherever a neighbour plane exists outside the slab
+    if (f->z0 > 0 && !d_minus) return set_error(VP_ERR_INVALID, "vp_jfa_pass: slab needs d_minus");
+    if (f->z1 < f->n && !d_plus) return set_error(VP_ERR_INVALID, "vp_jfa_pass: slab needs d_plus");
+    return launch_jfa_pass(ctx, make_frame(f), k, d_in, d_minus, d_plus, d_out, algo);
+}
+
+int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const uint32_t* d_ids,
+                    float fill_unset, float* d_sdf)
+{
+    if (!ctx || !d_words || !d_ids || !d_sdf) return set_error(VP_ERR_INVALID, "vp_jfa_finalize: null argument");
+    VP_TRY(check_frame(f, "vp_jfa_finalize", false));
+    VP_TRY(check_fill(fill_unset, "vp_jfa_finalize"));
+    return launch_jfa_final(ctx, make_frame(f), d_words, d_ids, fill_unset, d_sdf);
+}
+
+int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset, float* d_sdf,
+           void* d_work, size_t work_bytes, int algo)
+{
+    if (!ctx || !d_words || !d_sdf || !d_work) return set_error(VP_ERR_INVALID, "vp_jfa: null argument");
+    VP_TRY(check_frame(f, "vp_jfa", true));
+    VP_TRY(check_fill(fill_unset, "vp_jfa"));
+    if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_jfa: algo %d", algo);
+    if (work_bytes < vp_jfa_workspace_bytes(f)) return set_error(VP_ERR_INVALID, "vp_jfa: workspace too small");
+    const Frame fr = make_frame(f);
+    uint32_t* a = (uint32_t*)d_work;
+    uint32_t* b = a + vp_grid_voxels(f);
+    VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, a, nullptr));
+    for (uint32_t k = f->n / 2; k >= 1; k /= 2) {                  // jfa/sequential.cpp:72
+        VP_TRY(launch_jfa_pass(ctx, fr, k, a, nullptr, nullptr, b, algo));
+        uint32_t* t = a; a = b; b = t;
+    }
+    return launch_jfa_final(ctx, fr, d_words, a, fill_unset, d_sdf);
+}
+
+// ---- host-in / host-out ----------------------------------------------------------------------
+int vp_voxelize_host(vp_ctx* ctx, const vp_frame* f, uint32_t* h_words, const float* h_xyz, size_t nverts,
+                     const uint32_t* h_tri, size_t ntris, int algo)
+{
+    if (!ctx || !h_words) return set_error(VP_ERR_INVALID, "vp_voxelize_host: null argument");
+    VP_TRY(check_frame(f, "vp_voxelize_host", true));
+    void *dw = nullptr, *dx = nullptr, *dt = nullptr;
+    const size_t wb = vp_grid_words(f) * 4;
+    int rc = vp_malloc(ctx, wb, &dw);
+    if (!rc) rc = vp_malloc(ctx, nverts * 12, &dx);
+    if (!rc) rc = vp_malloc(ctx, ntris * 12, &dt);
+    if (!rc) rc = vp_upload(ctx, dx, h_xyz, nverts * 12);
+    if (!rc) rc = vp_upload(ctx, dt, h_tri, ntris * 12);
+    if (!rc) rc = vp_voxelize(ctx, f, (uint32_t*)dw, (const float*)dx, nverts, (const uint32_t*)dt, ntris, algo, 0);
+    if (!rc) rc = vp_download(ctx, h_words, dw, wb);
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    (void)vp_free(ctx, dw); (void)vp_free(ctx, dx); (void)vp_free(ctx, dt);
+    if (rc) memcpy(g_err, keep, sizeof(keep));
+    return rc;
+}
+
+int vp_csg_host(vp_ctx* ctx, uint32_t* h_a, const uint32_t* h_b, size_t nwords, int op)
+{
+    if (!ctx || ((!h_a || !h_b) && nwords)) return set_error(VP_ERR_INVALID, "vp_csg_host: null argument");
+    void *da = nullptr, *db = nullptr;
+    int rc = vp_malloc(ctx, nwords * 4, &da);
+    if (!rc) rc = vp_malloc(ctx, nwords * 4, &db);
+    if (!rc) rc = vp_upload(ctx, da, h_a, nwords * 4);
+    if (!rc) rc = vp_upload(ctx, db, h_b, nwords * 4);
+    if (!rc) rc = vp_csg(ctx, (uint32_t*)da, (const uint32_t*)db, nwords, op);
+    if (!rc) rc = vp_download(ctx, h_a, da, nwords * 4);
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    (void)vp_free(ctx, da); (void)vp_free(ctx, db);
+    if (rc) memcpy(g_err, keep, sizeof(keep));
+    return rc;
+}
+
+int vp_jfa_host(vp_ctx* ctx, const vp_frame* f, const uint32_t* h_words, float fill_unset, float* h_sdf, int algo)
+{
+    if (!ctx || !h_words || !h_sdf) return set_error(VP_ERR_INVALID, "vp_jfa_host: null argument");
+    VP_TRY(check_frame(f, "vp_jfa_host", true));
+    void *dw = nullptr, *ds = nullptr, *wk = nullptr;
+    const size_t wb = vp_grid_words(f) * 4, sb = vp_grid_voxels(f) * 4, kb = vp_jfa_workspace_bytes(f);
+    int rc = vp_malloc(ctx, wb, &dw);
+    if (!rc) rc = vp_malloc(ctx, sb, &ds);
+    if (!rc) rc = vp_malloc(ctx, kb, &wk);
+    if (!rc) rc = vp_upload(ctx, dw, h_words, wb);
+    if (!rc) rc = vp_jfa(ctx, f, (const uint32_t*)dw, fill_unset, (float*)ds, wk, kb, algo);
+    if (!rc) rc = vp_download(ctx, h_sdf, ds, sb);
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    (void)vp_free(ctx, dw); (void)vp_free(ctx, ds); (void)vp_free(ctx, wk);
+    if (rc) memcpy(g_err, keep, sizeof(keep));
+    return rc;
+}
+
+// ---- profiling -------------------------------------------------------------------------------
+int vp_prof_enable(vp_ctx* ctx, int on)
+{
+    if (!ctx) return set_error(VP_ERR_INVALID, "vp_prof_enable: null ctx");
+    if (!on) VP_TRY(prof_fold(ctx));
+    ctx->prof_on = on != 0;
+    return 0;
+}
+
+int vp_prof_reset(vp_ctx* ctx)
+{
+    if (!ctx) return set_error(VP_ERR_INVALID, "vp_prof_reset: null ctx");
+    VP_TRY(prof_fold(ctx));
+    for (int i = 0; i < VP_K_COUNT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+    return 0;
+}
+
+int vp_prof_get(vp_ctx* ctx, int kernel, double* total_ms, uint64_t* launches)
+{
+    if (!ctx || kernel < 0 || kernel >= VP_K_COUNT) return set_error(VP_ERR_INVALID, "vp_prof_get: bad argument");
+    VP_TRY(prof_fold(ctx));
+    if (total_ms) *total_ms = ctx->prof_ms[kernel];
+    if (launches) *launches = ctx->prof_n[kernel];
+    return 0;
+}
+
+const char* vp_prof_name(int kernel) { return (kernel >= 0 && kernel < VP_K_COUNT) ? kNames[kernel] : "?"; }
+
+}  // extern "C"

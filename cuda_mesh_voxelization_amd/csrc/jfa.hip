@@ -1,0 +1,329 @@
+// jfa.hip -- Jump-Flooding signed squared distance field for gfx950 (MI355X).
+//
+// Result contract: the sdf of the reference's sequential JFA
+// (/root/reference/vplib/src/jfa/sequential.cpp:7-127), bit for bit: same passes (k = n/2 .. 1,
+// :72), same 26-neighbour scan order (z, y, x outer->inner, :86-88), strict '<' acceptance (:106),
+// same float expressions for positions (:79-81) and distances (jfa/jfa.h:19-20), Jacobi update.
+//
+// State: the reference keeps float sdf + float3 seed position per voxel (16 B, two copies, plus a
+// deep copy per pass, :123-124).  Here the state is ONE uint32 per voxel -- the packed voxel
+// coordinates of the best seed so far (x | y<<10 | z<<22, 0xFFFFFFFF = none).  The seed position
+// and the distance are recomputed from it with the reference's expressions, which gives the same
+// floats because the reference's stored sdf is itself the result of exactly that expression.
+// Ping-pong between two id volumes; the last step converts ids to floats.
+//
+// Kernels
+//   jfa_init      bitmask -> ids (and/or border bitmask).  One lane = one 32-voxel word: the 26-
+//                 neighbourhood test is 27 word loads + shifts/ANDs; ids leave as coalesced 16-B
+//                 stores after a wave shuffle transposes word-per-lane into voxels-per-lane.
+//   jfa_pass_direct   (VP_ALGO_NAIVE) one thread per voxel, everything recomputed inline.
+//   jfa_pass_table    (VP_ALGO_TILED) one workgroup per x-row: per-row LDS tables hold the seed-
+//                 coordinate -> position / squared-delta maps, cutting ~11 VALU ops per candidate.
+//   jfa_final     ids + bitmask -> float sdf.
+//
+// Built with -ffp-contract=off (an FMA changes the result).
+#include "vp_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace vp {
+
+namespace {
+
+__device__ __forceinline__ uint32_t pack_id(uint32_t x, uint32_t y, uint32_t z) { return x | (y << 10) | (z << 22); }
+
+// jfa/sequential.cpp:79-81 / :32-34 : voxel corner position along one axis
+__device__ __forceinline__ float axis_pos(float o, uint32_t i, float vs) { return o + ((float)(int)i * vs); }
+
+// jfa/jfa.h:19-20 with p1 = seed position decoded from `id`, p0 = (px,py,pz)
+__device__ __forceinline__ float seed_distance(const Frame& f, uint32_t id, float px, float py, float pz)
+{
+    const float sx = axis_pos(f.ox, id & 1023u, f.vs);
+    const float sy = axis_pos(f.oy, (id >> 10) & 1023u, f.vs);
+    const float sz = axis_pos(f.oz, id >> 22, f.vs);
+    return ((sx - px) * (sx - px)) + ((sy - py) * (sy - py)) + ((sz - pz) * (sz - pz));
+}
+
+// ------------------------------------------------------------------------------------------ init
+// words: slab bitmask; below/above: plane z0-1 / z1 (or null).  Returns the word holding voxels
+// (32*xw .., y, zg) or 0 outside the grid (outside counts as unset, sequential.cpp:46-51).
+__device__ __forceinline__ uint32_t grid_word(const Frame& f, const uint32_t* __restrict__ words,
+                                              const uint32_t* __restrict__ below, const uint32_t* __restrict__ above,
+                                              int xw, int y, int zg)
+{
+    if (xw < 0 || xw >= (int)f.w || y < 0 || y >= (int)f.n || zg < 0 || zg >= (int)f.n) return 0u;
+    const size_t inPlane = (size_t)y * f.w + xw;
+    if (zg < (int)f.z0) return (below != nullptr && zg == (int)f.z0 - 1) ? below[inPlane] : 0u;
+    if (zg >= (int)f.z1) return (above != nullptr && zg == (int)f.z1) ? above[inPlane] : 0u;
+    return words[(size_t)(zg - (int)f.z0) * f.n * f.w + inPlane];
+}
+
+template <bool IDS, bool MASK>
+__global__ void __launch_bounds__(256)
+jfa_init(Frame f, const uint32_t* __restrict__ words, const uint32_t* __restrict__ below,
+         const uint32_t* __restrict__ above, uint32_t* __restrict__ ids, uint32_t* __restrict__ border_words)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wbase = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;   // first word of this wave
+    const size_t wi = wbase + lane;
+    const int W = f.w;
+    const int xw = (int)(wi % W);
+    const size_t row = wi / W;
+    const int y = (int)(row % f.n);
+    const int zg = (int)(row / f.n) + (int)f.z0;
+
+    const uint32_t centre = grid_word(f, words, below, above, xw, y, zg);
+    uint32_t border = 0;
+    if (centre != 0u) {
+        uint32_t interior = 0xFFFFFFFFu;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy) {
+                const uint32_t c = (dz == 0 && dy == 0) ? centre : grid_word(f, words, below, above, xw, y + dy, zg + dz);
+                const uint32_t p = grid_word(f, words, below, above, xw - 1, y + dy, zg + dz);
+                const uint32_t n = grid_word(f, words, below, above, xw + 1, y + dy, zg + dz);
+                const uint32_t left = (c << 1) | (p >> 31);       // bit i = voxel x-1
+                const uint32_t right = (c >> 1) | (n << 31);      // bit i = voxel x+1
+                interior &= left & c & right;
+            }
+        border = centre & ~interior;                              // sequential.cpp:28-55
+    }
+    if (MASK) border_words[wi] = border;
+    if (IDS) {
+        const uint32_t mybase = pack_id((uint32_t)xw * 32u, (uint32_t)y, (uint32_t)zg);
+        const int sub = (lane & 7) * 4;
+        uint4* out = reinterpret_cast<uint4*>(ids + wbase * 32);
+#pragma unroll 4
+        for (int j = 0; j < 8; ++j) {
+            const int src = j * 8 + (lane >> 3);
+            const uint32_t b = (__shfl(border, src) >> sub) & 0xFu;
+            const uint32_t id0 = __shfl(mybase, src) + (uint32_t)sub;
+            uint4 v;
+            v.x = (b & 1u) ? id0 : kNone;
+            v.y = (b & 2u) ? id0 + 1u : kNone;
+            v.z = (b & 4u) ? id0 + 2u : kNone;
+            v.w = (b & 8u) ? id0 + 3u : kNone;
+            out[j * 64 + lane] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ pass
+// Plane of global z `zg` among the three id buffers of a slab (see vphip.h, vp_jfa_pass).
+__device__ __forceinline__ const uint32_t* id_plane(const Frame& f, uint32_t k, const uint32_t* in,
+                                                    const uint32_t* minus, const uint32_t* plus, int zg)
+{
+    const size_t plane = (size_t)f.n * f.n;
+    if (zg < (int)f.z0) return minus + (size_t)(zg - ((int)f.z0 - (int)k)) * plane;
+    if (zg >= (int)f.z1) {
+        const int pbase = max((int)f.z1, (int)f.z0 + (int)k);
+        return plus + (size_t)(zg - pbase) * plane;
+    }
+    return in + (size_t)(zg - (int)f.z0) * plane;
+}
+
+__global__ void __launch_bounds__(256)
+jfa_pass_direct(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
+                const uint32_t* __restrict__ plus, uint32_t* __restrict__ out)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)f.n * f.n * (f.z1 - f.z0);
+    if (gid >= total) return;
+    const int N = (int)f.n;
+    const int x = (int)(gid % f.n);
+    const int y = (int)((gid / f.n) % f.n);
+    const int zg = (int)(gid / ((size_t)f.n * f.n)) + (int)f.z0;
+    const float px = axis_pos(f.ox, x, f.vs), py = axis_pos(f.oy, y, f.vs), pz = axis_pos(f.oz, zg, f.vs);
+
+    uint32_t best = in[gid];
+    float bestd = (best == kNone) ? INFINITY : seed_distance(f, best, px, py, pz);   // = fabs(sdf), :84
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int nz = zg + dz * (int)k;
+        if (nz < 0 || nz >= N) continue;
+        const uint32_t* pl = id_plane(f, k, in, minus, plus, nz);
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int ny = y + dy * (int)k;
+            if (ny < 0 || ny >= N) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (dx == 0 && dy == 0 && dz == 0) continue;
+                const int nx = x + dx * (int)k;
+                if (nx < 0 || nx >= N) continue;
+                const uint32_t c = pl[(size_t)ny * N + nx];
+                if (c != kNone) {                                  // fabs(seed) < INFINITY, :102
+                    const float d = seed_distance(f, c, px, py, pz);
+                    if (d < bestd) { bestd = d; best = c; }        // :106-110
+                }
+            }
+        }
+    }
+    out[gid] = best;
+}
+
+// Table variant.  Workgroup = RY consecutive x-rows of one z (RY = 1 when n >= 256).
+// LDS: PX[i] = ox + i*vs; TZ[i] = (PZ[i]-pz)^2 for this z; TY[r][i] = (PY[i]-py_r)^2 for row r.
+// dist = ((PX[ix]-px)^2 + TY[iy]) + TZ[iz]  -- the same float operations as seed_distance().
+constexpr int kTab = 1024;     // table stride: any 10-bit field (also those of kNone) stays in bounds
+
+__global__ void __launch_bounds__(256)
+jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
+               const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, int RY, const uint32_t* __restrict__ zorder)
+{
+    extern __shared__ float lds[];
+    float* PX = lds;
+    float* TZ = lds + kTab;
+    float* TY = lds + 2 * kTab;
+
+    const int N = (int)f.n;
+    const int tid = threadIdx.x;
+    const int zl = zorder ? (int)zorder[blockIdx.y] : (int)blockIdx.y;
+    const int zg = zl + (int)f.z0;
+    const int y0 = blockIdx.x * RY;
+    const float pz = axis_pos(f.oz, zg, f.vs);
+
+    for (int i = tid; i < N; i += 256) {
+        PX[i] = axis_pos(f.ox, i, f.vs);
+        const float dzv = axis_pos(f.oz, i, f.vs) - pz;
+        TZ[i] = dzv * dzv;
+        const float sy = axis_pos(f.oy, i, f.vs);
+        for (int r = 0; r < RY; ++r) {
+            const float dyv = sy - axis_pos(f.oy, y0 + r, f.vs);
+            TY[r * kTab + i] = dyv * dyv;
+        }
+    }
+    __syncthreads();
+
+    int r, xs, xstep;
+    if (N >= 256) { r = 0; xs = tid; xstep = 256; }
+    else          { r = tid / N; xs = tid - r * N; xstep = N; if (r >= RY) return; }
+    const int y = y0 + r;
+    if (y >= N) return;
+    const char* ty = reinterpret_cast<const char*>(TY + r * kTab);
+    const char* tz = reinterpret_cast<const char*>(TZ);
+    const char* tx = reinterpret_cast<const char*>(PX);
+
+    // the (up to) 9 source rows; null = outside the grid
+    const uint32_t* rows[9];
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int nz = zg + dz * (int)k;
+        const bool zin = nz >= 0 && nz < N;
+        const uint32_t* pl = zin ? id_plane(f, k, in, minus, plus, nz) : nullptr;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int ny = y + dy * (int)k;
+            rows[(dz + 1) * 3 + (dy + 1)] = (zin && ny >= 0 && ny < N) ? pl + (size_t)ny * N : nullptr;
+        }
+    }
+    uint32_t* orow = out + ((size_t)zl * N + y) * N;
+
+    for (int x = xs; x < N; x += xstep) {
+        const float px = PX[x];
+        const int xm = x - (int)k, xp = x + (int)k;
+        const bool hasM = xm >= 0, hasP = xp < N;
+
+        uint32_t c[27];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const uint32_t* rw = rows[q];
+            c[q * 3 + 0] = (rw && hasM) ? rw[xm] : kNone;
+            c[q * 3 + 1] = rw ? rw[x] : kNone;
+            c[q * 3 + 2] = (rw && hasP) ? rw[xp] : kNone;
+        }
+        uint32_t best = c[13];
+        float bestd = INFINITY;
+#pragma unroll
+        for (int j = 0; j < 27; ++j) {
+            // own state first (it wins ties: acceptance is strict, sequential.cpp:106), then scan order
+            const int q = (j == 0) ? 13 : (j <= 13 ? j - 1 : j);
+            const uint32_t id = c[q];
+            const float sx = *reinterpret_cast<const float*>(tx + ((id << 2) & 0xFFCu));
+            const float dy2 = *reinterpret_cast<const float*>(ty + ((id >> 8) & 0xFFCu));
+            const float dz2 = *reinterpret_cast<const float*>(tz + ((id >> 20) & 0xFFCu));
+            const float dxv = sx - px;
+            const float d = ((dxv * dxv) + dy2) + dz2;
+            const bool take = (id != kNone) && (d < bestd);
+            bestd = take ? d : bestd;
+            best = take ? id : best;
+        }
+        orow[x] = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ final
+// One lane = 4 voxels.  sequential.cpp:55-60,106-109 + apps/cli/main.cpp:200 give the sign rule.
+__global__ void __launch_bounds__(256)
+jfa_final(Frame f, const uint32_t* __restrict__ words, const uint4* __restrict__ ids, float fill,
+          float4* __restrict__ sdf)
+{
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total4 = (size_t)f.n * f.n * (f.z1 - f.z0) / 4;
+    if (i4 >= total4) return;
+    const size_t v = i4 * 4;
+    const uint32_t x = (uint32_t)(v % f.n);
+    const uint32_t y = (uint32_t)((v / f.n) % f.n);
+    const uint32_t zg = (uint32_t)(v / ((size_t)f.n * f.n)) + f.z0;
+    const uint32_t bits = (words[v >> 5] >> (v & 31)) & 0xFu;
+    const uint4 id = ids[i4];
+    const float py = axis_pos(f.oy, y, f.vs), pz = axis_pos(f.oz, zg, f.vs);
+    const uint32_t idv[4] = { id.x, id.y, id.z, id.w };
+    float o[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const bool set = (bits >> b) & 1u;
+        const float init = set ? INFINITY : fill;                  // interior +inf (:59) / caller's fill
+        if (idv[b] == kNone) { o[b] = init; continue; }
+        const float d = seed_distance(f, idv[b], axis_pos(f.ox, x + b, f.vs), py, pz);
+        o[b] = copysignf(d, init);                                 // :108
+    }
+    sdf[i4] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* below,
+                    const uint32_t* above, uint32_t* d_ids, uint32_t* d_border_words)
+{
+    const size_t nwords = (size_t)f.n * f.n * (f.z1 - f.z0) / 32;
+    const unsigned blocks = (unsigned)(nwords / 256);             // nwords is a multiple of 256
+    ProfScope p(ctx, d_ids ? VP_K_JFA_INIT : VP_K_SURFACE);
+    if (d_ids && d_border_words)
+        hipLaunchKernelGGL((jfa_init<true, true>), dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, below, above, d_ids, d_border_words);
+    else if (d_ids)
+        hipLaunchKernelGGL((jfa_init<true, false>), dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, below, above, d_ids, d_border_words);
+    else
+        hipLaunchKernelGGL((jfa_init<false, true>), dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, below, above, d_ids, d_border_words);
+    VP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
+                    const uint32_t* d_plus, uint32_t* d_out, int algo)
+{
+    const size_t total = (size_t)f.n * f.n * (f.z1 - f.z0);
+    ProfScope p(ctx, VP_K_JFA_PASS);
+    if (algo == VP_ALGO_NAIVE) {
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(jfa_pass_direct, dim3(blocks), dim3(256), 0, ctx->stream, f, k, d_in, d_minus, d_plus, d_out);
+    } else {
+        const int RY = f.n >= 256 ? 1 : (int)(256 / f.n);
+        const dim3 grid((f.n + RY - 1) / RY, f.z1 - f.z0);
+        const size_t lds = (size_t)(2 + RY) * kTab * sizeof(float);
+        hipLaunchKernelGGL(jfa_pass_table, grid, dim3(256), lds, ctx->stream, f, k, d_in, d_minus, d_plus, d_out, RY,
+                           (const uint32_t*)nullptr);
+    }
+    VP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* d_ids,
+                     float fill, float* d_sdf)
+{
+    const size_t total4 = (size_t)f.n * f.n * (f.z1 - f.z0) / 4;
+    const unsigned blocks = (unsigned)((total4 + 255) / 256);
+    ProfScope p(ctx, VP_K_JFA_FINAL);
+    hipLaunchKernelGGL(jfa_final, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint4*)d_ids, fill, (float4*)d_sdf);
+    VP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vp

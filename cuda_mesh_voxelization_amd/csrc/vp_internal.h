@@ -1,0 +1,93 @@
+// vp_internal.h -- shared declarations of libvphip.so (not part of the public ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/vphip.h"
+
+namespace vp {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;   // JFA state: no seed yet
+constexpr int kTile = 8;                  // voxelizer tile: 8x8 (y,z) columns = one wave64
+constexpr int kRecDwords = 20;            // per-triangle record, see vox.hip
+
+// Device-side copy of vp_frame plus derived constants.
+struct Frame {
+    uint32_t n;        // voxels per side (global)
+    uint32_t w;        // words per x-row = n / 32
+    uint32_t z0, z1;   // slab
+    float vs, ox, oy, oz;
+};
+
+inline Frame make_frame(const vp_frame* f)
+{
+    Frame r;
+    r.n = f->n; r.w = f->n / 32; r.z0 = f->z0; r.z1 = f->z1;
+    r.vs = f->voxel_size; r.ox = f->origin[0]; r.oy = f->origin[1]; r.oz = f->origin[2];
+    return r;
+}
+
+struct ProfSpan { int kernel; hipEvent_t a, b; };
+
+struct Buffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace vp
+
+struct vp_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // grow-only workspaces
+    vp::Buffer rec, tile_cnt, tile_off, tile_cur, pairs, scratch;
+    // profiling
+    bool prof_on = false;
+    std::vector<vp::ProfSpan> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[VP_K_COUNT] = {};
+    uint64_t prof_n[VP_K_COUNT] = {};
+};
+
+namespace vp {
+
+int set_error(int code, const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define VP_HIP(call)                                                          \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) return vp::hip_fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define VP_TRY(call)                 \
+    do {                             \
+        int rc_ = (call);            \
+        if (rc_ != 0) return rc_;    \
+    } while (0)
+
+int reserve(vp_ctx* ctx, Buffer& b, size_t bytes);
+
+// RAII-less profiling bracket: begin() before the launch, end() after.
+struct ProfScope {
+    vp_ctx* ctx; int kernel; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(vp_ctx* c, int k);
+    ~ProfScope();
+};
+
+// ---- stage launchers (each enqueues on ctx->stream) ----
+int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float* d_xyz, size_t nverts,
+                    const uint32_t* d_tri, size_t ntris, int algo, int accumulate);
+int launch_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int op);
+int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* below,
+                    const uint32_t* above, uint32_t* d_ids, uint32_t* d_border_words);
+int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
+                    const uint32_t* d_plus, uint32_t* d_out, int algo);
+int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* d_ids,
+                     float fill, float* d_sdf);
+
+}  // namespace vp
