@@ -80,7 +80,7 @@ def lib():
     sig = {
         "vp_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
         "vp_ctx_destroy": (ctypes.c_int, [_vp]),
-        "vp_ctx_set_stream": (ctypes.c_int, [_vp, _vp]),
+        "vp_ctx_set_stream": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
         "vp_ctx_sync": (ctypes.c_int, [_vp]),
         "vp_last_error": (ctypes.c_char_p, []),
         "vp_abi_version": (ctypes.c_int, []),
@@ -140,8 +140,9 @@ class Context:
             pass
 
     # -- plumbing
-    def set_stream(self, hip_stream):
-        check(lib().vp_ctx_set_stream(self._h, _vp(hip_stream) if hip_stream else None))
+    def set_stream(self, hip_stream, external: bool = True):
+        """external=True: run on the caller's stream handle (0 = the null stream = torch's default stream)."""
+        check(lib().vp_ctx_set_stream(self._h, _vp(hip_stream) if hip_stream else None, 1 if external else 0))
 
     def sync(self):
         check(lib().vp_ctx_sync(self._h))

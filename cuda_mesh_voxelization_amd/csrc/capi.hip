@@ -139,11 +139,11 @@ int vp_ctx_destroy(vp_ctx* ctx)
     return 0;
 }
 
-int vp_ctx_set_stream(vp_ctx* ctx, void* hip_stream)
+int vp_ctx_set_stream(vp_ctx* ctx, void* hip_stream, int external)
 {
     if (!ctx) return set_error(VP_ERR_INVALID, "vp_ctx_set_stream: null ctx");
     VP_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = external ? (hipStream_t)hip_stream : ctx->own_stream;
     return 0;
 }
 

@@ -7,7 +7,7 @@
 //
 // State: the reference keeps float sdf + float3 seed position per voxel (16 B, two copies, plus a
 // deep copy per pass, :123-124).  Here the state is ONE uint32 per voxel -- the packed voxel
-// coordinates of the best seed so far (x | y<<10 | z<<22, 0xFFFFFFFF = none).  The seed position
+// coordinates of the best seed so far ((x<<2) | y<<12 | z<<22, 0xFFFFFFFF = none).  The seed position
 // and the distance are recomputed from it with the reference's expressions, which gives the same
 // floats because the reference's stored sdf is itself the result of exactly that expression.
 // Ping-pong between two id volumes; the last step converts ids to floats.
@@ -30,7 +30,9 @@ namespace vp {
 
 namespace {
 
-__device__ __forceinline__ uint32_t pack_id(uint32_t x, uint32_t y, uint32_t z) { return x | (y << 10) | (z << 22); }
+// id layout: bits [2..11] x, [12..21] y, [22..31] z, bits [0,1] zero -- every field is already a
+// byte offset into a float table after one shift+mask (x: a single AND); kNone has bits 0,1 set.
+__device__ __forceinline__ uint32_t pack_id(uint32_t x, uint32_t y, uint32_t z) { return (x << 2) | (y << 12) | (z << 22); }
 
 // jfa/sequential.cpp:79-81 / :32-34 : voxel corner position along one axis
 __device__ __forceinline__ float axis_pos(float o, uint32_t i, float vs) { return o + ((float)(int)i * vs); }
@@ -38,8 +40,8 @@ __device__ __forceinline__ float axis_pos(float o, uint32_t i, float vs) { retur
 // jfa/jfa.h:19-20 with p1 = seed position decoded from `id`, p0 = (px,py,pz)
 __device__ __forceinline__ float seed_distance(const Frame& f, uint32_t id, float px, float py, float pz)
 {
-    const float sx = axis_pos(f.ox, id & 1023u, f.vs);
-    const float sy = axis_pos(f.oy, (id >> 10) & 1023u, f.vs);
+    const float sx = axis_pos(f.ox, (id >> 2) & 1023u, f.vs);
+    const float sy = axis_pos(f.oy, (id >> 12) & 1023u, f.vs);
     const float sz = axis_pos(f.oz, id >> 22, f.vs);
     return ((sx - px) * (sx - px)) + ((sy - py) * (sy - py)) + ((sz - pz) * (sz - pz));
 }
@@ -96,12 +98,12 @@ jfa_init(Frame f, const uint32_t* __restrict__ words, const uint32_t* __restrict
         for (int j = 0; j < 8; ++j) {
             const int src = j * 8 + (lane >> 3);
             const uint32_t b = (__shfl(border, src) >> sub) & 0xFu;
-            const uint32_t id0 = __shfl(mybase, src) + (uint32_t)sub;
+            const uint32_t id0 = __shfl(mybase, src) + ((uint32_t)sub << 2);
             uint4 v;
             v.x = (b & 1u) ? id0 : kNone;
-            v.y = (b & 2u) ? id0 + 1u : kNone;
-            v.z = (b & 4u) ? id0 + 2u : kNone;
-            v.w = (b & 8u) ? id0 + 3u : kNone;
+            v.y = (b & 2u) ? id0 + 4u : kNone;
+            v.z = (b & 4u) ? id0 + 8u : kNone;
+            v.w = (b & 8u) ? id0 + 12u : kNone;
             out[j * 64 + lane] = v;
         }
     }
@@ -235,14 +237,112 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
             // own state first (it wins ties: acceptance is strict, sequential.cpp:106), then scan order
             const int q = (j == 0) ? 13 : (j <= 13 ? j - 1 : j);
             const uint32_t id = c[q];
-            const float sx = *reinterpret_cast<const float*>(tx + ((id << 2) & 0xFFCu));
-            const float dy2 = *reinterpret_cast<const float*>(ty + ((id >> 8) & 0xFFCu));
+            const float sx = *reinterpret_cast<const float*>(tx + (id & 0xFFCu));
+            const float dy2 = *reinterpret_cast<const float*>(ty + ((id >> 10) & 0xFFCu));
             const float dz2 = *reinterpret_cast<const float*>(tz + ((id >> 20) & 0xFFCu));
             const float dxv = sx - px;
             const float d = ((dxv * dxv) + dy2) + dz2;
             const bool take = (id != kNone) && (d < bestd);
             bestd = take ? d : bestd;
             best = take ? id : best;
+        }
+        orow[x] = best;
+    }
+}
+
+// Fast path for n >= 256: one workgroup per x-row, tables at fixed LDS addresses.  All 27
+// neighbour loads of a voxel are issued before the first is consumed (clamped addresses, validity
+// folded into the accept mask).  SKIP = true: rows outside the grid are skipped with wave-uniform
+// branches (early passes, large k); SKIP = false: one branch-free block so the scheduler can
+// overlap the LDS table reads of all candidates (late passes, where every row is in the grid).
+template <bool SKIP>
+__global__ void __launch_bounds__(256)
+jfa_pass_row(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
+             const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, const uint32_t* __restrict__ zorder)
+{
+    __shared__ float PX[kTab];
+    __shared__ float TY[kTab];
+    __shared__ float TZ[kTab];
+
+    const uint32_t N = f.n;
+    const uint32_t tid = threadIdx.x;
+    const int y = blockIdx.x;
+    const int zl = zorder ? (int)zorder[blockIdx.y] : (int)blockIdx.y;
+    const int zg = zl + (int)f.z0;
+    {
+        const float py = axis_pos(f.oy, y, f.vs), pz = axis_pos(f.oz, zg, f.vs);
+        for (uint32_t i = tid; i < N; i += 256) {
+            PX[i] = axis_pos(f.ox, i, f.vs);
+            const float dyv = axis_pos(f.oy, i, f.vs) - py;
+            TY[i] = dyv * dyv;
+            const float dzv = axis_pos(f.oz, i, f.vs) - pz;
+            TZ[i] = dzv * dzv;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t* own = in + ((size_t)zl * N + y) * N;
+    const uint32_t* rp[9];
+    bool rv[9];
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int nz = zg + dz * (int)k;
+        const bool zin = nz >= 0 && nz < (int)N;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int ny = y + dy * (int)k;
+            const bool ok = zin && ny >= 0 && ny < (int)N;
+            rv[(dz + 1) * 3 + (dy + 1)] = ok;
+            rp[(dz + 1) * 3 + (dy + 1)] = ok ? id_plane(f, k, in, minus, plus, nz) + (size_t)ny * N : own;
+        }
+    }
+    uint32_t* orow = out + ((size_t)zl * N + y) * N;
+    const char* tx = reinterpret_cast<const char*>(PX);
+    const char* ty = reinterpret_cast<const char*>(TY);
+    const char* tz = reinterpret_cast<const char*>(TZ);
+
+    for (uint32_t x = tid; x < N; x += 256) {
+        const float px = PX[x];
+        const bool hasM = x >= k, hasP = x + k < N;
+        const uint32_t xmc = hasM ? x - k : x, xpc = hasP ? x + k : x;
+
+        uint32_t c[27];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            if (!SKIP || rv[q]) {
+                c[q * 3 + 0] = rp[q][xmc];
+                c[q * 3 + 1] = rp[q][x];
+                c[q * 3 + 2] = rp[q][xpc];
+            } else {
+                c[q * 3 + 0] = kNone; c[q * 3 + 1] = kNone; c[q * 3 + 2] = kNone;
+            }
+        }
+        uint32_t best = c[13];
+        float bestd = INFINITY;
+        auto eval = [&](uint32_t id, bool ok) {
+            const float sx = *reinterpret_cast<const float*>(tx + (id & 0xFFCu));
+            const float dy2 = *reinterpret_cast<const float*>(ty + ((id >> 10) & 0xFFCu));
+            const float dz2 = *reinterpret_cast<const float*>(tz + ((id >> 20) & 0xFFCu));
+            const float dxv = sx - px;
+            const float d = ((dxv * dxv) + dy2) + dz2;
+            const bool take = ok & (id != kNone) & (d < bestd);
+            bestd = take ? d : bestd;
+            best = take ? id : best;
+        };
+        eval(c[13], true);                       // own state first: it wins ties (strict '<', sequential.cpp:106)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            if (SKIP) {
+                if (rv[q]) {                     // wave-uniform
+                    eval(c[q * 3 + 0], hasM);
+                    if (q != 4) eval(c[q * 3 + 1], true);
+                    eval(c[q * 3 + 2], hasP);
+                }
+            } else {
+                eval(c[q * 3 + 0], hasM & rv[q]);
+                if (q != 4) eval(c[q * 3 + 1], rv[q]);
+                eval(c[q * 3 + 2], hasP & rv[q]);
+            }
         }
         orow[x] = best;
     }
@@ -305,7 +405,18 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_i
         const unsigned blocks = (unsigned)((total + 255) / 256);
         hipLaunchKernelGGL(jfa_pass_direct, dim3(blocks), dim3(256), 0, ctx->stream, f, k, d_in, d_minus, d_plus, d_out);
     } else {
-        const int RY = f.n >= 256 ? 1 : (int)(256 / f.n);
+        if (f.n >= 256) {
+            // rows fall outside the grid for a sizeable share of the workgroups only while k is large
+            if (k * 8 >= f.n)
+                hipLaunchKernelGGL(jfa_pass_row<true>, dim3(f.n, f.z1 - f.z0), dim3(256), 0, ctx->stream, f, k, d_in, d_minus,
+                                   d_plus, d_out, (const uint32_t*)nullptr);
+            else
+                hipLaunchKernelGGL(jfa_pass_row<false>, dim3(f.n, f.z1 - f.z0), dim3(256), 0, ctx->stream, f, k, d_in, d_minus,
+                                   d_plus, d_out, (const uint32_t*)nullptr);
+            VP_HIP(hipGetLastError());
+            return 0;
+        }
+        const int RY = (int)(256 / f.n);
         const dim3 grid((f.n + RY - 1) / RY, f.z1 - f.z0);
         const size_t lds = (size_t)(2 + RY) * kTab * sizeof(float);
         hipLaunchKernelGGL(jfa_pass_table, grid, dim3(256), lds, ctx->stream, f, k, d_in, d_minus, d_plus, d_out, RY,

@@ -23,12 +23,12 @@ class Engine:
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.ctx = capi.Context(device)
-        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream, external=True)
         self._work = None
 
     # -- buffers ---------------------------------------------------------------------------
     def to_device(self, arr, dtype):
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype).view(np.int32 if dtype == np.uint32 else dtype))
+        t = torch.from_numpy(np.array(arr, dtype=dtype, order="C", copy=True).view(np.int32 if dtype == np.uint32 else dtype))
         return t.to(self.device)
 
     def mesh_to_device(self, xyz, tri):

@@ -63,8 +63,9 @@ typedef struct vp_ctx vp_ctx;
  * grow-only workspace so that steady-state calls allocate nothing. */
 int vp_ctx_create(int device, vp_ctx** out);
 int vp_ctx_destroy(vp_ctx* ctx);
-/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
-int vp_ctx_set_stream(vp_ctx* ctx, void* hip_stream);
+/* external != 0: enqueue on the caller's hipStream_t `hip_stream` (NULL = the device's null stream,
+ * which is what torch's default stream is); external == 0: back to the context's own stream. */
+int vp_ctx_set_stream(vp_ctx* ctx, void* hip_stream, int external);
 int vp_ctx_sync(vp_ctx* ctx);
 const char* vp_last_error(void);
 int vp_abi_version(void);
@@ -105,7 +106,7 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
  * the sequential path (jfa/sequential.cpp:7-127): signed SQUARED distance, +inside, -outside.
  *
  * State between passes is one uint32 per voxel: the packed coordinates of the nearest seed
- * found so far (x | y<<10 | z<<20, 0xFFFFFFFF = none) instead of the reference's float sdf +
+ * found so far (x<<2 | y<<12 | z<<22, 0xFFFFFFFF = none) instead of the reference's float sdf +
  * float3 position; distances are recomputed from it with the reference's expressions.
  *
  * vp_jfa runs init + all passes + finalize on one device for a whole-grid frame.
