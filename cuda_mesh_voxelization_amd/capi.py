@@ -7,7 +7,7 @@ import ctypes
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libvphip.so")
+LIB_PATH = os.environ.get("VPHIP_LIB") or os.path.join(PKG, "libvphip.so")   # VPHIP_LIB: dev experiments only
 
 ALGO_NAIVE, ALGO_TILED = 1, 2
 OP_VOID, OP_UNION, OP_INTERSECTION, OP_DIFFERENCE = 0, 1, 2, 3

@@ -17,8 +17,8 @@
 //                 neighbourhood test is 27 word loads + shifts/ANDs; ids leave as coalesced 16-B
 //                 stores after a wave shuffle transposes word-per-lane into voxels-per-lane.
 //   jfa_pass_direct   (VP_ALGO_NAIVE) one thread per voxel, everything recomputed inline.
-//   jfa_pass_table    (VP_ALGO_TILED) one workgroup per x-row: per-row LDS tables hold the seed-
-//                 coordinate -> position / squared-delta maps, cutting ~11 VALU ops per candidate.
+//   jfa_pass_chain    (VP_ALGO_TILED, n >= 256) LDS coordinate tables + register sliding window over
+//                 rows k apart; jfa_pass_table is the small-n variant of the table idea.
 //   jfa_final     ids + bitmask -> float sdf.
 //
 // Built with -ffp-contract=off (an FMA changes the result).
@@ -32,7 +32,12 @@ namespace {
 
 // id layout: bits [2..11] x, [12..21] y, [22..31] z, bits [0,1] zero -- every field is already a
 // byte offset into a float table after one shift+mask (x: a single AND); kNone has bits 0,1 set.
-__device__ __forceinline__ uint32_t pack_id(uint32_t x, uint32_t y, uint32_t z) { return (x << 2) | (y << 12) | (z << 22); }
+// The y and z fields hold scr(y), scr(z): the low five bits XORed with the next five.  Seeds reached
+// by jumps of 2^j >= 32 differ from the voxel only in high coordinate bits; unscrambled they would all
+// index the same LDS bank of the TY/TZ tables (measured: passes k = 32, 16 ran 2x slower).  scr is an
+// involution and stays inside [0, n) because n % 32 == 0.
+__device__ __forceinline__ uint32_t scr(uint32_t i) { return i ^ ((i >> 5) & 31u); }
+__device__ __forceinline__ uint32_t pack_id(uint32_t x, uint32_t y, uint32_t z) { return (x << 2) | (scr(y) << 12) | (scr(z) << 22); }
 
 // jfa/sequential.cpp:79-81 / :32-34 : voxel corner position along one axis
 __device__ __forceinline__ float axis_pos(float o, uint32_t i, float vs) { return o + ((float)(int)i * vs); }
@@ -41,8 +46,8 @@ __device__ __forceinline__ float axis_pos(float o, uint32_t i, float vs) { retur
 __device__ __forceinline__ float seed_distance(const Frame& f, uint32_t id, float px, float py, float pz)
 {
     const float sx = axis_pos(f.ox, (id >> 2) & 1023u, f.vs);
-    const float sy = axis_pos(f.oy, (id >> 12) & 1023u, f.vs);
-    const float sz = axis_pos(f.oz, id >> 22, f.vs);
+    const float sy = axis_pos(f.oy, scr((id >> 12) & 1023u), f.vs);
+    const float sz = axis_pos(f.oz, scr(id >> 22), f.vs);
     return ((sx - px) * (sx - px)) + ((sy - py) * (sy - py)) + ((sz - pz) * (sz - pz));
 }
 
@@ -184,11 +189,11 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
     for (int i = tid; i < N; i += 256) {
         PX[i] = axis_pos(f.ox, i, f.vs);
         const float dzv = axis_pos(f.oz, i, f.vs) - pz;
-        TZ[i] = dzv * dzv;
+        TZ[scr(i)] = dzv * dzv;
         const float sy = axis_pos(f.oy, i, f.vs);
         for (int r = 0; r < RY; ++r) {
             const float dyv = sy - axis_pos(f.oy, y0 + r, f.vs);
-            TY[r * kTab + i] = dyv * dyv;
+            TY[r * kTab + scr(i)] = dyv * dyv;
         }
     }
     __syncthreads();
@@ -250,101 +255,149 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
     }
 }
 
-// Fast path for n >= 256: one workgroup per x-row, tables at fixed LDS addresses.  All 27
-// neighbour loads of a voxel are issued before the first is consumed (clamped addresses, validity
-// folded into the accept mask).  SKIP = true: rows outside the grid are skipped with wave-uniform
-// branches (early passes, large k); SKIP = false: one branch-free block so the scheduler can
-// overlap the LDS table reads of all candidates (late passes, where every row is in the grid).
-template <bool SKIP>
+// Fast path for n >= 256 ("chain" kernel).  A workgroup owns kChain rows of one plane that are k
+// apart: y_j = r + (j0 + j) * k.  Row y_j reads rows y_j - k, y_j, y_j + k, i.e. its chain
+// neighbours, so a thread walks the chain with a sliding 3-row window of candidate ids in registers
+// and loads only ONE new row triple (9 ids) per voxel instead of 27 -- the L1/TA path, not HBM, was
+// the limiter of the straightforward version (measured: 27 loads/voxel cost 43 % of the pass).
+// Per-row LDS tables at fixed addresses turn a candidate id into (seed x, dy^2, dz^2) with 5 VALU
+// ops + 3 ds_read_b32.
+//   SKIP = true   (early passes: large k, sparse state) rows outside the grid are skipped with
+//                 wave-uniform branches and a candidate column in which no lane of the wave holds
+//                 a seed is skipped after a ballot;
+//   SKIP = false  branch-free per voxel, so the scheduler overlaps the table reads of all candidates.
+//   CHECK_NONE = false (n < 1024): table slot 1023 can never be a real scrambled coordinate; it
+//                 holds +inf, so a kNone candidate yields d = inf/NaN and loses without a compare.
+constexpr int kChain = 4;
+
+template <bool SKIP, bool CHECK_NONE>
 __global__ void __launch_bounds__(256)
-jfa_pass_row(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
-             const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, const uint32_t* __restrict__ zorder)
+jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
+               const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, const uint32_t* __restrict__ zorder)
 {
     __shared__ float PX[kTab];
-    __shared__ float TY[kTab];
     __shared__ float TZ[kTab];
+    __shared__ float TY[kChain][kTab];
 
-    const uint32_t N = f.n;
+    const int N = (int)f.n;
     const uint32_t tid = threadIdx.x;
-    const int y = blockIdx.x;
+    const int r = (int)(blockIdx.x % k);
+    const int j0 = (int)(blockIdx.x / k) * kChain;
+    const int ybase = r + j0 * (int)k;                           // row of chain element 0 of this workgroup
     const int zl = zorder ? (int)zorder[blockIdx.y] : (int)blockIdx.y;
     const int zg = zl + (int)f.z0;
     {
-        const float py = axis_pos(f.oy, y, f.vs), pz = axis_pos(f.oz, zg, f.vs);
-        for (uint32_t i = tid; i < N; i += 256) {
+        const float pz = axis_pos(f.oz, zg, f.vs);
+        float py[kChain];
+#pragma unroll
+        for (int j = 0; j < kChain; ++j) py[j] = axis_pos(f.oy, ybase + j * (int)k, f.vs);
+        for (uint32_t i = tid; i < (uint32_t)N; i += 256) {
+            const uint32_t si = scr(i);
             PX[i] = axis_pos(f.ox, i, f.vs);
-            const float dyv = axis_pos(f.oy, i, f.vs) - py;
-            TY[i] = dyv * dyv;
             const float dzv = axis_pos(f.oz, i, f.vs) - pz;
-            TZ[i] = dzv * dzv;
+            TZ[si] = dzv * dzv;
+            const float sy = axis_pos(f.oy, i, f.vs);
+#pragma unroll
+            for (int j = 0; j < kChain; ++j) {
+                const float dyv = sy - py[j];
+                TY[j][si] = dyv * dyv;
+            }
+        }
+        if (!CHECK_NONE && tid == 0) {
+            PX[kTab - 1] = 0.0f; TZ[kTab - 1] = INFINITY;
+#pragma unroll
+            for (int j = 0; j < kChain; ++j) TY[j][kTab - 1] = 0.0f;
         }
     }
     __syncthreads();
 
-    const uint32_t* own = in + ((size_t)zl * N + y) * N;
-    const uint32_t* rp[9];
-    bool rv[9];
+    const char* tx = reinterpret_cast<const char*>(PX);
+    const char* tz = reinterpret_cast<const char*>(TZ);
+    const char* zp[3];                                             // the three source planes (byte pointers)
+    bool zv[3];
 #pragma unroll
     for (int dz = -1; dz <= 1; ++dz) {
         const int nz = zg + dz * (int)k;
-        const bool zin = nz >= 0 && nz < (int)N;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int ny = y + dy * (int)k;
-            const bool ok = zin && ny >= 0 && ny < (int)N;
-            rv[(dz + 1) * 3 + (dy + 1)] = ok;
-            rp[(dz + 1) * 3 + (dy + 1)] = ok ? id_plane(f, k, in, minus, plus, nz) + (size_t)ny * N : own;
-        }
+        zv[dz + 1] = nz >= 0 && nz < N;
+        zp[dz + 1] = reinterpret_cast<const char*>(zv[dz + 1] ? id_plane(f, k, in, minus, plus, nz) : in + (size_t)zl * N * N);
     }
-    uint32_t* orow = out + ((size_t)zl * N + y) * N;
-    const char* tx = reinterpret_cast<const char*>(PX);
-    const char* ty = reinterpret_cast<const char*>(TY);
-    const char* tz = reinterpret_cast<const char*>(TZ);
+    const uint32_t rowBytes = (uint32_t)N * 4u;
 
-    for (uint32_t x = tid; x < N; x += 256) {
+    for (uint32_t x = tid; x < (uint32_t)N; x += 256) {
         const float px = PX[x];
-        const bool hasM = x >= k, hasP = x + k < N;
-        const uint32_t xmc = hasM ? x - k : x, xpc = hasP ? x + k : x;
+        const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
+        const uint32_t xo = x * 4u, xmo = hasM ? xo - k * 4u : xo, xpo = hasP ? xo + k * 4u : xo;
 
-        uint32_t c[27];
+        // 9 ids of source row yy (3 planes x {x-k, x, x+k}); kNone where the row/plane is outside the grid
+        auto load_row = [&](int yy, uint32_t (&w)[9]) {
+            const bool yin = yy >= 0 && yy < N;                    // wave-uniform
+            const uint32_t ro = (uint32_t)(yin ? yy : 0) * rowBytes;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            if (!SKIP || rv[q]) {
-                c[q * 3 + 0] = rp[q][xmc];
-                c[q * 3 + 1] = rp[q][x];
-                c[q * 3 + 2] = rp[q][xpc];
-            } else {
-                c[q * 3 + 0] = kNone; c[q * 3 + 1] = kNone; c[q * 3 + 2] = kNone;
-            }
-        }
-        uint32_t best = c[13];
-        float bestd = INFINITY;
-        auto eval = [&](uint32_t id, bool ok) {
-            const float sx = *reinterpret_cast<const float*>(tx + (id & 0xFFCu));
-            const float dy2 = *reinterpret_cast<const float*>(ty + ((id >> 10) & 0xFFCu));
-            const float dz2 = *reinterpret_cast<const float*>(tz + ((id >> 20) & 0xFFCu));
-            const float dxv = sx - px;
-            const float d = ((dxv * dxv) + dy2) + dz2;
-            const bool take = ok & (id != kNone) & (d < bestd);
-            bestd = take ? d : bestd;
-            best = take ? id : best;
-        };
-        eval(c[13], true);                       // own state first: it wins ties (strict '<', sequential.cpp:106)
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            if (SKIP) {
-                if (rv[q]) {                     // wave-uniform
-                    eval(c[q * 3 + 0], hasM);
-                    if (q != 4) eval(c[q * 3 + 1], true);
-                    eval(c[q * 3 + 2], hasP);
+            for (int dz = 0; dz < 3; ++dz) {
+                if (yin && zv[dz]) {
+                    const char* b = zp[dz] + ro;                   // uniform base; 32-bit lane offsets
+                    w[dz * 3 + 0] = *reinterpret_cast<const uint32_t*>(b + xmo);
+                    w[dz * 3 + 1] = *reinterpret_cast<const uint32_t*>(b + xo);
+                    w[dz * 3 + 2] = *reinterpret_cast<const uint32_t*>(b + xpo);
+                } else {
+                    w[dz * 3 + 0] = kNone; w[dz * 3 + 1] = kNone; w[dz * 3 + 2] = kNone;
                 }
-            } else {
-                eval(c[q * 3 + 0], hasM & rv[q]);
-                if (q != 4) eval(c[q * 3 + 1], rv[q]);
-                eval(c[q * 3 + 2], hasP & rv[q]);
+            }
+        };
+
+        // one chain step: window (wm, w0, wp) = rows (y-k, y, y+k); TY table of this row at `ty`
+        auto step = [&](int y, const char* ty, const uint32_t (&wm)[9], const uint32_t (&w0)[9], const uint32_t (&wp)[9]) {
+            uint32_t best = w0[4];
+            float bestd = INFINITY;
+            auto eval = [&](uint32_t id, bool ok) {
+#ifdef VP_EXP_NOLDS         /* timing experiment only: same VALU work, no table reads */
+                const float sx = __uint_as_float((id & 0xFFCu) | 0x3f800000u);
+                const float dy2 = __uint_as_float(((id >> 10) & 0xFFCu) | 0x3f800000u);
+                const float dz2 = __uint_as_float(((id >> 20) & 0xFFCu) | 0x3f800000u);
+#else
+                const float sx = *reinterpret_cast<const float*>(tx + (id & 0xFFCu));
+                const float dy2 = *reinterpret_cast<const float*>(ty + ((id >> 10) & 0xFFCu));
+                const float dz2 = *reinterpret_cast<const float*>(tz + ((id >> 20) & 0xFFCu));
+#endif
+                const float dxv = sx - px;
+                const float d = ((dxv * dxv) + dy2) + dz2;
+                bool take = ok & (d < bestd);
+                if (CHECK_NONE) take = take & (id != kNone);
+                bestd = take ? d : bestd;
+                best = take ? id : best;
+            };
+            auto cand = [&](uint32_t id, bool ok) {
+                if (SKIP) { if (__any(ok & (id != kNone))) eval(id, ok); }
+                else eval(id, ok);
+            };
+            eval(w0[4], true);                       // own state first: it wins ties (strict '<', sequential.cpp:106)
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {         // reference scan order: z, then y, then x (sequential.cpp:86-88)
+                cand(wm[dz * 3 + 0], hasM); cand(wm[dz * 3 + 1], true); cand(wm[dz * 3 + 2], hasP);
+                cand(w0[dz * 3 + 0], hasM); if (dz != 1) cand(w0[dz * 3 + 1], true); cand(w0[dz * 3 + 2], hasP);
+                cand(wp[dz * 3 + 0], hasM); cand(wp[dz * 3 + 1], true); cand(wp[dz * 3 + 2], hasP);
+            }
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out + ((size_t)zl * N + y) * N) + xo) = best;
+        };
+
+        uint32_t wa[9], wb[9], wc[9];
+        load_row(ybase - (int)k, wa);
+        load_row(ybase, wb);
+        // kChain = 4 steps, window registers rotate by renaming
+        load_row(ybase + (int)k, wc);
+        step(ybase, reinterpret_cast<const char*>(TY[0]), wa, wb, wc);
+        if (ybase + (int)k < N) {
+            load_row(ybase + 2 * (int)k, wa);
+            step(ybase + (int)k, reinterpret_cast<const char*>(TY[1]), wb, wc, wa);
+            if (ybase + 2 * (int)k < N) {
+                load_row(ybase + 3 * (int)k, wb);
+                step(ybase + 2 * (int)k, reinterpret_cast<const char*>(TY[2]), wc, wa, wb);
+                if (ybase + 3 * (int)k < N) {
+                    load_row(ybase + 4 * (int)k, wc);
+                    step(ybase + 3 * (int)k, reinterpret_cast<const char*>(TY[3]), wa, wb, wc);
+                }
             }
         }
-        orow[x] = best;
     }
 }
 
@@ -396,6 +449,36 @@ int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const 
     return 0;
 }
 
+// Plane processing order for step k: planes z, z+k, z+2k, ... back to back, so the three planes a
+// workgroup reads (z-k, z, z+k) were touched by the immediately preceding / following workgroups
+// and are served from L2 / Infinity Cache instead of HBM.  Cached per (n, slab, k) on the device.
+static int jfa_zorder(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t** out)
+{
+    const uint32_t nz = f.z1 - f.z0;
+    *out = nullptr;
+    if (k < 16 || k >= nz) return 0;                               // natural order already reuses / nothing to gain
+    if (ctx->zorder_n != f.n || ctx->zorder_z0 != f.z0 || ctx->zorder_z1 != f.z1) {
+        std::vector<uint32_t> host;
+        ctx->zorder_k.clear();
+        for (uint32_t kk = f.n / 2; kk >= 1; kk /= 2) {
+            if (kk < 16 || kk >= nz) continue;
+            ctx->zorder_k.push_back(kk);
+            for (uint32_t r = 0; r < kk; ++r)
+                for (uint32_t zg = f.z0; zg < f.z1; ++zg)
+                    if (zg % kk == r) host.push_back(zg - f.z0);
+        }
+        VP_TRY(reserve(ctx, ctx->zorder, std::max<size_t>(host.size(), 1) * 4));
+        if (!host.empty()) {
+            VP_HIP(hipMemcpyAsync(ctx->zorder.ptr, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            VP_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        ctx->zorder_n = f.n; ctx->zorder_z0 = f.z0; ctx->zorder_z1 = f.z1;
+    }
+    for (size_t i = 0; i < ctx->zorder_k.size(); ++i)
+        if (ctx->zorder_k[i] == k) { *out = (const uint32_t*)ctx->zorder.ptr + i * nz; return 0; }
+    return 0;
+}
+
 int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
                     const uint32_t* d_plus, uint32_t* d_out, int algo)
 {
@@ -406,13 +489,16 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_i
         hipLaunchKernelGGL(jfa_pass_direct, dim3(blocks), dim3(256), 0, ctx->stream, f, k, d_in, d_minus, d_plus, d_out);
     } else {
         if (f.n >= 256) {
-            // rows fall outside the grid for a sizeable share of the workgroups only while k is large
-            if (k * 8 >= f.n)
-                hipLaunchKernelGGL(jfa_pass_row<true>, dim3(f.n, f.z1 - f.z0), dim3(256), 0, ctx->stream, f, k, d_in, d_minus,
-                                   d_plus, d_out, (const uint32_t*)nullptr);
-            else
-                hipLaunchKernelGGL(jfa_pass_row<false>, dim3(f.n, f.z1 - f.z0), dim3(256), 0, ctx->stream, f, k, d_in, d_minus,
-                                   d_plus, d_out, (const uint32_t*)nullptr);
+            const uint32_t* zorder = nullptr;
+            VP_TRY(jfa_zorder(ctx, f, k, &zorder));
+            // early passes: large k => many rows outside the grid and a sparse state => wave-level skipping pays
+            const uint32_t chainLen = (f.n + k - 1) / k;                       // rows per residue class
+            const dim3 grid(k * ((chainLen + kChain - 1) / kChain), f.z1 - f.z0);
+            const bool skip = k * 4 >= f.n, chk = f.n >= 1024;
+#define VP_LAUNCH_CHAIN(S, C) hipLaunchKernelGGL((jfa_pass_chain<S, C>), grid, dim3(256), 0, ctx->stream, f, k, d_in, d_minus, d_plus, d_out, zorder)
+            if (skip) { if (chk) VP_LAUNCH_CHAIN(true, true); else VP_LAUNCH_CHAIN(true, false); }
+            else      { if (chk) VP_LAUNCH_CHAIN(false, true); else VP_LAUNCH_CHAIN(false, false); }
+#undef VP_LAUNCH_CHAIN
             VP_HIP(hipGetLastError());
             return 0;
         }

@@ -44,7 +44,10 @@ struct vp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only workspaces
-    vp::Buffer rec, tile_cnt, tile_off, tile_cur, pairs, scratch;
+    vp::Buffer rec, tile_cnt, tile_off, tile_cur, pairs, scratch, zorder;
+    // cached JFA plane orders (see jfa_zorder)
+    uint32_t zorder_n = 0, zorder_z0 = 0, zorder_z1 = 0;
+    std::vector<uint32_t> zorder_k;
     // profiling
     bool prof_on = false;
     std::vector<vp::ProfSpan> prof_pending;
