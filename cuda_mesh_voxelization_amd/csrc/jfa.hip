@@ -270,10 +270,12 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 //                 holds +inf, so a kNone candidate yields d = inf/NaN and loses without a compare.
 constexpr int kChain = 4;
 
+// launch_bounds: 5 waves/SIMD (<= 96 VGPRs) measured best -- 4 (99 VGPRs) is 6 % slower, 6 spills.
 template <bool SKIP, bool CHECK_NONE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 5)
 jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
-               const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, const uint32_t* __restrict__ zorder)
+               const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, const uint32_t* __restrict__ zorder,
+               const uint32_t* __restrict__ none_row)
 {
     __shared__ float PX[kTab];
     __shared__ float TZ[kTab];
@@ -334,7 +336,13 @@ jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
             const uint32_t ro = (uint32_t)(yin ? yy : 0) * rowBytes;
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz) {
-                if (yin && zv[dz]) {
+                if (!SKIP) {
+                    // branch-free: a row outside the grid reads from a row of kNone (uniform pointer select)
+                    const char* b = (yin && zv[dz]) ? zp[dz] + ro : reinterpret_cast<const char*>(none_row);
+                    w[dz * 3 + 0] = *reinterpret_cast<const uint32_t*>(b + xmo);
+                    w[dz * 3 + 1] = *reinterpret_cast<const uint32_t*>(b + xo);
+                    w[dz * 3 + 2] = *reinterpret_cast<const uint32_t*>(b + xpo);
+                } else if (yin && zv[dz]) {
                     const char* b = zp[dz] + ro;                   // uniform base; 32-bit lane offsets
                     w[dz * 3 + 0] = *reinterpret_cast<const uint32_t*>(b + xmo);
                     w[dz * 3 + 1] = *reinterpret_cast<const uint32_t*>(b + xo);
@@ -380,22 +388,23 @@ jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
             *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out + ((size_t)zl * N + y) * N) + xo) = best;
         };
 
-        uint32_t wa[9], wb[9], wc[9];
-        load_row(ybase - (int)k, wa);
+        // kChain = 4 steps over a 4-row register ring: the row needed by the NEXT step is requested
+        // before the current step is evaluated, so its latency hides behind ~270 VALU instructions.
+        uint32_t wa[9], wb[9], wc[9], wd[9];
+        const int K = (int)k;
+        load_row(ybase - K, wa);
         load_row(ybase, wb);
-        // kChain = 4 steps, window registers rotate by renaming
-        load_row(ybase + (int)k, wc);
+        load_row(ybase + K, wc);
+        load_row(ybase + 2 * K, wd);
         step(ybase, reinterpret_cast<const char*>(TY[0]), wa, wb, wc);
-        if (ybase + (int)k < N) {
-            load_row(ybase + 2 * (int)k, wa);
-            step(ybase + (int)k, reinterpret_cast<const char*>(TY[1]), wb, wc, wa);
-            if (ybase + 2 * (int)k < N) {
-                load_row(ybase + 3 * (int)k, wb);
-                step(ybase + 2 * (int)k, reinterpret_cast<const char*>(TY[2]), wc, wa, wb);
-                if (ybase + 3 * (int)k < N) {
-                    load_row(ybase + 4 * (int)k, wc);
-                    step(ybase + 3 * (int)k, reinterpret_cast<const char*>(TY[3]), wa, wb, wc);
-                }
+        if (ybase + K < N) {
+            load_row(ybase + 3 * K, wa);
+            step(ybase + K, reinterpret_cast<const char*>(TY[1]), wb, wc, wd);
+            if (ybase + 2 * K < N) {
+                load_row(ybase + 4 * K, wb);
+                step(ybase + 2 * K, reinterpret_cast<const char*>(TY[2]), wc, wd, wa);
+                if (ybase + 3 * K < N)
+                    step(ybase + 3 * K, reinterpret_cast<const char*>(TY[3]), wd, wa, wb);
             }
         }
     }
@@ -492,10 +501,15 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_i
             const uint32_t* zorder = nullptr;
             VP_TRY(jfa_zorder(ctx, f, k, &zorder));
             // early passes: large k => many rows outside the grid and a sparse state => wave-level skipping pays
+            if (!ctx->none_row.ptr) {                                             // a row of kNone for out-of-grid reads
+                VP_TRY(reserve(ctx, ctx->none_row, kTab * sizeof(uint32_t)));
+                VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, kTab * sizeof(uint32_t), ctx->stream));
+            }
+            const uint32_t* none_row = (const uint32_t*)ctx->none_row.ptr;
             const uint32_t chainLen = (f.n + k - 1) / k;                       // rows per residue class
             const dim3 grid(k * ((chainLen + kChain - 1) / kChain), f.z1 - f.z0);
             const bool skip = k * 4 >= f.n, chk = f.n >= 1024;
-#define VP_LAUNCH_CHAIN(S, C) hipLaunchKernelGGL((jfa_pass_chain<S, C>), grid, dim3(256), 0, ctx->stream, f, k, d_in, d_minus, d_plus, d_out, zorder)
+#define VP_LAUNCH_CHAIN(S, C) hipLaunchKernelGGL((jfa_pass_chain<S, C>), grid, dim3(256), 0, ctx->stream, f, k, d_in, d_minus, d_plus, d_out, zorder, none_row)
             if (skip) { if (chk) VP_LAUNCH_CHAIN(true, true); else VP_LAUNCH_CHAIN(true, false); }
             else      { if (chk) VP_LAUNCH_CHAIN(false, true); else VP_LAUNCH_CHAIN(false, false); }
 #undef VP_LAUNCH_CHAIN

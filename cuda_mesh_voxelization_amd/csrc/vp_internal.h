@@ -44,7 +44,7 @@ struct vp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only workspaces
-    vp::Buffer rec, tile_cnt, tile_off, tile_cur, pairs, scratch, zorder;
+    vp::Buffer rec, tile_cnt, tile_off, tile_cur, pairs, scratch, zorder, none_row;
     // cached JFA plane orders (see jfa_zorder)
     uint32_t zorder_n = 0, zorder_z0 = 0, zorder_z1 = 0;
     std::vector<uint32_t> zorder_k;
