@@ -6,17 +6,22 @@
 // at startX and a prefix-XOR along X afterwards fills the rows -- the same map, because XOR is
 // associative and commutative.
 //
-// TILED (reference: vox/tiled.cu:14-576, re-designed):
+// TILED (reference: vox/tiled.cu:14-576, re-designed as a hybrid):
 //   vox_setup    one thread per triangle: per-triangle record with the reference's float
-//                expressions (sign, edge deltas, plane A,B,C,D, clamped y/z voxel ranges) and a
-//                histogram of the 8x8-column YZ tiles its range overlaps.
+//                expressions (sign, edge deltas, plane A,B,C,D, clamped y/z voxel ranges).
+//                SMALL triangles (<= kSmallCells columns in their y/z range -- almost every triangle
+//                of a fine mesh) are rasterised right here: one atomicXor per covered column into
+//                the toggle grid, no binning at all.  LARGE triangles get their record stored and
+//                are counted into the 8x8-column YZ tiles their range overlaps.
 //   vox_scan     exclusive scan of the tile histogram (one workgroup).
-//   vox_scatter  per-tile triangle lists (order inside a tile is irrelevant: XOR commutes).
-//   vox_tile     one 256-thread workgroup per tile.  A tile OWNS its 64 x-rows, so toggles go
-//                to an LDS bit-row buffer with ds_xor (no global atomics); triangle records are
-//                staged through LDS in batches; lane = (y,z) column of the tile, wave = triangle
-//                slice.  The prefix-XOR runs in LDS and the finished rows leave as coalesced
-//                16-byte stores (8 consecutive y-rows of one z are contiguous in the grid).
+//   vox_scatter  per-tile lists of large triangles (order inside a tile is irrelevant: XOR commutes).
+//   vox_tile     one 256-thread workgroup per tile.  A tile OWNS its 64 x-rows: they are brought
+//                into an LDS bit-row buffer (coalesced), the tile's large triangles toggle bits
+//                there with ds_xor (no global atomics; records staged through LDS in batches; lane =
+//                (y,z) column, wave = triangle slice), the prefix-XOR runs in LDS and the finished
+//                rows leave as coalesced 16-byte stores (8 consecutive y-rows of one z are contiguous).
+//                When a mesh has no large triangle the tile stage is replaced by the streaming
+//                vox_fill kernel.
 // NAIVE (reference: vox/naive.cu:12-122): one thread per triangle toggling single bits with
 //   global atomicXor, then vox_fill streams the grid once doing the prefix-XOR per row.
 //
@@ -132,9 +137,11 @@ __device__ __forceinline__ void for_each_tile(bool valid, uint32_t t, int ty0, i
 }
 
 // ---------------------------------------------------------------------------------------------
+constexpr int kSmallCells = 16;   // triangles whose y/z voxel range holds at most this many columns skip the binning
+
 __global__ void __launch_bounds__(256)
 vox_setup(Frame f, const float* __restrict__ xyz, size_t nverts, const uint32_t* __restrict__ tri, size_t ntris,
-          uint4* __restrict__ rec, uint32_t* __restrict__ tile_cnt)
+          uint4* __restrict__ rec, uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ toggles)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int tilesY = f.n / kTile;
@@ -142,19 +149,35 @@ vox_setup(Frame f, const float* __restrict__ xyz, size_t nverts, const uint32_t*
     float r[16];
     int sy = 0, ey = 0, sz = 0, ez = 0;
     bool valid = false;
-    if (t < ntris) {
-        valid = make_record(f, xyz, nverts, tri, t, r, sy, ey, sz, ez);
-        if (!valid) { sy = ey = sz = ez = 0; for (int i = 0; i < 16; ++i) r[i] = 0.0f; }
-        uint4* dst = rec + t * 5;
-        dst[0] = make_uint4(__float_as_uint(r[0]),  __float_as_uint(r[1]),  __float_as_uint(r[2]),  __float_as_uint(r[3]));
-        dst[1] = make_uint4(__float_as_uint(r[4]),  __float_as_uint(r[5]),  __float_as_uint(r[6]),  __float_as_uint(r[7]));
-        dst[2] = make_uint4(__float_as_uint(r[8]),  __float_as_uint(r[9]),  __float_as_uint(r[10]), __float_as_uint(r[11]));
-        dst[3] = make_uint4(__float_as_uint(r[12]), __float_as_uint(r[13]), __float_as_uint(r[14]), __float_as_uint(r[15]));
-        dst[4] = make_uint4((uint32_t)sy | ((uint32_t)ey << 16), (uint32_t)sz | ((uint32_t)ez << 16), (uint32_t)t, 0u);
+    if (t < ntris) valid = make_record(f, xyz, nverts, tri, t, r, sy, ey, sz, ez);
+    const int ny = ey - sy, cells = valid ? ny * (ez - sz) : 0;
+    const bool small = cells <= kSmallCells;
+    if (valid && small) {
+        for (int i = 0; i < cells; ++i) {                         // same columns, same tests as the tile kernel
+            const int y = sy + i % ny, z = sz + i / ny;
+            int sx;
+            if (column_hit(r, centre(f.oy, y, f.vs), centre(f.oz, z, f.vs), f.ox, f.vs, (int)f.n, sx)) {
+                const size_t row = ((size_t)(z - (int)f.z0) * f.n + (size_t)y) * f.w;
+                atomicXor(&toggles[row + (sx >> 5)], 1u << (sx & 31));
+            }
+        }
     }
-    const int ty0 = sy / kTile, ty1 = valid ? (ey - 1) / kTile : 0;
-    const int tz0 = sz / kTile, tz1 = valid ? (ez - 1) / kTile : 0;
-    for_each_tile(valid, (uint32_t)t, ty0, ty1, tz0, tz1, [&](uint32_t, int ty, int tz) {
+    const bool big = valid && !small;
+    if (t < ntris) {
+        uint4* dst = rec + t * 5;
+        if (big) {
+            dst[0] = make_uint4(__float_as_uint(r[0]),  __float_as_uint(r[1]),  __float_as_uint(r[2]),  __float_as_uint(r[3]));
+            dst[1] = make_uint4(__float_as_uint(r[4]),  __float_as_uint(r[5]),  __float_as_uint(r[6]),  __float_as_uint(r[7]));
+            dst[2] = make_uint4(__float_as_uint(r[8]),  __float_as_uint(r[9]),  __float_as_uint(r[10]), __float_as_uint(r[11]));
+            dst[3] = make_uint4(__float_as_uint(r[12]), __float_as_uint(r[13]), __float_as_uint(r[14]), __float_as_uint(r[15]));
+            dst[4] = make_uint4((uint32_t)sy | ((uint32_t)ey << 16), (uint32_t)sz | ((uint32_t)ez << 16), (uint32_t)t, 0u);
+        } else {
+            dst[4] = make_uint4(0u, 0u, (uint32_t)t, 0u);         // empty range: vox_scatter skips it
+        }
+    }
+    const int ty0 = sy / kTile, ty1 = big ? (ey - 1) / kTile : 0;
+    const int tz0 = sz / kTile, tz1 = big ? (ez - 1) / kTile : 0;
+    for_each_tile(big, (uint32_t)t, ty0, ty1, tz0, tz1, [&](uint32_t, int ty, int tz) {
         atomicAdd(&tile_cnt[(tz - tzBase) * tilesY + ty], 1u);
     });
 }
@@ -206,10 +229,12 @@ vox_scatter(Frame f, const uint4* __restrict__ rec, size_t ntris, uint32_t* __re
 constexpr int kBatch = 64;        // triangle records staged in LDS per round
 constexpr int kMaxW = 32;         // words per x-row at n = 1024
 
+// tog: toggle grid written by vox_setup (small triangles); dst: output grid.  !ACC: dst = fill(tog ^
+// tile toggles), tog may alias dst.  ACC: dst ^= fill(...), tog is a separate scratch grid.
 template <bool ACC>
 __global__ void __launch_bounds__(256)
 vox_tile(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ off,
-         const uint32_t* __restrict__ pairs, uint32_t* __restrict__ words)
+         const uint32_t* __restrict__ pairs, const uint32_t* tog, uint32_t* words)
 {
     __shared__ uint32_t acc[64 * (kMaxW + 1)];
     __shared__ uint4 srec[kBatch * 5];
@@ -226,17 +251,11 @@ vox_tile(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ of
     const size_t base = ((size_t)(tzl * kTile) * f.n + (size_t)ty * kTile) * W;
     const size_t planeStride = (size_t)f.n * W;
 
-    if (begin == end) {                                           // empty tile: rows are all zero
-        if (!ACC) {
-            for (int i = tid; i < rowWords; i += 256) {
-                const int r = i / W, w = i - r * W;
-                words[base + (size_t)(r >> 3) * planeStride + (size_t)(r & 7) * W + w] = 0u;
-            }
-        }
-        return;
+    // bring the tile's rows of the toggle grid into LDS (row r = lz*8+ly; 8 rows of one lz are contiguous)
+    for (int i = tid; i < rowWords; i += 256) {
+        const int r = i / W, w = i - r * W;
+        acc[r * stride + w] = tog[base + (size_t)(r >> 3) * planeStride + (size_t)(r & 7) * W + w];
     }
-
-    for (int i = tid; i < 64 * stride; i += 256) acc[i] = 0u;
 
     const int y = ty * kTile + (lane & 7);
     const int z = (int)f.z0 + tzl * kTile + (lane >> 3);
@@ -390,50 +409,60 @@ vox_fill_row(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+// dst = (accumulate ? dst : 0) ^ prefix-XOR-along-x(tog); tog may alias dst when !accumulate.
+static int launch_fill(vp_ctx* ctx, const Frame& f, const uint32_t* tog, uint32_t* d_words, int accumulate)
+{
+    hipStream_t st = ctx->stream;
+    const size_t nz = f.z1 - f.z0;
+    const size_t nwords = (size_t)f.n * f.n * nz / 32;
+    const size_t nrows = (size_t)f.n * nz;
+    ProfScope p(ctx, VP_K_VOX_FILL);
+    const int W = f.w;
+    const bool vec = (W % 4 == 0) && ((W / 4) & (W / 4 - 1)) == 0 && (W / 4) <= 64;
+    if (vec) {
+        const size_t nvec = nwords / 4;
+        const unsigned blocks = (unsigned)std::min<size_t>((nvec + 255) / 256, 256 * 16);
+        if (accumulate)
+            hipLaunchKernelGGL(vox_fill_vec<true>, dim3(blocks), dim3(256), 0, st, (const uint4*)tog, (uint4*)d_words, nvec, W / 4);
+        else
+            hipLaunchKernelGGL(vox_fill_vec<false>, dim3(blocks), dim3(256), 0, st, (const uint4*)tog, (uint4*)d_words, nvec, W / 4);
+    } else {
+        const unsigned blocks = (unsigned)((nrows + 255) / 256);
+        if (accumulate)
+            hipLaunchKernelGGL(vox_fill_row<true>, dim3(blocks), dim3(256), 0, st, tog, d_words, nrows, W);
+        else
+            hipLaunchKernelGGL(vox_fill_row<false>, dim3(blocks), dim3(256), 0, st, tog, d_words, nrows, W);
+    }
+    return 0;
+}
+
 int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float* d_xyz, size_t nverts,
                     const uint32_t* d_tri, size_t ntris, int algo, int accumulate)
 {
     hipStream_t st = ctx->stream;
     const size_t nz = f.z1 - f.z0;
     const size_t nwords = (size_t)f.n * f.n * nz / 32;
-    const size_t nrows = (size_t)f.n * nz;
     const unsigned tblocks = (unsigned)((ntris + 255) / 256);
 
+    // toggle grid: the output itself, or a scratch grid when the result is XORed into existing content
+    uint32_t* tog = d_words;
+    if (accumulate) {
+        VP_TRY(reserve(ctx, ctx->scratch, nwords * 4));
+        tog = (uint32_t*)ctx->scratch.ptr;
+    }
+    VP_HIP(hipMemsetAsync(tog, 0, nwords * 4, st));
+
     if (algo == VP_ALGO_NAIVE) {
-        uint32_t* tog = d_words;
-        if (accumulate) {
-            VP_TRY(reserve(ctx, ctx->scratch, nwords * 4));
-            tog = (uint32_t*)ctx->scratch.ptr;
-        }
-        VP_HIP(hipMemsetAsync(tog, 0, nwords * 4, st));
         if (ntris) {
             ProfScope p(ctx, VP_K_VOX_NAIVE);
             hipLaunchKernelGGL(vox_naive, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, tog);
         }
-        {
-            ProfScope p(ctx, VP_K_VOX_FILL);
-            const int W = f.w;
-            const bool vec = (W % 4 == 0) && ((W / 4) & (W / 4 - 1)) == 0 && (W / 4) <= 64;
-            if (vec) {
-                const size_t nvec = nwords / 4;
-                const unsigned blocks = (unsigned)std::min<size_t>((nvec + 255) / 256, 256 * 16);
-                if (accumulate)
-                    hipLaunchKernelGGL(vox_fill_vec<true>, dim3(blocks), dim3(256), 0, st, (const uint4*)tog, (uint4*)d_words, nvec, W / 4);
-                else
-                    hipLaunchKernelGGL(vox_fill_vec<false>, dim3(blocks), dim3(256), 0, st, (const uint4*)tog, (uint4*)d_words, nvec, W / 4);
-            } else {
-                const unsigned blocks = (unsigned)((nrows + 255) / 256);
-                if (accumulate)
-                    hipLaunchKernelGGL(vox_fill_row<true>, dim3(blocks), dim3(256), 0, st, tog, d_words, nrows, W);
-                else
-                    hipLaunchKernelGGL(vox_fill_row<false>, dim3(blocks), dim3(256), 0, st, tog, d_words, nrows, W);
-            }
-        }
+        VP_TRY(launch_fill(ctx, f, tog, d_words, accumulate));
         VP_HIP(hipGetLastError());
         return 0;
     }
 
-    // ---- TILED ----
+    // ---- TILED (hybrid) ----
     const uint32_t tilesY = f.n / kTile;
     const uint32_t numTiles = tilesY * (uint32_t)(nz / kTile);
     VP_TRY(reserve(ctx, ctx->rec, std::max<size_t>(ntris, 1) * kRecDwords * 4));
@@ -445,30 +474,38 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
     uint32_t* off = (uint32_t*)ctx->tile_off.ptr;
     uint32_t* cur = (uint32_t*)ctx->tile_cur.ptr;
 
-    VP_HIP(hipMemsetAsync(cnt, 0, (size_t)numTiles * 4, st));
+    uint32_t total = 0;
     if (ntris) {
-        ProfScope p(ctx, VP_K_VOX_SETUP);
-        hipLaunchKernelGGL(vox_setup, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, rec, cnt);
+        VP_HIP(hipMemsetAsync(cnt, 0, (size_t)numTiles * 4, st));
+        {
+            ProfScope p(ctx, VP_K_VOX_SETUP);
+            hipLaunchKernelGGL(vox_setup, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, rec, cnt, tog);
+        }
+        {
+            ProfScope p(ctx, VP_K_VOX_SCAN);
+            hipLaunchKernelGGL(vox_scan, dim3(1), dim3(1024), 0, st, cnt, numTiles, off, cur);
+        }
+        // size of the large-triangle work queue: one 4-byte read-back (0 for fine meshes)
+        VP_HIP(hipMemcpyAsync(&total, off + numTiles, 4, hipMemcpyDeviceToHost, st));
+        VP_HIP(hipStreamSynchronize(st));
     }
-    {
-        ProfScope p(ctx, VP_K_VOX_SCAN);
-        hipLaunchKernelGGL(vox_scan, dim3(1), dim3(1024), 0, st, cnt, numTiles, off, cur);
+    if (total == 0) {                                              // nothing binned: plain streaming fill
+        VP_TRY(launch_fill(ctx, f, tog, d_words, accumulate));
+        VP_HIP(hipGetLastError());
+        return 0;
     }
-    uint32_t total = 0;                                            // work-queue size: one 4-byte read-back
-    VP_HIP(hipMemcpyAsync(&total, off + numTiles, 4, hipMemcpyDeviceToHost, st));
-    VP_HIP(hipStreamSynchronize(st));
-    VP_TRY(reserve(ctx, ctx->pairs, std::max<size_t>(total, 1) * 4));
+    VP_TRY(reserve(ctx, ctx->pairs, (size_t)total * 4));
     uint32_t* pairs = (uint32_t*)ctx->pairs.ptr;
-    if (ntris && total) {
+    {
         ProfScope p(ctx, VP_K_VOX_SCATTER);
         hipLaunchKernelGGL(vox_scatter, dim3(tblocks), dim3(256), 0, st, f, rec, ntris, cur, pairs, total);
     }
     {
         ProfScope p(ctx, VP_K_VOX_TILE);
         if (accumulate)
-            hipLaunchKernelGGL(vox_tile<true>, dim3(numTiles), dim3(256), 0, st, f, rec, off, pairs, d_words);
+            hipLaunchKernelGGL(vox_tile<true>, dim3(numTiles), dim3(256), 0, st, f, rec, off, pairs, tog, d_words);
         else
-            hipLaunchKernelGGL(vox_tile<false>, dim3(numTiles), dim3(256), 0, st, f, rec, off, pairs, d_words);
+            hipLaunchKernelGGL(vox_tile<false>, dim3(numTiles), dim3(256), 0, st, f, rec, off, pairs, tog, d_words);
     }
     VP_HIP(hipGetLastError());
     return 0;
