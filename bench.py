@@ -101,8 +101,8 @@ def main():
             eng.voxelize(frame, d_xyz, d_tri, out=grid, algo=ALGO_TILED)
             eng.jfa(frame, grid, out=sdf, algo=ALGO_TILED)
     else:
-        from cuda_mesh_voxelization_amd.slab import SlabPipeline
-        pipe = SlabPipeline(eng, frame, rank, world, dist)
+        from cuda_mesh_voxelization_amd.slab import HipSlabBackend, SlabPipeline
+        pipe = SlabPipeline(HipSlabBackend(eng), frame, rank, world, dist)
 
         def step():
             pipe.voxelize(d_xyz, d_tri, algo=ALGO_TILED)

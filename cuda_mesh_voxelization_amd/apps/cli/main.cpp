@@ -1,0 +1,226 @@
+// cli -- command-line front end with the flags and the flow of the reference's apps/cli
+// (/root/reference/apps/cli/main.cpp:21-235): load meshes -> one frame over all of them -> voxelize
+// each -> CSG into grid 0 -> optional JFA sdf.  Timer lines "[Label]: <ms> ms" keep the grammar the
+// reference's benchmark script parses (scripts/benchmarks.py:74-95).
+//
+//   cli [flags] a.obj [b.obj ...]
+//     -n, --num-voxels N     voxels per side (default 32)
+//     -t, --type T           0 sequential, 1 naive (GPU), 2 tiled (GPU, default), 3 openmp
+//     -p, --operation P      CSG: 0 none, 1 union, 2 intersection, 3 difference
+//     -s, --sdf              compute the signed (squared) distance field of grid 0
+//     -b, --block-size B     tiled block size hint (multiple of 16; accepted for compatibility)
+//     -m, --benckmark M      iterations; M > 1 = benchmark mode (mesh 0 only, CSG against an empty grid)
+//     -o, --output NAME      output name (default out.obj)
+//     -e, --export           export phases as OBJ (not built in this round: prints a notice)
+//     -d, --dump PREFIX      (extension) write PREFIX.grid.u32 and PREFIX.sdf.f32 raw little-endian dumps
+//     -h, --help
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <span>
+#include <string>
+#include <vector>
+
+#include "bounding_box.h"
+#include "csg/csg.h"
+#include "debug_utils.h"
+#include "grid/voxels_grid.h"
+#include "jfa/jfa.h"
+#include "mesh/mesh.h"
+#include "mesh/mesh_io.h"
+#include "proc_utils.h"
+#include "vox/vox.h"
+
+using gridType = uint32_t;
+
+namespace {
+
+struct Options {
+    std::vector<std::string> filenames;
+    unsigned numVoxels = 32;
+    int type = 2;
+    std::string output = "out.obj";
+    int operation = 0;
+    bool doExport = false;
+    bool sdf = false;
+    unsigned blockSize = 32;
+    unsigned iterations = 1;
+    std::string dump;
+    bool help = false;
+};
+
+const char* kUsage =
+    "CLI apps to test csg voxelization\nUsage:\n  cli [OPTION...] filenames...\n\n"
+    "  -n, --num-voxels arg  Number of voxel per side (default: 32)\n"
+    "  -t, --type arg        Type of processing (0 = sequential, 1 = naive, 2 = tiled, 3 = openmp) (default: 2)\n"
+    "  -o, --output arg      Output filename (default: out.obj)\n"
+    "  -p, --operation arg   CSG Operations (1 = union, 2 = inter, 3 = diff) (default: 0)\n"
+    "  -e, --export          Exports the phases\n"
+    "  -s, --sdf             Active SDF calculation on output file\n"
+    "  -b, --block-size arg  Number of thread in block to process tiled voxelization (default: 32)\n"
+    "  -m, --benckmark arg   Number of iteration in benckmark mode (if not present benckmark are off) (default: 1)\n"
+    "  -d, --dump arg        Write raw dumps <arg>.grid.u32 / <arg>.sdf.f32 (extension)\n"
+    "  -h, --help            Print usage\n";
+
+// Minimal getopt-style parser: -x V, -xV, --long V, --long=V, boolean switches, positionals.
+Options Parse(int argc, char** argv)
+{
+    static const std::map<std::string, char> longNames = {
+        {"filenames", 'i'}, {"num-voxels", 'n'}, {"type", 't'}, {"output", 'o'}, {"operation", 'p'}, {"export", 'e'},
+        {"sdf", 's'}, {"block-size", 'b'}, {"benckmark", 'm'}, {"benchmark", 'm'}, {"dump", 'd'}, {"help", 'h'}};
+    Options o;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        char key = 0;
+        std::string value;
+        bool hasValue = false;
+        if (a.rfind("--", 0) == 0) {
+            std::string name = a.substr(2);
+            const size_t eq = name.find('=');
+            if (eq != std::string::npos) { value = name.substr(eq + 1); name = name.substr(0, eq); hasValue = true; }
+            const auto it = longNames.find(name);
+            cpuAssert(it != longNames.end(), "Unknown option --" + name + "\n");
+            key = it->second;
+        } else if (a.size() >= 2 && a[0] == '-' && !std::isdigit(static_cast<unsigned char>(a[1]))) {
+            key = a[1];
+            if (a.size() > 2) { value = a.substr(2); hasValue = true; }
+        } else {
+            o.filenames.push_back(a);
+            continue;
+        }
+        const bool isSwitch = key == 'e' || key == 's' || key == 'h';
+        if (isSwitch) {
+            const bool v = !hasValue || value == "true" || value == "1";
+            if (key == 'e') o.doExport = v; else if (key == 's') o.sdf = v; else o.help = v;
+            continue;
+        }
+        if (!hasValue) {
+            cpuAssert(i + 1 < argc, std::string("Option -") + key + " needs a value\n");
+            value = argv[++i];
+        }
+        switch (key) {
+            case 'i': o.filenames.push_back(value); break;
+            case 'n': o.numVoxels = static_cast<unsigned>(std::stoul(value)); break;
+            case 't': o.type = std::stoi(value); break;
+            case 'o': o.output = value; break;
+            case 'p': o.operation = std::stoi(value); break;
+            case 'b': o.blockSize = static_cast<unsigned>(std::stoul(value)); break;
+            case 'm': o.iterations = static_cast<unsigned>(std::stoul(value)); break;
+            case 'd': o.dump = value; break;
+            default: cpuAssert(false, std::string("Unknown option -") + key + "\n");
+        }
+    }
+    return o;
+}
+
+template <Types T>
+void Voxelize(unsigned blockSize, HostVoxelsGrid<gridType>& grid, const Mesh& mesh)
+{
+    if constexpr (T == Types::TILED) VOX::Compute<Types::TILED>(blockSize, grid, mesh);
+    else VOX::Compute<T>(grid, mesh);
+}
+
+template <Types T>
+void Csg(CSG::Op op, HostVoxelsGrid<gridType>& a, HostVoxelsGrid<gridType>& b)
+{
+    switch (op) {
+        case CSG::Op::UNION:        CSG::Compute<T>(a, b, CSG::Union<gridType>()); break;
+        case CSG::Op::INTERSECTION: CSG::Compute<T>(a, b, CSG::Intersection<gridType>()); break;
+        case CSG::Op::DIFFERENCE:   CSG::Compute<T>(a, b, CSG::Difference<gridType>()); break;
+        case CSG::Op::VOID:         break;
+    }
+}
+
+void WriteRaw(const std::string& path, const void* data, size_t bytes)
+{
+    std::FILE* f = std::fopen(path.c_str(), "wb");
+    cpuAssert(f != nullptr, "Cannot open " + path + "\n");
+    cpuAssert(std::fwrite(data, 1, bytes, f) == bytes, "Short write on " + path + "\n");
+    std::fclose(f);
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    cpuAssert(argc >= 2, "Need [input file]\n");
+    const Options opt = Parse(argc, argv);
+    if (opt.help) { std::printf("%s", kUsage); return 0; }
+    cpuAssert(!opt.filenames.empty(), "Need [input filename]");
+    cpuAssert(opt.type >= 0 && opt.type <= 3, "Type must be 0..3");
+    cpuAssert(opt.operation >= 0 && opt.operation <= 3, "Operation must be 0..3");
+    cpuAssert(opt.blockSize % 16 == 0, "Thread per voxel must be a multiple of 16");
+
+    const Types TYPE = static_cast<Types>(opt.type);
+    const CSG::Op OPERATION = static_cast<CSG::Op>(opt.operation);
+    const unsigned N = opt.numVoxels;
+    const bool BENCHMARK = opt.iterations > 1;
+    const bool EXPORT = !BENCHMARK && opt.doExport;
+
+    std::vector<Mesh> meshes(opt.filenames.size());
+    std::vector<HostVoxelsGrid<gridType>> grids(opt.filenames.size());
+
+    // one frame over the vertices of all meshes, so that CSG operands are aligned (main.cpp:65-87)
+    float originX, originY, originZ, voxelSize;
+    {
+        std::vector<Position> all;
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            cpuAssert(ImportMesh(opt.filenames[i], meshes[i]), "Error in " + opt.filenames[i] + " import");
+            all.insert(all.end(), meshes[i].Coords.begin(), meshes[i].Coords.end());
+        }
+        cpuAssert(!all.empty(), "No vertices in the input");
+        MinMax bx, by, bz;
+        const float side = CalculateBoundingBox(std::span<const Position>(all.data(), all.size()), bx, by, bz);
+        originX = bx.first; originY = by.first; originZ = bz.first;
+        voxelSize = side / N;
+    }
+
+    HostVoxelsGrid<gridType> emptyGrid(N, voxelSize);       // benchmark-mode CSG operand (main.cpp:89,127)
+    HostGrid<float> sdf;
+
+    for (unsigned iter = 0; iter < opt.iterations; ++iter) {
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            HostVoxelsGrid<gridType>& grid = grids[i];
+            grid = HostVoxelsGrid<gridType>(N, voxelSize);
+            grid.View().SetOrigin(originX, originY, originZ);
+            switch (TYPE) {
+                case Types::SEQUENTIAL:
+                case Types::OPENMP: Voxelize<Types::SEQUENTIAL>(opt.blockSize, grid, meshes[i]); break;   // main.cpp:99-103
+                case Types::NAIVE:  Voxelize<Types::NAIVE>(opt.blockSize, grid, meshes[i]); break;
+                case Types::TILED:  Voxelize<Types::TILED>(opt.blockSize, grid, meshes[i]); break;
+            }
+            if (i > 0 || BENCHMARK) {
+                HostVoxelsGrid<gridType>& operand = BENCHMARK ? emptyGrid : grid;
+                switch (TYPE) {
+                    case Types::SEQUENTIAL: Csg<Types::SEQUENTIAL>(OPERATION, grids[0], operand); break;
+                    case Types::OPENMP:     Csg<Types::OPENMP>(OPERATION, grids[0], operand); break;
+                    case Types::NAIVE:
+                    case Types::TILED:      Csg<Types::NAIVE>(OPERATION, grids[0], operand); break;       // main.cpp:167-185
+                }
+            }
+            if (BENCHMARK) break;
+        }
+
+        if (opt.sdf) {
+            sdf = HostGrid<float>(N, -INFINITY);                                                        // main.cpp:200
+            switch (TYPE) {
+                case Types::SEQUENTIAL: JFA::Compute<Types::SEQUENTIAL>(grids[0], sdf); break;
+                case Types::OPENMP:     JFA::Compute<Types::OPENMP>(grids[0], sdf); break;
+                case Types::NAIVE:      JFA::Compute<Types::NAIVE>(grids[0], sdf); break;
+                case Types::TILED:      JFA::Compute<Types::TILED>(grids[0], sdf); break;
+            }
+        }
+    }
+
+    if (EXPORT)
+        std::printf("export (-e) of grid meshes / point clouds is not part of this build (see DESIGN.md, out of scope rows)\n");
+
+    if (!opt.dump.empty()) {
+        WriteRaw(opt.dump + ".grid.u32", grids[0].View().Data(), grids[0].View().StorageSize() * sizeof(gridType));
+        if (opt.sdf) WriteRaw(opt.dump + ".sdf.f32", sdf.View().Data(), sdf.View().Size() * sizeof(float));
+    }
+    return 0;
+}

@@ -1,0 +1,172 @@
+"""Z-slab sharding of one n^3 job over the GPUs of a node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI) point-to-point halo exchange between JFA steps.
+
+The reference is single-GPU; this is the multi-GPU extension the north star
+asks for.  Rank r owns the planes [r*nz, (r+1)*nz), nz = n / world.
+
+  voxelize   every (y,z) column is independent (vox/sequential.cpp:40-57): each rank rasterises the
+             whole (small) mesh into its own slab -- no exchange.
+  CSG        word-wise -- no exchange.
+  JFA init   26-neighbourhood -> one bitmask plane from each Z-neighbour.
+  JFA pass k voxel z reads planes z-k, z, z+k -> before the pass every rank receives the id planes
+             [z0-k, min(z0, z1-k)) and [max(z1, z0+k), z1+k) from whoever owns them (for k >= nz
+             these are whole slabs of ranks r -+ k/nz), as one batch of isend/irecv.
+  finalize   local.
+
+Every stage is a pure function of the previous buffers, so the concatenated slabs are bit-identical
+to the single-GPU result for any world size -- that is the parity test (tests/test_slab_*.py).
+
+The compute backend is pluggable only so that the exchange logic can be exercised on CPU with gloo
+in the test-suite; the product backend (HipSlabBackend) calls libvphip.so and nothing else.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .capi import ALGO_TILED, Frame
+
+
+class HipSlabBackend:
+    """Product backend: torch CUDA tensors for memory, libvphip.so (via Engine.ctx) for compute."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.ctx = engine.ctx
+        self.device = engine.device
+
+    def empty_u32(self, n):
+        return torch.empty(int(n), dtype=torch.int32, device=self.device)
+
+    def empty_f32(self, n):
+        return torch.empty(int(n), dtype=torch.float32, device=self.device)
+
+    @staticmethod
+    def _p(t):
+        return t.data_ptr() if t is not None else None
+
+    def voxelize(self, frame, words, d_xyz, d_tri, algo):
+        self.ctx.voxelize(frame, words.data_ptr(), d_xyz.data_ptr(), d_xyz.shape[0], d_tri.data_ptr(), d_tri.shape[0], algo, False)
+
+    def csg(self, a, b, op):
+        self.ctx.csg(a.data_ptr(), b.data_ptr(), a.numel(), op)
+
+    def jfa_init(self, frame, words, below, above, ids):
+        self.ctx.jfa_init(frame, words.data_ptr(), self._p(below), self._p(above), ids.data_ptr())
+
+    def jfa_pass(self, frame, k, src, minus, plus, dst, algo):
+        self.ctx.jfa_pass(frame, k, src.data_ptr(), self._p(minus), self._p(plus), dst.data_ptr(), algo)
+
+    def jfa_finalize(self, frame, words, ids, fill, sdf):
+        self.ctx.jfa_finalize(frame, words.data_ptr(), ids.data_ptr(), fill, sdf.data_ptr())
+
+
+def slab_range(n: int, rank: int, world: int):
+    if n % world != 0 or (n // world) % 8 != 0:
+        raise ValueError("n=%d cannot be cut into %d Z-slabs of a multiple of 8 planes" % (n, world))
+    nz = n // world
+    return rank * nz, (rank + 1) * nz
+
+
+def halo_plan(n: int, world: int, k: int):
+    """For step k: list of (src_rank, dst_rank, side, g0, g1) = dst needs global planes [g0, g1) owned
+    by src, for its 'minus' or 'plus' buffer.  Deterministic and identical on every rank."""
+    nz = n // world
+    plan = []
+    for dst in range(world):
+        z0, z1 = dst * nz, (dst + 1) * nz
+        regions = (("minus", max(z0 - k, 0), min(z0, z1 - k)), ("plus", max(z1, z0 + k), min(z1 + k, n)))
+        for side, a, b in regions:
+            g = a
+            while g < b:
+                src = g // nz
+                e = min(b, (src + 1) * nz)
+                plan.append((src, dst, side, g, e))
+                g = e
+    return plan
+
+
+class SlabPipeline:
+    """voxelize -> (CSG) -> JFA for the slab of this rank."""
+
+    def __init__(self, backend, frame: Frame, rank: int, world: int, dist):
+        self.be = backend
+        self.dist = dist
+        self.rank, self.world = rank, world
+        self.global_frame = frame
+        self.z0, self.z1 = slab_range(frame.n, rank, world)
+        self.frame = frame.slab(self.z0, self.z1)
+        n = frame.n
+        self.plane_ids = n * n                    # ids per plane
+        self.plane_words = n * n // 32            # bitmask words per plane
+        self.nz = self.z1 - self.z0
+        self.words = self.be.empty_u32(self.frame.words)
+        self.ids = [self.be.empty_u32(self.frame.voxels), self.be.empty_u32(self.frame.voxels)]
+        self.sdf = self.be.empty_f32(self.frame.voxels)
+        # halo buffers, sized for the largest request (a whole slab)
+        self.minus = self.be.empty_u32(self.frame.voxels) if world > 1 else None
+        self.plus = self.be.empty_u32(self.frame.voxels) if world > 1 else None
+        self.below = self.be.empty_u32(self.plane_words) if rank > 0 else None
+        self.above = self.be.empty_u32(self.plane_words) if rank < world - 1 else None
+        self.bytes_received = 0
+
+    # -- stages ---------------------------------------------------------------------------
+    def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
+        out = self.words if out is None else out
+        self.be.voxelize(self.frame, out, d_xyz, d_tri, algo)
+        return out
+
+    def csg(self, other, op: int):
+        self.be.csg(self.words, other, op)
+        return self.words
+
+    def _exchange(self, ops):
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def _exchange_mask_planes(self):
+        d, P = self.dist, self.dist.P2POp
+        ops = []
+        pw = self.plane_words
+        if self.rank > 0:                                         # my first plane is the 'above' plane of rank-1
+            ops.append(P(d.isend, self.words[:pw], self.rank - 1))
+            ops.append(P(d.irecv, self.below, self.rank - 1))
+        if self.rank < self.world - 1:                            # my last plane is the 'below' plane of rank+1
+            ops.append(P(d.isend, self.words[(self.nz - 1) * pw:], self.rank + 1))
+            ops.append(P(d.irecv, self.above, self.rank + 1))
+        self._exchange(ops)
+
+    def _exchange_ids(self, k: int, src):
+        d, P = self.dist, self.dist.P2POp
+        pi = self.plane_ids
+        minus_base = self.z0 - k                                  # global plane of minus[0] (vphip.h, vp_jfa_pass)
+        plus_base = max(self.z1, self.z0 + k)
+        ops = []
+        for s, t, side, g0, g1 in halo_plan(self.global_frame.n, self.world, k):
+            if s == t:
+                continue
+            if s == self.rank:
+                ops.append(P(d.isend, src[(g0 - self.z0) * pi:(g1 - self.z0) * pi], t))
+            elif t == self.rank:
+                buf, base = (self.minus, minus_base) if side == "minus" else (self.plus, plus_base)
+                ops.append(P(d.irecv, buf[(g0 - base) * pi:(g1 - base) * pi], s))
+                self.bytes_received += (g1 - g0) * pi * 4
+        self._exchange(ops)
+
+    def jfa(self, algo=ALGO_TILED, fill=-math.inf, out=None):
+        out = self.sdf if out is None else out
+        if self.world > 1:
+            self._exchange_mask_planes()
+        a, b = self.ids
+        self.be.jfa_init(self.frame, self.words, self.below, self.above, a)
+        k = self.global_frame.n // 2
+        while k >= 1:                                             # jfa/sequential.cpp:72
+            if self.world > 1:
+                self._exchange_ids(k, a)
+            self.be.jfa_pass(self.frame, k, a, self.minus, self.plus, b, algo)
+            a, b = b, a
+            k //= 2
+        self.be.jfa_finalize(self.frame, self.words, a, fill, out)
+        return out

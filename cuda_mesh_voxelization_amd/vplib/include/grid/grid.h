@@ -1,0 +1,73 @@
+// grid.h -- dense x-fastest 3-D array view + owning host wrapper
+// (/root/reference/vplib/src/grid/grid.h:22-230).  Index is 64-bit here (reference: 32-bit, :89-92).
+#ifndef VPLIB_GRID_H
+#define VPLIB_GRID_H
+
+#include <algorithm>
+#include <cassert>
+#include <cstddef>
+#include <cstdio>
+#include <memory>
+#include <span>
+
+#include "mesh/mesh.h"
+
+template <typename T>
+class HostGrid;
+
+template <typename T>
+class Grid {
+protected:
+    size_t mSizeX = 1, mSizeY = 1, mSizeZ = 1;
+    std::span<T> mGrid;
+
+public:
+    Grid() = default;
+    Grid(T* data, size_t sizeX, size_t sizeY, size_t sizeZ)
+        : mSizeX(sizeX), mSizeY(sizeY), mSizeZ(sizeZ), mGrid(data, sizeX * sizeY * sizeZ) {}
+    Grid(T* data, size_t size) : Grid(data, size, size, size) {}
+
+    T operator()(size_t x, size_t y, size_t z) const { assert(x < mSizeX && y < mSizeY && z < mSizeZ); return mGrid[Index(x, y, z)]; }
+    T& operator()(size_t x, size_t y, size_t z) { assert(x < mSizeX && y < mSizeY && z < mSizeZ); return mGrid[Index(x, y, z)]; }
+
+    size_t Size() const { return mSizeX * mSizeY * mSizeZ; }
+    size_t SizeX() const { return mSizeX; }
+    size_t SizeY() const { return mSizeY; }
+    size_t SizeZ() const { return mSizeZ; }
+    size_t Index(size_t x, size_t y, size_t z) const { return x + (y * mSizeX) + (z * mSizeX * mSizeY); }
+    T* Data() { return mGrid.data(); }
+    const T* Data() const { return mGrid.data(); }
+
+    friend class HostGrid<T>;
+};
+
+template <typename T>
+class HostGrid {
+    std::unique_ptr<T[]> mData;
+    Grid<T> mView;
+
+public:
+    HostGrid() = default;
+    HostGrid(size_t size, const T init) : HostGrid(size, size, size, init) {}
+    explicit HostGrid(size_t size) : HostGrid(size, size, size, T{}) {}   // reference reaches this through DeviceGrid (SURVEY A-2)
+    HostGrid(size_t sx, size_t sy, size_t sz, const T init)
+        : mData(std::make_unique<T[]>(sx * sy * sz)), mView(mData.get(), sx, sy, sz)
+    {
+        std::fill_n(mData.get(), sx * sy * sz, init);
+    }
+    HostGrid(const HostGrid& o)
+        : mData(std::make_unique<T[]>(o.mView.Size())), mView(mData.get(), o.mView.SizeX(), o.mView.SizeY(), o.mView.SizeZ())
+    {
+        std::copy_n(o.mData.get(), o.mView.Size(), mData.get());
+    }
+    HostGrid(HostGrid&& o) noexcept { swap(o); }
+    HostGrid& operator=(HostGrid o) noexcept { swap(o); return *this; }
+
+    void swap(HostGrid& o) noexcept { std::swap(mData, o.mData); std::swap(mView, o.mView); }
+    friend void swap(HostGrid& a, HostGrid& b) noexcept { a.swap(b); }
+
+    Grid<T>& View() { return mView; }
+    const Grid<T>& View() const { return mView; }
+};
+
+#endif

@@ -1,0 +1,118 @@
+// voxels_grid.h -- bit-packed occupancy grid (/root/reference/vplib/src/grid/voxels_grid.h:32-284).
+// Layout contract: voxel (x,y,z) -> linear bit i = x + y*nx + z*nx*ny, word i / wordbits, bit
+// i % wordbits, LSB first (:116-129); storage ceil(n^3 / wordbits) words (:189-192).  A uint64_t
+// grid and a uint32_t grid of the same shape hold identical bytes (little endian), which is what
+// lets both word types share the uint32 device kernels.
+#ifndef VPLIB_VOXELS_GRID_H
+#define VPLIB_VOXELS_GRID_H
+
+#include <algorithm>
+#include <cassert>
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <span>
+#include <type_traits>
+
+#include "grid/grid.h"
+
+template <typename T>
+concept VGType = std::is_same_v<T, uint32_t> || std::is_same_v<T, uint64_t>;
+
+template <VGType T>
+class HostVoxelsGrid;
+
+template <VGType T>
+class VoxelsGrid {
+    size_t mSizeX = 1, mSizeY = 1, mSizeZ = 1;
+    std::span<T> mGrid;
+    float mVoxelSize = 1;
+    float mOriginX = 0, mOriginY = 0, mOriginZ = 0;
+
+public:
+    class Bit {
+        T* mWord;
+        T mMask;
+
+    public:
+        Bit(T* word, T mask) : mWord(word), mMask(mask) {}
+        Bit& operator=(bool v) { if (v) *mWord |= mMask; else *mWord &= ~mMask; return *this; }
+        Bit& operator^=(bool v) { if (v) *mWord ^= mMask; return *this; }
+        operator bool() const { return (*mWord & mMask) != 0; }
+    };
+
+    VoxelsGrid() = default;
+    VoxelsGrid(T* data, size_t nx, size_t ny, size_t nz, float voxelSize = 1.0f)
+        : mSizeX(nx), mSizeY(ny), mSizeZ(nz), mGrid(data, CalculateStorageSize(nx, ny, nz)), mVoxelSize(voxelSize) {}
+    VoxelsGrid(T* data, size_t n, float voxelSize = 1.0f) : VoxelsGrid(data, n, n, n, voxelSize) {}
+
+    size_t Index(size_t x, size_t y, size_t z) const { return x + (y * mSizeX) + (z * mSizeX * mSizeY); }
+    Bit Voxel(size_t x, size_t y, size_t z)
+    {
+        assert(x < mSizeX && y < mSizeY && z < mSizeZ);
+        const size_t i = Index(x, y, z);
+        return Bit(&mGrid[i / WordSize()], T(1) << (i % WordSize()));
+    }
+    bool Voxel(size_t x, size_t y, size_t z) const
+    {
+        assert(x < mSizeX && y < mSizeY && z < mSizeZ);
+        const size_t i = Index(x, y, z);
+        return (mGrid[i / WordSize()] & (T(1) << (i % WordSize()))) != 0;
+    }
+    T& Word(size_t x, size_t y, size_t z) { return mGrid[Index(x, y, z) / WordSize()]; }
+    T Word(size_t x, size_t y, size_t z) const { return mGrid[Index(x, y, z) / WordSize()]; }
+
+    size_t Size() const { return mSizeX * mSizeY * mSizeZ; }
+    size_t SizeX() const { return mSizeX; }
+    size_t SizeY() const { return mSizeY; }
+    size_t SizeZ() const { return mSizeZ; }
+    size_t VoxelsPerSide() const { assert(mSizeX == mSizeY && mSizeY == mSizeZ); return mSizeX; }
+    float VoxelSize() const { return mVoxelSize; }
+    void SetOrigin(float x, float y, float z) { mOriginX = x; mOriginY = y; mOriginZ = z; }
+    float OriginX() const { return mOriginX; }
+    float OriginY() const { return mOriginY; }
+    float OriginZ() const { return mOriginZ; }
+
+    T* Data() { return mGrid.data(); }
+    const T* Data() const { return mGrid.data(); }
+    size_t StorageSize() const { return mGrid.size(); }
+
+    static constexpr size_t WordSize() { return sizeof(T) * 8; }
+    static size_t CalculateStorageSize(size_t n) { return CalculateStorageSize(n, n, n); }
+    static size_t CalculateStorageSize(size_t nx, size_t ny, size_t nz) { return (nx * ny * nz + WordSize() - 1) / WordSize(); }
+
+    friend class HostVoxelsGrid<T>;
+};
+
+template <VGType T>
+class HostVoxelsGrid {
+    std::unique_ptr<T[]> mData;
+    VoxelsGrid<T> mView;
+
+public:
+    HostVoxelsGrid() = default;
+    HostVoxelsGrid(size_t nx, size_t ny, size_t nz, float voxelSize = 1.0f)
+        : mData(std::make_unique<T[]>(VoxelsGrid<T>::CalculateStorageSize(nx, ny, nz))),     // zero-filled (voxels_grid.cu:16,24)
+          mView(mData.get(), nx, ny, nz, voxelSize) {}
+    explicit HostVoxelsGrid(size_t n, float voxelSize = 1.0f) : HostVoxelsGrid(n, n, n, voxelSize) {}
+    HostVoxelsGrid(const HostVoxelsGrid& o)
+        : mData(std::make_unique<T[]>(o.mView.StorageSize())),
+          mView(mData.get(), o.mView.SizeX(), o.mView.SizeY(), o.mView.SizeZ(), o.mView.VoxelSize())
+    {
+        std::copy_n(o.mData.get(), o.mView.StorageSize(), mData.get());
+        mView.SetOrigin(o.mView.OriginX(), o.mView.OriginY(), o.mView.OriginZ());
+    }
+    HostVoxelsGrid(HostVoxelsGrid&& o) noexcept { swap(o); }
+    HostVoxelsGrid& operator=(HostVoxelsGrid o) noexcept { swap(o); return *this; }
+
+    void swap(HostVoxelsGrid& o) noexcept { std::swap(mData, o.mData); std::swap(mView, o.mView); }
+    friend void swap(HostVoxelsGrid& a, HostVoxelsGrid& b) noexcept { a.swap(b); }
+
+    VoxelsGrid<T>& View() { return mView; }
+    const VoxelsGrid<T>& View() const { return mView; }
+};
+
+using HostVoxelsGrid32bit = HostVoxelsGrid<uint32_t>;
+using HostVoxelsGrid64bit = HostVoxelsGrid<uint64_t>;
+
+#endif

@@ -1,0 +1,59 @@
+// csg.cpp -- CSG::Compute back ends (/root/reference/vplib/src/csg/sequential.cpp:7-30,
+// csg/openmp.cpp:9-31, csg/naive.cu:26-64): word-wise a = a op b.
+#include "csg/csg.h"
+
+#include "profiling.h"
+#include "vp_runtime.h"
+
+namespace CSG::detail {
+
+void Host(bool parallel, uint32_t* a, const uint32_t* b, size_t n, int op)
+{
+    const std::string L = parallel ? "OpenmpCSG" : "SequentialCSG";
+    PROFILING_SCOPE(L);
+    PROFILING_SCOPE(L + "::Processing");
+    const long long count = static_cast<long long>(n);
+    switch (static_cast<Op>(op)) {
+        case Op::UNION:
+#pragma omp parallel for if (parallel) schedule(static)
+            for (long long i = 0; i < count; ++i) a[i] |= b[i];
+            break;
+        case Op::INTERSECTION:
+#pragma omp parallel for if (parallel) schedule(static)
+            for (long long i = 0; i < count; ++i) a[i] &= b[i];
+            break;
+        case Op::DIFFERENCE:
+#pragma omp parallel for if (parallel) schedule(static)
+            for (long long i = 0; i < count; ++i) a[i] &= ~b[i];
+            break;
+        case Op::VOID:
+            break;
+    }
+}
+
+void Device(uint32_t* a, const uint32_t* b, size_t n, int op)
+{
+    PROFILING_SCOPE("NaiveCSG");
+    vp_ctx* ctx = vplib::Context();
+    void *da = nullptr, *db = nullptr;
+    {
+        PROFILING_SCOPE("NaiveCSG::Memory");
+        gpuAssert(vp_malloc(ctx, n * 4, &da));
+        gpuAssert(vp_malloc(ctx, n * 4, &db));
+        gpuAssert(vp_upload(ctx, da, a, n * 4));
+        gpuAssert(vp_upload(ctx, db, b, n * 4));
+    }
+    {
+        PROFILING_SCOPE("NaiveCSG::Processing");
+        gpuAssert(vp_csg(ctx, static_cast<uint32_t*>(da), static_cast<const uint32_t*>(db), n, op));
+        gpuAssert(vp_ctx_sync(ctx));
+    }
+    {
+        PROFILING_SCOPE("NaiveCSG::Memory");
+        gpuAssert(vp_download(ctx, a, da, n * 4));
+        gpuAssert(vp_free(ctx, da));
+        gpuAssert(vp_free(ctx, db));
+    }
+}
+
+}  // namespace CSG::detail

@@ -1,0 +1,109 @@
+"""The C++23 vplib mirror + CLI (cuda_mesh_voxelization_amd/vplib, apps/cli): same flags and timer-line
+grammar as the reference CLI (apps/cli/main.cpp:28-40, vplib/src/profiling.h:22).  CPU variants run
+here; GPU variants are gpu-marked."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from cuda_mesh_voxelization_amd import build, mesh as M
+from oracle import oracle as O
+
+LINE = re.compile(r"^\[(?P<label>[^\]]+)\]: (?P<ms>\d+\.\d+) ms$")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    return build.build_cli()
+
+
+def _run(cli, args, tmp_path, dump=True):
+    prefix = str(tmp_path / "out")
+    cmd = [cli] + args + (["-d", prefix] if dump else [])
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    return p, prefix
+
+
+def _check_row(prefix, row):
+    g = np.fromfile(prefix + ".grid.u32", np.uint32)
+    pc, h = row.get("csg", row["grids"][0])
+    assert (O.popcount(g), O.fnv(g)) == (pc, h)
+    s = np.fromfile(prefix + ".sdf.f32", np.float32)
+    assert O.fnv(s) == row["sdf"]["fnv"]
+
+
+def _row(golden_rows, meshes, n, op):
+    (r,) = [r for r in golden_rows if r["meshes"] == meshes and r["n"] == n and r["op"] == op]
+    return r
+
+
+@pytest.mark.parametrize("t", [0, 3])
+def test_cli_cpu_variants_match_golden(cli, golden_rows, tmp_path, t):
+    for meshes, n, op in ((["bunny.obj"], 64, 0), (["bimba.obj", "bunny.obj"], 64, 1), (["bimba.obj", "bunny.obj"], 64, 3)):
+        args = [M.asset(m) for m in meshes] + ["-n", str(n), "-t", str(t), "-s"] + (["-p", str(op)] if op else [])
+        p, prefix = _run(cli, args, tmp_path)
+        assert p.returncode == 0, p.stdout + p.stderr
+        _check_row(prefix, _row(golden_rows, meshes, n, op))
+
+
+def test_cli_timer_grammar_sequential(cli, tmp_path):
+    p, _ = _run(cli, [M.asset("bimba.obj"), M.asset("bunny.obj"), "--num-voxels=32", "--type", "0", "-p1", "--sdf"], tmp_path, dump=False)
+    assert p.returncode == 0
+    labels = []
+    for line in p.stdout.strip().splitlines():
+        m = LINE.match(line)
+        assert m, line
+        labels.append(m.group("label"))
+    # inner scopes print before the outer one; outer vox label carries the mesh name (vox/sequential.cpp:9-12)
+    assert labels[0] == "SequentialVox::Processing"
+    assert labels[1] == "SequentialVox(%s)" % M.asset("bimba.obj")
+    assert "SequentialCSG::Processing" in labels and "SequentialCSG" in labels
+    assert labels[-4:] == ["SequentialJFA::Memory", "SequentialJFA::Initialization", "SequentialJFA::Processing", "SequentialJFA"]
+
+
+def test_cli_usage_and_errors(cli, tmp_path):
+    p = subprocess.run([cli, "-h"], capture_output=True, text=True)
+    assert p.returncode == 0 and "--num-voxels" in p.stdout and "--benckmark" in p.stdout
+    p = subprocess.run([cli], capture_output=True, text=True)
+    assert p.returncode != 0 and "CPU Assert" in p.stdout            # debug_utils.h:52-60 behaviour
+    p = subprocess.run([cli, M.asset("d20.obj"), "-b", "24"], capture_output=True, text=True)
+    assert p.returncode != 0 and "multiple of 16" in p.stdout         # main.cpp:60
+    p = subprocess.run([cli, str(tmp_path / "missing.obj"), "-t", "0"], capture_output=True, text=True)
+    assert p.returncode != 0
+
+
+def test_cli_gpu_type_without_gpu_fails_loudly(cli):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = subprocess.run([cli, M.asset("d20.obj"), "-t", "2"], capture_output=True, text=True)
+    assert p.returncode != 0 and "HIP Assert" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [1, 2])
+def test_cli_gpu_variants_match_golden(cli, golden_rows, tmp_path, t):
+    for meshes, n, op in ((["bunny.obj"], 64, 0), (["bimba.obj", "bunny.obj"], 128, 1), (["bunny.obj"], 256, 0)):
+        args = [M.asset(m) for m in meshes] + ["-n", str(n), "-t", str(t), "-s"] + (["-p", str(op)] if op else [])
+        p, prefix = _run(cli, args, tmp_path)
+        assert p.returncode == 0, p.stdout + p.stderr
+        _check_row(prefix, _row(golden_rows, meshes, n, op))
+    labels = [LINE.match(l).group("label") for l in p.stdout.strip().splitlines() if LINE.match(l)]
+    name = "Tiled" if t == 2 else "Naive"
+    for want in ("%sVox::Memory" % name, "%sVox::Processing" % name, "%sJFA::Initialization" % name,
+                 "%sJFA::Processing" % name, "%sJFA" % name):
+        assert want in labels, (want, labels)
+
+
+@pytest.mark.gpu
+def test_cli_benchmark_mode(cli, tmp_path):
+    # -m > 1: only mesh 0, CSG against an empty grid, export disabled (main.cpp:55-57,126-127,188)
+    p, prefix = _run(cli, [M.asset("sphere.obj"), M.asset("torus.obj"), "-n", "64", "-t", "2", "-p", "1", "-m", "3"], tmp_path)
+    assert p.returncode == 0
+    assert p.stdout.count("[NaiveCSG]:") == 3 and p.stdout.count("TiledVox(") == 3
+    xyz, tri = M.import_mesh(M.asset("sphere.obj"))
+    x2, _ = M.import_mesh(M.asset("torus.obj"))
+    origin, vs = O.frame([xyz, x2], 64)
+    assert np.array_equal(np.fromfile(prefix + ".grid.u32", np.uint32), O.voxelize(xyz, tri, 64, vs, origin))

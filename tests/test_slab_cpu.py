@@ -1,0 +1,97 @@
+"""Z-slab pipeline (cuda_mesh_voxelization_amd/slab.py) under gloo with world_size 2 and 4 on CPU:
+the concatenated slabs must be bit-identical to the single-domain oracle.  The compute backend is the
+numpy stand-in of tests/slab_cpu_backend.py; what is under test is the halo plan and the exchange."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, asset, op, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuda_mesh_voxelization_amd import mesh as M
+        from cuda_mesh_voxelization_amd.capi import Frame
+        from cuda_mesh_voxelization_amd.slab import SlabPipeline
+        from slab_cpu_backend import CpuSlabBackend
+        meshes = [M.import_mesh(M.asset(a)) for a in asset]
+        origin, vs = M.frame([m[0] for m in meshes], n)
+        fr = Frame.make(n, vs, origin)
+        pipe = SlabPipeline(CpuSlabBackend(meshes[0]), fr, rank, world, dist)
+        pipe.voxelize(None, None)
+        if len(meshes) > 1:
+            other = pipe.be.empty_u32(pipe.frame.words)
+            pipe.be.mesh_host = meshes[1]
+            pipe.voxelize(None, None, out=other)
+            pipe.csg(other, op)
+        sdf = pipe.jfa()
+        np.save(os.path.join(outdir, "words_%d.npy" % rank), pipe.words.numpy().view(np.uint32))
+        np.save(os.path.join(outdir, "sdf_%d.npy" % rank), sdf.numpy())
+        np.save(os.path.join(outdir, "rx_%d.npy" % rank), np.array([pipe.bytes_received]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,n,assets,op", [(2, 32, ["sphere.obj"], 0), (4, 32, ["torus.obj"], 0),
+                                               (2, 64, ["bimba.obj", "bunny.obj"], 1)])
+def test_slab_pipeline_matches_single_domain_oracle(tmp_path, world, n, assets, op):
+    sys.path.insert(0, ROOT)
+    from cuda_mesh_voxelization_amd import mesh as M
+    from oracle import oracle as O
+    mp.spawn(_worker, args=(world, _free_port(), n, assets, op, str(tmp_path)), nprocs=world, join=True)
+    meshes = [M.import_mesh(M.asset(a)) for a in assets]
+    origin, vs = M.frame([m[0] for m in meshes], n)
+    words = O.voxelize(meshes[0][0], meshes[0][1], n, vs, origin)
+    if len(meshes) > 1:
+        O.csg(words, O.voxelize(meshes[1][0], meshes[1][1], n, vs, origin), op)
+    exp = O.jfa(words, n, vs, origin)
+    got_w = np.concatenate([np.load(tmp_path / ("words_%d.npy" % r)) for r in range(world)])
+    got_s = np.concatenate([np.load(tmp_path / ("sdf_%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got_w, words)
+    assert np.array_equal(got_s.view(np.uint32), exp.view(np.uint32))
+    rx = [int(np.load(tmp_path / ("rx_%d.npy" % r))[0]) for r in range(world)]
+    assert all(b > 0 for b in rx)
+
+
+def test_halo_plan_covers_exactly_what_a_pass_reads():
+    sys.path.insert(0, ROOT)
+    from cuda_mesh_voxelization_amd.slab import halo_plan, slab_range
+    for n, world in ((64, 2), (64, 4), (64, 8), (512, 8), (1024, 4)):
+        nz = n // world
+        k = n // 2
+        while k >= 1:
+            plan = halo_plan(n, world, k)
+            for dst in range(world):
+                z0, z1 = slab_range(n, dst, world)
+                need = set()
+                for z in range(z0, z1):
+                    for zz in (z - k, z + k):
+                        if 0 <= zz < n and not (z0 <= zz < z1):
+                            need.add(zz)
+                have = set()
+                for s, t, side, g0, g1 in plan:
+                    if t != dst:
+                        continue
+                    assert g0 // nz == s and (g1 - 1) // nz == s          # one owner per piece
+                    have.update(range(g0, g1))
+                assert have == need, (n, world, k, dst)
+            k //= 2
+    with pytest.raises(ValueError):
+        slab_range(64, 0, 16)          # 4 planes per slab: not a multiple of the 8-row tile

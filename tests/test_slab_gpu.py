@@ -1,0 +1,93 @@
+"""Z-slab path on ONE GPU: world_size ranks are emulated by threads, the point-to-point exchange by an
+in-process loopback that implements the torch.distributed calls slab.py uses.  This drives the real
+HIP kernels with slab frames and halo buffers (vp_jfa_init / vp_jfa_pass addressing, slab voxelize),
+which the single-GPU tests never do.  Results must be bit-identical to the whole-grid run."""
+import queue
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from cuda_mesh_voxelization_amd import mesh as M
+from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, Frame
+from cuda_mesh_voxelization_amd.pipeline import Engine
+from cuda_mesh_voxelization_amd.slab import HipSlabBackend, SlabPipeline
+
+pytestmark = pytest.mark.gpu
+
+
+class _Req:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def wait(self):
+        self.fn()
+
+
+class LoopbackDist:
+    """The subset of torch.distributed that slab.py touches, for ranks living in one process."""
+    isend, irecv = "isend", "irecv"
+
+    def __init__(self, rank, queues):
+        self.rank, self.queues = rank, queues
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    def batch_isend_irecv(self, ops):
+        reqs = []
+        for o in ops:
+            if o.op == "isend":
+                self.queues[(self.rank, o.peer)].put(o.tensor.clone())
+        for o in ops:
+            if o.op == "irecv":
+                def rx(o=o):
+                    o.tensor.copy_(self.queues[(o.peer, self.rank)].get(timeout=120))
+                reqs.append(_Req(rx))
+        return reqs
+
+
+def _run_slabs(world, frame, xyz, tri, algo):
+    queues = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    engines = [Engine(0) for _ in range(world)]
+    pipes, errors = [], []
+    for r in range(world):
+        pipes.append(SlabPipeline(HipSlabBackend(engines[r]), frame, r, world, LoopbackDist(r, queues)))
+    meshes = [engines[r].mesh_to_device(xyz, tri) for r in range(world)]
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            pipes[r].voxelize(meshes[r][0], meshes[r][1], algo=algo)
+            pipes[r].jfa(algo=algo)
+            torch.cuda.synchronize()
+        except Exception as e:          # surface in the main thread
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    words = np.concatenate([Engine.words_to_numpy(p.words) for p in pipes])
+    sdf = np.concatenate([p.sdf.cpu().numpy() for p in pipes])
+    return words, sdf
+
+
+@pytest.mark.parametrize("world,n,name,algo", [(2, 64, "bunny.obj", ALGO_TILED), (4, 64, "bunny.obj", ALGO_TILED),
+                                               (8, 64, "torus.obj", ALGO_TILED), (4, 32, "d20.obj", ALGO_NAIVE),
+                                               (2, 256, "bimba.obj", ALGO_TILED), (8, 256, "bunny.obj", ALGO_TILED)])
+def test_slabs_equal_whole_grid(engine, world, n, name, algo):
+    xyz, tri = M.import_mesh(M.asset(name))
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    ref_w = engine.voxelize(fr, dx, dt, algo=algo)
+    ref_s = engine.jfa(fr, ref_w, algo=algo).cpu().numpy()
+    ref_w = engine.words_to_numpy(ref_w)
+    words, sdf = _run_slabs(world, fr, xyz, tri, algo)
+    assert np.array_equal(words, ref_w)
+    assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
