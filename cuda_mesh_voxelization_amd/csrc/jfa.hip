@@ -7,7 +7,7 @@
 //
 // State: the reference keeps float sdf + float3 seed position per voxel (16 B, two copies, plus a
 // deep copy per pass, :123-124).  Here the state is ONE uint32 per voxel -- the packed voxel
-// coordinates of the best seed so far ((x<<2) | y<<12 | z<<22, 0xFFFFFFFF = none).  The seed position
+// coordinates of the best seed so far (scr(y)<<2 | x<<12 | scr(z)<<22, 0xFFFFFFFF = none).  The seed position
 // and the distance are recomputed from it with the reference's expressions, which gives the same
 // floats because the reference's stored sdf is itself the result of exactly that expression.
 // Ping-pong between two id volumes; the last step converts ids to floats.
@@ -30,14 +30,16 @@ namespace vp {
 
 namespace {
 
-// id layout: bits [2..11] x, [12..21] y, [22..31] z, bits [0,1] zero -- every field is already a
-// byte offset into a float table after one shift+mask (x: a single AND); kNone has bits 0,1 set.
+// id layout: bits [2..11] scr(y), [12..21] x, [22..31] scr(z), bits [0,1] zero -- every field is already
+// a byte offset into a float table after one shift+mask.  y sits in the low field because its table is
+// the one looked up once per candidate AND chain step (a single AND); x and z are decoded once per id.
+// kNone has bits 0,1 set.
 // The y and z fields hold scr(y), scr(z): the low five bits XORed with the next five.  Seeds reached
 // by jumps of 2^j >= 32 differ from the voxel only in high coordinate bits; unscrambled they would all
 // index the same LDS bank of the TY/TZ tables (measured: passes k = 32, 16 ran 2x slower).  scr is an
 // involution and stays inside [0, n) because n % 32 == 0.
 __device__ __forceinline__ uint32_t scr(uint32_t i) { return i ^ ((i >> 5) & 31u); }
-__device__ __forceinline__ uint32_t pack_id(uint32_t x, uint32_t y, uint32_t z) { return (x << 2) | (scr(y) << 12) | (scr(z) << 22); }
+__device__ __forceinline__ uint32_t pack_id(uint32_t x, uint32_t y, uint32_t z) { return (scr(y) << 2) | (x << 12) | (scr(z) << 22); }
 
 // jfa/sequential.cpp:79-81 / :32-34 : voxel corner position along one axis
 __device__ __forceinline__ float axis_pos(float o, uint32_t i, float vs) { return o + ((float)(int)i * vs); }
@@ -45,8 +47,8 @@ __device__ __forceinline__ float axis_pos(float o, uint32_t i, float vs) { retur
 // jfa/jfa.h:19-20 with p1 = seed position decoded from `id`, p0 = (px,py,pz)
 __device__ __forceinline__ float seed_distance(const Frame& f, uint32_t id, float px, float py, float pz)
 {
-    const float sx = axis_pos(f.ox, (id >> 2) & 1023u, f.vs);
-    const float sy = axis_pos(f.oy, scr((id >> 12) & 1023u), f.vs);
+    const float sx = axis_pos(f.ox, (id >> 12) & 1023u, f.vs);
+    const float sy = axis_pos(f.oy, scr((id >> 2) & 1023u), f.vs);
     const float sz = axis_pos(f.oz, scr(id >> 22), f.vs);
     return ((sx - px) * (sx - px)) + ((sy - py) * (sy - py)) + ((sz - pz) * (sz - pz));
 }
@@ -103,12 +105,12 @@ jfa_init(Frame f, const uint32_t* __restrict__ words, const uint32_t* __restrict
         for (int j = 0; j < 8; ++j) {
             const int src = j * 8 + (lane >> 3);
             const uint32_t b = (__shfl(border, src) >> sub) & 0xFu;
-            const uint32_t id0 = __shfl(mybase, src) + ((uint32_t)sub << 2);
+            const uint32_t id0 = __shfl(mybase, src) + ((uint32_t)sub << 12);
             uint4 v;
             v.x = (b & 1u) ? id0 : kNone;
-            v.y = (b & 2u) ? id0 + 4u : kNone;
-            v.z = (b & 4u) ? id0 + 8u : kNone;
-            v.w = (b & 8u) ? id0 + 12u : kNone;
+            v.y = (b & 2u) ? id0 + (1u << 12) : kNone;
+            v.z = (b & 4u) ? id0 + (2u << 12) : kNone;
+            v.w = (b & 8u) ? id0 + (3u << 12) : kNone;
             out[j * 64 + lane] = v;
         }
     }
@@ -242,8 +244,8 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
             // own state first (it wins ties: acceptance is strict, sequential.cpp:106), then scan order
             const int q = (j == 0) ? 13 : (j <= 13 ? j - 1 : j);
             const uint32_t id = c[q];
-            const float sx = *reinterpret_cast<const float*>(tx + (id & 0xFFCu));
-            const float dy2 = *reinterpret_cast<const float*>(ty + ((id >> 10) & 0xFFCu));
+            const float sx = *reinterpret_cast<const float*>(tx + ((id >> 10) & 0xFFCu));
+            const float dy2 = *reinterpret_cast<const float*>(ty + (id & 0xFFCu));
             const float dz2 = *reinterpret_cast<const float*>(tz + ((id >> 20) & 0xFFCu));
             const float dxv = sx - px;
             const float d = ((dxv * dxv) + dy2) + dz2;
@@ -363,8 +365,8 @@ jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
                 const float dy2 = __uint_as_float(((id >> 10) & 0xFFCu) | 0x3f800000u);
                 const float dz2 = __uint_as_float(((id >> 20) & 0xFFCu) | 0x3f800000u);
 #else
-                const float sx = *reinterpret_cast<const float*>(tx + (id & 0xFFCu));
-                const float dy2 = *reinterpret_cast<const float*>(ty + ((id >> 10) & 0xFFCu));
+                const float sx = *reinterpret_cast<const float*>(tx + ((id >> 10) & 0xFFCu));
+                const float dy2 = *reinterpret_cast<const float*>(ty + (id & 0xFFCu));
                 const float dz2 = *reinterpret_cast<const float*>(tz + ((id >> 20) & 0xFFCu));
 #endif
                 const float dxv = sx - px;
