@@ -8,8 +8,9 @@ One "step" = tiled voxelization of the resident mesh into a bit-packed 512^3 gri
 full JFA (init + 9 passes + finalize) into a float sdf -- both through the C ABI of libvphip.so,
 inputs already in HBM.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 
-N > 1: the grid is cut into N Z-slabs, one process per GPU, RCCL halo exchange between JFA passes
-(strong scaling of the same 512^3 job).
+N > 1: strong scaling of the same 512^3 job over N Z-slabs, one process per GPU.  Default: ghost planes are
+recomputed instead of exchanged (a plane costs ~1.6 us to recompute and ~20 us to move over xGMI);
+--multi halo selects the RCCL point-to-point halo exchange.
 """
 from __future__ import annotations
 
@@ -64,6 +65,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi", choices=["ghost", "halo"], default="ghost",
+                    help="N > 1: 'ghost' = communication-free Z-slabs with recomputed ghost planes (default); "
+                         "'halo' = Z-slabs with RCCL point-to-point halo exchange between JFA passes")
     ap.add_argument("--n", type=int, default=N_GRID, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -101,8 +105,11 @@ def main():
             eng.voxelize(frame, d_xyz, d_tri, out=grid, algo=ALGO_TILED)
             eng.jfa(frame, grid, out=sdf, algo=ALGO_TILED)
     else:
-        from cuda_mesh_voxelization_amd.slab import HipSlabBackend, SlabPipeline
-        pipe = SlabPipeline(HipSlabBackend(eng), frame, rank, world, dist)
+        from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline, HipSlabBackend, SlabPipeline
+        if args.multi == "ghost":
+            pipe = GhostSlabPipeline(HipSlabBackend(eng), frame, rank, world)
+        else:
+            pipe = SlabPipeline(HipSlabBackend(eng), frame, rank, world, dist)
 
         def step():
             pipe.voxelize(d_xyz, d_tri, algo=ALGO_TILED)
@@ -137,8 +144,9 @@ def main():
         value = n ** 3 / (elapsed / args.steps) / 1e6
         passes = int(math.log2(n))
         kp = prof.get("jfa_pass", {"ms": 0.0, "launches": 0})
-        slab_vox = n * n * (n // world)
-        alg_bytes = 2 * STATE_BYTES * slab_vox                         # one id read + one id write per voxel
+        # mean planes per jfa_pass launch on this rank (ghost mode widens the slab by the reach of later passes)
+        planes = pipe.planes_computed / passes if (world > 1 and args.multi == "ghost") else n // world
+        alg_bytes = int(2 * STATE_BYTES * n * n * planes)              # one id read + one id write per voxel
         avg_ms = kp["ms"] / max(kp["launches"], 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
@@ -157,7 +165,8 @@ def main():
             "config": {"workload": "bunny.obj refined x24 (1,348,128 faces, 680k verts) -> tiled solid voxelize into bit-packed "
                                    "%d^3 grid + JFA sdf (init + %d passes + finalize), device-resident" % (n, passes),
                        "n": n, "triangles": int(tri.shape[0]), "jfa_state_bytes": STATE_BYTES,
-                       "parallelism": "1 gpu" if world == 1 else "z-slab x%d, RCCL halo exchange" % world,
+                       "parallelism": "1 gpu" if world == 1 else ("z-slab x%d, ghost planes recomputed, no exchange" % world if args.multi == "ghost"
+                                                                   else "z-slab x%d, RCCL p2p halo exchange" % world),
                        "baseline": "480 Mvoxels/s = reference tiled vox+JFA kernels-only at n=512 (BASELINE.md, unstated NVIDIA GPU)"},
             "roofline": {"kernel": "jfa_pass", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

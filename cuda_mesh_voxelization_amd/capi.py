@@ -20,7 +20,7 @@ SYMBOLS = [
     "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_stream", "vp_ctx_sync", "vp_last_error", "vp_abi_version",
     "vp_malloc", "vp_free", "vp_memset", "vp_upload", "vp_download", "vp_grid_words", "vp_grid_voxels",
     "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa", "vp_jfa_init", "vp_jfa_pass",
-    "vp_jfa_finalize", "vp_surface", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
+    "vp_jfa_finalize", "vp_jfa_last_pass", "vp_surface", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
 ]
 
@@ -98,6 +98,7 @@ def lib():
         "vp_jfa_init": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
         "vp_jfa_pass": (ctypes.c_int, [_vp, fp, ctypes.c_uint32, _vp, _vp, _vp, _vp, ctypes.c_int]),
         "vp_jfa_finalize": (ctypes.c_int, [_vp, fp, _vp, _vp, ctypes.c_float, _vp]),
+        "vp_jfa_last_pass": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int]),
         "vp_surface": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
         "vp_voxelize_host": (ctypes.c_int, [_vp, fp, _vp, _vp, _sz, _vp, _sz, ctypes.c_int]),
         "vp_csg_host": (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int]),
@@ -190,6 +191,11 @@ class Context:
 
     def jfa_finalize(self, frame: Frame, d_words: int, d_ids: int, fill: float, d_sdf: int):
         check(lib().vp_jfa_finalize(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_ids), fill, _vp(d_sdf)))
+
+    def jfa_last_pass(self, frame: Frame, d_in: int, d_minus, d_plus, d_scratch: int, d_words: int, fill: float, d_sdf: int,
+                      algo: int = ALGO_TILED):
+        check(lib().vp_jfa_last_pass(self._h, ctypes.byref(frame), _vp(d_in), _vp(d_minus or None), _vp(d_plus or None),
+                                     _vp(d_scratch), _vp(d_words), fill, _vp(d_sdf), algo))
 
     def surface(self, frame: Frame, d_words: int, d_below, d_above, d_border: int):
         check(lib().vp_surface(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_below or None),

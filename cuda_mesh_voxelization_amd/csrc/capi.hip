@@ -276,10 +276,29 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
     uint32_t* b = a + vp_grid_voxels(f);
     VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, a, nullptr));
     for (uint32_t k = f->n / 2; k >= 1; k /= 2) {                  // jfa/sequential.cpp:72
+        if (k == 1 && jfa_pass_can_fuse_final(fr, k, algo))        // last pass writes the sdf itself
+            return launch_jfa_pass_ex(ctx, fr, k, a, nullptr, nullptr, b, algo, d_words, fill_unset, d_sdf);
         VP_TRY(launch_jfa_pass(ctx, fr, k, a, nullptr, nullptr, b, algo));
         uint32_t* t = a; a = b; b = t;
     }
     return launch_jfa_final(ctx, fr, d_words, a, fill_unset, d_sdf);
+}
+
+int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_in, const uint32_t* d_minus, const uint32_t* d_plus,
+                     uint32_t* d_scratch, const uint32_t* d_words, float fill_unset, float* d_sdf, int algo)
+{
+    if (!ctx || !d_in || !d_scratch || !d_words || !d_sdf || d_in == d_scratch)
+        return set_error(VP_ERR_INVALID, "vp_jfa_last_pass: bad buffers");
+    VP_TRY(check_frame(f, "vp_jfa_last_pass", false));
+    VP_TRY(check_fill(fill_unset, "vp_jfa_last_pass"));
+    if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_jfa_last_pass: algo %d", algo);
+    if (f->z0 > 0 && !d_minus) return set_error(VP_ERR_INVALID, "vp_jfa_last_pass: slab needs d_minus");
+    if (f->z1 < f->n && !d_plus) return set_error(VP_ERR_INVALID, "vp_jfa_last_pass: slab needs d_plus");
+    const Frame fr = make_frame(f);
+    if (jfa_pass_can_fuse_final(fr, 1, algo))
+        return launch_jfa_pass_ex(ctx, fr, 1, d_in, d_minus, d_plus, d_scratch, algo, d_words, fill_unset, d_sdf);
+    VP_TRY(launch_jfa_pass(ctx, fr, 1, d_in, d_minus, d_plus, d_scratch, algo));
+    return launch_jfa_final(ctx, fr, d_words, d_scratch, fill_unset, d_sdf);
 }
 
 // ---- host-in / host-out ----------------------------------------------------------------------

@@ -264,20 +264,25 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 // the limiter of the straightforward version (measured: 27 loads/voxel cost 43 % of the pass).
 // Per-row LDS tables at fixed addresses turn a candidate id into (seed x, dy^2, dz^2) with 5 VALU
 // ops + 3 ds_read_b32.
-//   SKIP = true   (early passes: large k, sparse state) rows outside the grid are skipped with
-//                 wave-uniform branches and a candidate column in which no lane of the wave holds
-//                 a seed is skipped after a ballot;
-//   SKIP = false  branch-free per voxel, so the scheduler overlaps the table reads of all candidates.
+//   SKIP = true   (early passes, k >= n/4: sparse state, many rows outside the grid) rows / planes outside
+//                 the grid are skipped with wave-uniform branches and a candidate column in which no lane
+//                 of the wave holds a seed is skipped after a ballot.  (A table-free per-voxel kernel and
+//                 the branch-free variant were both measured slower for these passes.)
+//   SKIP = false  the voxel loop is branch-free (rows outside the grid read a row of kNone through a uniform
+//                 pointer select), so the scheduler overlaps the table reads of all candidates.
 //   CHECK_NONE = false (n < 1024): table slot 1023 can never be a real scrambled coordinate; it
 //                 holds +inf, so a kNone candidate yields d = inf/NaN and loses without a compare.
+//   FINAL = true  last pass (k = 1) fused with the id -> sdf conversion of jfa_final: the winning
+//                 distance is already in a register, so the pass writes floats instead of ids and the
+//                 separate read+write of the id volume disappears.
 constexpr int kChain = 4;
 
 // launch_bounds: 5 waves/SIMD (<= 96 VGPRs) measured best -- 4 (99 VGPRs) is 6 % slower, 6 spills.
-template <bool SKIP, bool CHECK_NONE>
+template <bool SKIP, bool CHECK_NONE, bool FINAL>
 __global__ void __launch_bounds__(256, 5)
 jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
                const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, const uint32_t* __restrict__ zorder,
-               const uint32_t* __restrict__ none_row)
+               const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
 {
     __shared__ float PX[kTab];
     __shared__ float TZ[kTab];
@@ -338,14 +343,10 @@ jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
             const uint32_t ro = (uint32_t)(yin ? yy : 0) * rowBytes;
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz) {
-                if (!SKIP) {
-                    // branch-free: a row outside the grid reads from a row of kNone (uniform pointer select)
+                // uniform base + 32-bit lane offsets -> global_load ... saddr
+                if (!SKIP || (yin && zv[dz])) {
+                    // !SKIP: branch-free, a row outside the grid reads from a row of kNone (uniform pointer select)
                     const char* b = (yin && zv[dz]) ? zp[dz] + ro : reinterpret_cast<const char*>(none_row);
-                    w[dz * 3 + 0] = *reinterpret_cast<const uint32_t*>(b + xmo);
-                    w[dz * 3 + 1] = *reinterpret_cast<const uint32_t*>(b + xo);
-                    w[dz * 3 + 2] = *reinterpret_cast<const uint32_t*>(b + xpo);
-                } else if (yin && zv[dz]) {
-                    const char* b = zp[dz] + ro;                   // uniform base; 32-bit lane offsets
                     w[dz * 3 + 0] = *reinterpret_cast<const uint32_t*>(b + xmo);
                     w[dz * 3 + 1] = *reinterpret_cast<const uint32_t*>(b + xo);
                     w[dz * 3 + 2] = *reinterpret_cast<const uint32_t*>(b + xpo);
@@ -387,7 +388,16 @@ jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
                 cand(w0[dz * 3 + 0], hasM); if (dz != 1) cand(w0[dz * 3 + 1], true); cand(w0[dz * 3 + 2], hasP);
                 cand(wp[dz * 3 + 0], hasM); cand(wp[dz * 3 + 1], true); cand(wp[dz * 3 + 2], hasP);
             }
-            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out + ((size_t)zl * N + y) * N) + xo) = best;
+            const size_t rowIdx = (size_t)zl * N + y;
+            if (FINAL) {
+                // jfa_final's rule (sequential.cpp:55-60,106-109): set voxels carry +, unset ones the sign of the
+                // caller's fill; bestd is +inf when no seed was found, which copysign turns into the fill itself.
+                const uint32_t wbits = words[rowIdx * f.w + (x >> 5)];
+                const bool set = (wbits >> (x & 31)) & 1u;
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(sdf + rowIdx * N) + xo) = set ? bestd : copysignf(bestd, fill);
+            } else {
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out + rowIdx * N) + xo) = best;
+            }
         };
 
         // kChain = 4 steps over a 4-row register ring: the row needed by the NEXT step is requested
@@ -493,33 +503,45 @@ static int jfa_zorder(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t** 
 int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
                     const uint32_t* d_plus, uint32_t* d_out, int algo)
 {
+    return launch_jfa_pass_ex(ctx, f, k, d_in, d_minus, d_plus, d_out, algo, nullptr, 0.0f, nullptr);
+}
+
+bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo)
+{
+    return algo == VP_ALGO_TILED && f.n >= 256;
+}
+
+// d_sdf != nullptr: this is the last pass and it writes the sdf directly (only where
+// jfa_pass_can_fuse_final() says so); otherwise ids go to d_out.
+int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
+                       const uint32_t* d_plus, uint32_t* d_out, int algo, const uint32_t* d_words, float fill, float* d_sdf)
+{
     const size_t total = (size_t)f.n * f.n * (f.z1 - f.z0);
+    const uint32_t nz = f.z1 - f.z0;
     ProfScope p(ctx, VP_K_JFA_PASS);
     if (algo == VP_ALGO_NAIVE) {
         const unsigned blocks = (unsigned)((total + 255) / 256);
         hipLaunchKernelGGL(jfa_pass_direct, dim3(blocks), dim3(256), 0, ctx->stream, f, k, d_in, d_minus, d_plus, d_out);
-    } else {
-        if (f.n >= 256) {
-            const uint32_t* zorder = nullptr;
-            VP_TRY(jfa_zorder(ctx, f, k, &zorder));
-            // early passes: large k => many rows outside the grid and a sparse state => wave-level skipping pays
-            if (!ctx->none_row.ptr) {                                             // a row of kNone for out-of-grid reads
-                VP_TRY(reserve(ctx, ctx->none_row, kTab * sizeof(uint32_t)));
-                VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, kTab * sizeof(uint32_t), ctx->stream));
-            }
-            const uint32_t* none_row = (const uint32_t*)ctx->none_row.ptr;
-            const uint32_t chainLen = (f.n + k - 1) / k;                       // rows per residue class
-            const dim3 grid(k * ((chainLen + kChain - 1) / kChain), f.z1 - f.z0);
-            const bool skip = k * 4 >= f.n, chk = f.n >= 1024;
-#define VP_LAUNCH_CHAIN(S, C) hipLaunchKernelGGL((jfa_pass_chain<S, C>), grid, dim3(256), 0, ctx->stream, f, k, d_in, d_minus, d_plus, d_out, zorder, none_row)
-            if (skip) { if (chk) VP_LAUNCH_CHAIN(true, true); else VP_LAUNCH_CHAIN(true, false); }
-            else      { if (chk) VP_LAUNCH_CHAIN(false, true); else VP_LAUNCH_CHAIN(false, false); }
-#undef VP_LAUNCH_CHAIN
-            VP_HIP(hipGetLastError());
-            return 0;
+    } else if (f.n >= 256) {
+        const uint32_t* zorder = nullptr;
+        VP_TRY(jfa_zorder(ctx, f, k, &zorder));
+        if (!ctx->none_row.ptr) {                                  // a row of kNone for out-of-grid reads
+            VP_TRY(reserve(ctx, ctx->none_row, kTab * sizeof(uint32_t)));
+            VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, kTab * sizeof(uint32_t), ctx->stream));
         }
+        const uint32_t* none_row = (const uint32_t*)ctx->none_row.ptr;
+        const uint32_t chainLen = (f.n + k - 1) / k;               // rows per residue class
+        const dim3 grid(k * ((chainLen + kChain - 1) / kChain), nz);
+        const bool skip = k * 4 >= f.n, chk = f.n >= 1024, fin = d_sdf != nullptr;
+#define VP_LAUNCH_CHAIN(S, C, F) hipLaunchKernelGGL((jfa_pass_chain<S, C, F>), grid, dim3(256), 0, ctx->stream, f, k, d_in, \
+                                                    d_minus, d_plus, d_out, zorder, none_row, d_words, fill, d_sdf)
+        if (fin)       { if (chk) VP_LAUNCH_CHAIN(false, true, true);  else VP_LAUNCH_CHAIN(false, false, true); }
+        else if (skip) { if (chk) VP_LAUNCH_CHAIN(true, true, false);  else VP_LAUNCH_CHAIN(true, false, false); }
+        else           { if (chk) VP_LAUNCH_CHAIN(false, true, false); else VP_LAUNCH_CHAIN(false, false, false); }
+#undef VP_LAUNCH_CHAIN
+    } else {
         const int RY = (int)(256 / f.n);
-        const dim3 grid((f.n + RY - 1) / RY, f.z1 - f.z0);
+        const dim3 grid((f.n + RY - 1) / RY, nz);
         const size_t lds = (size_t)(2 + RY) * kTab * sizeof(float);
         hipLaunchKernelGGL(jfa_pass_table, grid, dim3(256), lds, ctx->stream, f, k, d_in, d_minus, d_plus, d_out, RY,
                            (const uint32_t*)nullptr);

@@ -90,6 +90,9 @@ int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const 
                     const uint32_t* above, uint32_t* d_ids, uint32_t* d_border_words);
 int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
                     const uint32_t* d_plus, uint32_t* d_out, int algo);
+bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo);
+int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
+                       const uint32_t* d_plus, uint32_t* d_out, int algo, const uint32_t* d_words, float fill, float* d_sdf);
 int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* d_ids,
                      float fill, float* d_sdf);
 

@@ -131,6 +131,12 @@ int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const uint32_t* d_in
                 const uint32_t* d_minus, const uint32_t* d_plus, uint32_t* d_out, int algo);
 int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const uint32_t* d_ids,
                     float fill_unset, float* d_sdf);
+/* The last pass (step k = 1) and the finalize in one call: where the kernel supports it the pass writes
+ * the sdf directly and the id volume is neither written nor re-read; d_scratch (one id volume) is used
+ * only when it does not.  Same result as vp_jfa_pass(k = 1) + vp_jfa_finalize. */
+int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_in, const uint32_t* d_minus,
+                     const uint32_t* d_plus, uint32_t* d_scratch, const uint32_t* d_words, float fill_unset,
+                     float* d_sdf, int algo);
 
 /* "Surface" output (README.md:9): the border-voxel mask that JFA seeds
  * from (jfa/sequential.cpp:24-64), as a bitmask with the grid's layout. */

@@ -71,8 +71,6 @@ class CpuSlabBackend:
     def jfa_pass(self, frame, k, src, minus, plus, dst, algo):
         n, z0, z1 = frame.n, frame.z0, frame.z1
         nz = z1 - z0
-        f32 = np.float32
-        vs, ox, oy, oz = f32(frame.voxel_size), f32(frame.origin[0]), f32(frame.origin[1]), f32(frame.origin[2])
         S = _np(src).reshape(nz, n, n)
         M = _np(minus).reshape(-1, n, n) if minus is not None else None
         P = _np(plus).reshape(-1, n, n) if plus is not None else None
@@ -87,6 +85,28 @@ class CpuSlabBackend:
                 return P[zg - max(z1, z0 + k)]
             return S[zg - z0]
 
+        _np(dst)[:] = self._pass(frame, k, plane).reshape(-1)
+
+    # -- whole-grid buffers addressed by global plane (GhostSlabPipeline) --
+    def jfa_pass_global(self, region, k, src_full, dst_full, algo):
+        n = region.n
+        A = _np(src_full).reshape(n, n, n)
+        none_plane = np.full((n, n), NONE, np.int32)
+        best = self._pass(region, k, lambda zg: A[zg] if 0 <= zg < n else none_plane)
+        _np(dst_full).reshape(n, n, n)[region.z0:region.z1] = best
+
+    def jfa_last_pass_global(self, region, src_full, scratch_full, words_region, fill, sdf, algo):
+        n = region.n
+        self.jfa_pass_global(region, 1, src_full, scratch_full, algo)
+        ids = torch.from_numpy(_np(scratch_full).reshape(n, n, n)[region.z0:region.z1].reshape(-1).copy())
+        self.jfa_finalize(region, words_region, ids, fill, sdf)
+
+    def _pass(self, frame, k, plane):
+        n, z0, z1 = frame.n, frame.z0, frame.z1
+        nz = z1 - z0
+        f32 = np.float32
+        vs, ox, oy, oz = f32(frame.voxel_size), f32(frame.origin[0]), f32(frame.origin[1]), f32(frame.origin[2])
+        S = np.stack([plane(zg) for zg in range(z0, z1)], 0)
         zz, yy, xx = np.meshgrid(np.arange(z0, z1), np.arange(n), np.arange(n), indexing="ij")
         px = ox + xx.astype(f32) * vs
         py = oy + yy.astype(f32) * vs
@@ -105,7 +125,7 @@ class CpuSlabBackend:
                     take = (c != NONE) & (d < bestd)
                     bestd = np.where(take, d, bestd)
                     best = np.where(take, c, best)
-        _np(dst)[:] = best.reshape(-1)
+        return best
 
     def jfa_finalize(self, frame, words, ids, fill, sdf):
         n, nz = frame.n, frame.z1 - frame.z0

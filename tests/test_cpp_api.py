@@ -1,0 +1,64 @@
+"""C++ vplib mirror used as a library (not through the CLI): every Types value, T = uint32_t and
+uint64_t (reference instantiations: vox/sequential.cpp:65-69, vox/tiled.cu:619-622, ...)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cuda_mesh_voxelization_amd import build, mesh as M
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api_check(tmp_path_factory):
+    build.build_lib()
+    exe = str(tmp_path_factory.mktemp("cpp") / "api_check")
+    pkg = os.path.join(ROOT, "cuda_mesh_voxelization_amd")
+    srcs = [os.path.join(pkg, "vplib", "src", f) for f in sorted(os.listdir(os.path.join(pkg, "vplib", "src"))) if f.endswith(".cpp")]
+    subprocess.check_call(["g++", "-std=c++23", "-O2", "-ffp-contract=off", "-fopenmp",
+                           "-I", os.path.join(pkg, "vplib", "include"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "api_check.cpp")] + srcs +
+                          ["-o", exe, "-L", pkg, "-lvphip", "-Wl,-rpath," + pkg])
+    return exe
+
+
+def _expected(name, n):
+    xyz, tri = M.import_mesh(M.asset(name))
+    origin, vs = O.frame([xyz], n)
+    g = O.voxelize(xyz, tri, n, vs, origin)
+    h = g.copy()
+    h[: (n // 2) * n * n // 32] = 0
+    d = O.csg(g.copy(), h, 3)
+    i = O.csg(g.copy(), h, 2)
+    u = O.csg(d.copy(), i, 1)
+    assert np.array_equal(u, g)
+    s = O.jfa(g, n, vs, origin)
+    return {"vox": [O.fnv(g)], "csg": [O.fnv(d), O.fnv(i), O.fnv(u)], "sdf": [O.fnv(s)]}
+
+
+def _check(out, tags, exp):
+    got = {}
+    for line in out.strip().splitlines():
+        p = line.split()
+        got[(p[0], p[1])] = p[2:]
+    for t in tags:
+        for k, v in exp.items():
+            assert got[(t, k)] == v, (t, k, got[(t, k)], v)
+
+
+def test_cpp_api_cpu_variants(api_check):
+    exp = _expected("sphere.obj", 32)
+    p = subprocess.run([api_check, M.asset("sphere.obj"), "32", "0"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    _check(p.stdout, ["seq32", "seq64", "omp32"], exp)
+
+
+@pytest.mark.gpu
+def test_cpp_api_gpu_variants(api_check):
+    exp = _expected("bunny.obj", 64)
+    p = subprocess.run([api_check, M.asset("bunny.obj"), "64", "1"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    _check(p.stdout, ["seq32", "seq64", "omp32", "naive32", "naive64", "tiled32", "tiled64"], exp)

@@ -95,3 +95,60 @@ def test_halo_plan_covers_exactly_what_a_pass_reads():
             k //= 2
     with pytest.raises(ValueError):
         slab_range(64, 0, 16)          # 4 planes per slab: not a multiple of the 8-row tile
+
+
+def _ghost_worker(rank, world, port, n, asset, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuda_mesh_voxelization_amd import mesh as M
+        from cuda_mesh_voxelization_amd.capi import Frame
+        from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
+        from slab_cpu_backend import CpuSlabBackend
+        mesh = M.import_mesh(M.asset(asset))
+        origin, vs = M.frame([mesh[0]], n)
+        pipe = GhostSlabPipeline(CpuSlabBackend(mesh), Frame.make(n, vs, origin), rank, world)
+        pipe.voxelize(None, None)
+        sdf = pipe.jfa()
+        dist.barrier()
+        np.save(os.path.join(outdir, "sdf_%d.npy" % rank), sdf.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,asset", [(2, 32, "sphere.obj"), (4, 32, "torus.obj")])
+def test_ghost_slab_pipeline_matches_single_domain_oracle(tmp_path, world, n, asset):
+    sys.path.insert(0, ROOT)
+    from cuda_mesh_voxelization_amd import mesh as M
+    from oracle import oracle as O
+    mp.spawn(_ghost_worker, args=(world, _free_port(), n, asset, str(tmp_path)), nprocs=world, join=True)
+    xyz, tri = M.import_mesh(M.asset(asset))
+    origin, vs = M.frame([xyz], n)
+    exp = O.jfa(O.voxelize(xyz, tri, n, vs, origin), n, vs, origin)
+    got = np.concatenate([np.load(tmp_path / ("sdf_%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_ghost_regions_feed_each_other():
+    """Each pass must produce (at least) the slab widened by the reach of all later passes, and what it
+    reads there must have been produced by the previous pass.  (Regions are rounded outwards to the
+    8-plane tile; the rounding extras may read stale planes -- their values are never consumed.)"""
+    sys.path.insert(0, ROOT)
+    from cuda_mesh_voxelization_amd.slab import ghost_regions, slab_range
+    for n, world in ((64, 2), (64, 8), (512, 8), (512, 4), (1024, 4), (1024, 8)):
+        for rank in range(world):
+            regs = ghost_regions(n, rank, world)
+            z0, z1 = slab_range(n, rank, world)
+            assert regs[-1][1:] == (z0, z1) and regs[-1][0] == 1          # last pass = bare slab
+            ks = [k for k, _, _ in regs]
+            prev_valid = (0, n)                                             # init covers the whole grid
+            for i, (k, b0, b1) in enumerate(regs):
+                g = sum(ks[i + 1:])
+                u0, u1 = max(0, z0 - g), min(n, z1 + g)                    # planes whose values matter
+                assert b0 % 8 == 0 and b1 % 8 == 0 and 0 <= b0 <= u0 < u1 <= b1 <= n
+                r0, r1 = max(0, u0 - k), min(n, u1 + k)                    # what those planes read
+                assert prev_valid[0] <= r0 and r1 <= prev_valid[1], (n, world, rank, k)
+                prev_valid = (u0, u1)

@@ -91,3 +91,23 @@ def test_slabs_equal_whole_grid(engine, world, n, name, algo):
     words, sdf = _run_slabs(world, fr, xyz, tri, algo)
     assert np.array_equal(words, ref_w)
     assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,n,name", [(2, 64, "bunny.obj"), (4, 64, "torus.obj"), (8, 256, "bunny.obj"), (4, 512, "bimba.obj")])
+def test_ghost_slabs_equal_whole_grid(engine, world, n, name):
+    """Communication-free variant: every emulated rank recomputes its ghost planes; no exchange at all."""
+    from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
+    xyz, tri = M.import_mesh(M.asset(name))
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    ref_w = engine.voxelize(fr, dx, dt)
+    ref_s = engine.jfa(fr, ref_w).cpu().numpy()
+    parts = []
+    for r in range(world):
+        pipe = GhostSlabPipeline(HipSlabBackend(engine), fr, r, world)
+        pipe.voxelize(dx, dt)
+        parts.append(pipe.jfa().cpu().numpy())
+        del pipe
+    sdf = np.concatenate(parts)
+    assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
