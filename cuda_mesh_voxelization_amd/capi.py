@@ -20,7 +20,8 @@ SYMBOLS = [
     "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_stream", "vp_ctx_sync", "vp_last_error", "vp_abi_version",
     "vp_malloc", "vp_free", "vp_memset", "vp_upload", "vp_download", "vp_grid_words", "vp_grid_voxels",
     "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa", "vp_jfa_init", "vp_jfa_pass",
-    "vp_jfa_finalize", "vp_jfa_last_pass", "vp_surface", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
+    "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass",
+    "vp_surface", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
 ]
 
@@ -99,6 +100,8 @@ def lib():
         "vp_jfa_pass": (ctypes.c_int, [_vp, fp, ctypes.c_uint32, _vp, _vp, _vp, _vp, ctypes.c_int]),
         "vp_jfa_finalize": (ctypes.c_int, [_vp, fp, _vp, _vp, ctypes.c_float, _vp]),
         "vp_jfa_last_pass": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int]),
+        "vp_jfa_can_start_from_mask": (ctypes.c_int, [fp, ctypes.c_int]),
+        "vp_jfa_first_pass": (ctypes.c_int, [_vp, fp, _vp, _vp]),
         "vp_surface": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
         "vp_voxelize_host": (ctypes.c_int, [_vp, fp, _vp, _vp, _sz, _vp, _sz, ctypes.c_int]),
         "vp_csg_host": (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int]),
@@ -196,6 +199,12 @@ class Context:
                       algo: int = ALGO_TILED):
         check(lib().vp_jfa_last_pass(self._h, ctypes.byref(frame), _vp(d_in), _vp(d_minus or None), _vp(d_plus or None),
                                      _vp(d_scratch), _vp(d_words), fill, _vp(d_sdf), algo))
+
+    def jfa_can_start_from_mask(self, frame: Frame, algo: int = ALGO_TILED) -> bool:
+        return bool(lib().vp_jfa_can_start_from_mask(ctypes.byref(frame), algo))
+
+    def jfa_first_pass(self, frame: Frame, d_border_grid: int, d_out: int):
+        check(lib().vp_jfa_first_pass(self._h, ctypes.byref(frame), _vp(d_border_grid), _vp(d_out)))
 
     def surface(self, frame: Frame, d_words: int, d_below, d_above, d_border: int):
         check(lib().vp_surface(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_below or None),

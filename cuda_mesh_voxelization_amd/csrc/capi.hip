@@ -217,7 +217,11 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
     return launch_csg(ctx, d_a, d_b, nwords, op);
 }
 
-size_t vp_jfa_workspace_bytes(const vp_frame* f) { return f ? 2 * vp_grid_voxels(f) * sizeof(uint32_t) : 0; }
+size_t vp_jfa_workspace_bytes(const vp_frame* f)
+{
+    // two id volumes + border mask
+    return f ? 2 * vp_grid_voxels(f) * sizeof(uint32_t) + vp_grid_words(f) * 4 : 0;
+}
 
 static int check_fill(float fill, const char* who)
 {
@@ -274,14 +278,38 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
     const Frame fr = make_frame(f);
     uint32_t* a = (uint32_t*)d_work;
     uint32_t* b = a + vp_grid_voxels(f);
-    VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, a, nullptr));
-    for (uint32_t k = f->n / 2; k >= 1; k /= 2) {                  // jfa/sequential.cpp:72
+    uint32_t k = f->n / 2;                                         // jfa/sequential.cpp:72
+    if (jfa_can_start_from_mask(fr, algo) && k > 1) {
+        // border mask -> first pass directly (no init id volume)
+        uint32_t* border = b + vp_grid_voxels(f);
+        VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, nullptr, border));
+        VP_TRY(launch_jfa_first_pass(ctx, fr, border, a));
+        k /= 2;
+    } else {
+        VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, a, nullptr));
+    }
+    for (; k >= 1; k /= 2) {
         if (k == 1 && jfa_pass_can_fuse_final(fr, k, algo))        // last pass writes the sdf itself
             return launch_jfa_pass_ex(ctx, fr, k, a, nullptr, nullptr, b, algo, d_words, fill_unset, d_sdf);
         VP_TRY(launch_jfa_pass(ctx, fr, k, a, nullptr, nullptr, b, algo));
         uint32_t* t = a; a = b; b = t;
     }
     return launch_jfa_final(ctx, fr, d_words, a, fill_unset, d_sdf);
+}
+
+int vp_jfa_can_start_from_mask(const vp_frame* f, int algo)
+{
+    return (f && check_frame(f, "vp_jfa_can_start_from_mask", false) == 0 && jfa_can_start_from_mask(make_frame(f), algo)) ? 1 : 0;
+}
+
+int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, uint32_t* d_out)
+{
+    if (!ctx || !d_border_grid || !d_out) return set_error(VP_ERR_INVALID, "vp_jfa_first_pass: null argument");
+    VP_TRY(check_frame(f, "vp_jfa_first_pass", false));
+    const Frame fr = make_frame(f);
+    if (!jfa_can_start_from_mask(fr, VP_ALGO_TILED))
+        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_pass: needs n >= 256 and n %% 128 == 0");
+    return launch_jfa_first_pass(ctx, fr, d_border_grid, d_out);
 }
 
 int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_in, const uint32_t* d_minus, const uint32_t* d_plus,

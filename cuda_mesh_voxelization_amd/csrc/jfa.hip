@@ -167,6 +167,75 @@ jfa_pass_direct(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint
     out[gid] = best;
 }
 
+// First pass (k = n/2) straight from the border bitmask.  Before any pass the state is trivial: a border
+// voxel's seed is itself, everything else is none (sequential.cpp:55-60), so the first pass needs no id
+// volume at all -- a candidate exists iff its border bit is set and its id is its own coordinates.  This
+// drops the 4 n^3-byte id volume jfa_init would write and this pass would read back.
+// One wave = one 64-voxel x-segment.  Requires n % 128 == 0, so k is a multiple of 64 and every candidate
+// segment of a wave is exactly two aligned mask words.  Lane q of the wave fetches the words of candidate
+// segment q -- ONE vector load instruction per wave (the vector-memory instruction rate, not bytes, is
+// what limits these kernels; one scalar load per segment was measured 10x slower: the scalar cache thrashes
+// on 16 lines per wave) -- and v_readlane distributes the 27 masks as wave-uniform values, so segments
+// without border bits are skipped with scalar branches.  The pass is a pure store stream: 4 n^3 bytes out.
+// `border` is the border mask of the WHOLE grid (vp_surface); the kernel produces the planes of `f`.
+constexpr int kFirstRows = 8;     // rows per wave: their mask loads are all in flight before the first is used
+
+__global__ void __launch_bounds__(256)
+jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, uint32_t* __restrict__ out)
+{
+    const int N = (int)f.n;
+    const int lane = threadIdx.x & 63;
+    const int x0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 256u + (threadIdx.x & ~63u)));   // segment start
+    if (x0 >= N) return;                                            // whole wave
+    const int x = x0 + lane;
+    const int ybase = blockIdx.y * kFirstRows;
+    const int zl = blockIdx.z;
+    const int zg = zl + (int)f.z0;
+
+    // Lane q (< 27) fetches the two mask words of candidate segment q, so the whole wave issues ONE vector
+    // load per row; v_readlane then hands every lane all 27 segment masks as wave-uniform values.
+    const int q = lane;
+    const int qz = zg + (q / 9 - 1) * (int)k, qdy = ((q / 3) % 3 - 1) * (int)k, qx0 = x0 + (q % 3 - 1) * (int)k;
+    const bool qin = q < 27 && qz >= 0 && qz < N && qx0 >= 0 && qx0 < N;
+    uint2 mine[kFirstRows];
+#pragma unroll
+    for (int r = 0; r < kFirstRows; ++r) {
+        const int ny = ybase + r + qdy;
+        mine[r] = make_uint2(0u, 0u);
+        if (qin && ny >= 0 && ny < N)
+            mine[r] = *reinterpret_cast<const uint2*>(border + ((((size_t)qz * N + ny) * N + qx0) >> 5));   // 8-byte aligned: qx0 % 64 == 0
+    }
+    const float px = axis_pos(f.ox, x, f.vs), pz = axis_pos(f.oz, zg, f.vs);
+#pragma unroll
+    for (int r = 0; r < kFirstRows; ++r) {
+        const int y = ybase + r;
+        const unsigned long long own = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].x, 13) |
+                                       ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].y, 13) << 32);
+        uint32_t best = kNone;
+        float bestd = INFINITY;
+        if ((own >> lane) & 1ull) { best = pack_id(x, y, zg); bestd = 0.0f; }            // own seed: distance 0 (:56)
+        // one ballot tells whether ANY neighbour segment holds a border voxel; for most waves none does
+        if (__any(lane != 13 && (mine[r].x | mine[r].y) != 0u)) {
+            const float py = axis_pos(f.oy, y, f.vs);
+#pragma unroll
+            for (int c = 0; c < 27; ++c) {                         // reference scan order z, y, x (sequential.cpp:86-88)
+                if (c == 13) continue;
+                const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].x, c) |
+                                             ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].y, c) << 32);
+                if (m == 0ull) continue;                           // scalar branch
+                const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
+                const bool has = (m >> lane) & 1ull;
+                const uint32_t id = pack_id((uint32_t)(x + dx * (int)k), (uint32_t)(y + dy * (int)k), (uint32_t)(zg + dz * (int)k));
+                const float d = seed_distance(f, id, px, py, pz);
+                const bool take = has & (d < bestd);
+                bestd = take ? d : bestd;
+                best = take ? id : best;
+            }
+        }
+        out[((size_t)zl * N + y) * N + x] = best;
+    }
+}
+
 // Table variant.  Workgroup = RY consecutive x-rows of one z (RY = 1 when n >= 256).
 // LDS: PX[i] = ox + i*vs; TZ[i] = (PZ[i]-pz)^2 for this z; TY[r][i] = (PY[i]-py_r)^2 for row r.
 // dist = ((PX[ix]-px)^2 + TY[iy]) + TZ[iz]  -- the same float operations as seed_distance().
@@ -336,7 +405,6 @@ jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
         const float px = PX[x];
         const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
         const uint32_t xo = x * 4u, xmo = hasM ? xo - k * 4u : xo, xpo = hasP ? xo + k * 4u : xo;
-
         // 9 ids of source row yy (3 planes x {x-k, x, x+k}); kNone where the row/plane is outside the grid
         auto load_row = [&](int yy, uint32_t (&w)[9]) {
             const bool yin = yy >= 0 && yy < N;                    // wave-uniform
@@ -344,9 +412,14 @@ jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz) {
                 // uniform base + 32-bit lane offsets -> global_load ... saddr
-                if (!SKIP || (yin && zv[dz])) {
-                    // !SKIP: branch-free, a row outside the grid reads from a row of kNone (uniform pointer select)
+                if (!SKIP) {
+                    // branch-free, a row outside the grid reads from a row of kNone (uniform pointer select)
                     const char* b = (yin && zv[dz]) ? zp[dz] + ro : reinterpret_cast<const char*>(none_row);
+                    w[dz * 3 + 0] = *reinterpret_cast<const uint32_t*>(b + xmo);
+                    w[dz * 3 + 1] = *reinterpret_cast<const uint32_t*>(b + xo);
+                    w[dz * 3 + 2] = *reinterpret_cast<const uint32_t*>(b + xpo);
+                } else if (yin && zv[dz]) {
+                    const char* b = zp[dz] + ro;
                     w[dz * 3 + 0] = *reinterpret_cast<const uint32_t*>(b + xmo);
                     w[dz * 3 + 1] = *reinterpret_cast<const uint32_t*>(b + xo);
                     w[dz * 3 + 2] = *reinterpret_cast<const uint32_t*>(b + xpo);
@@ -504,6 +577,18 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_i
                     const uint32_t* d_plus, uint32_t* d_out, int algo)
 {
     return launch_jfa_pass_ex(ctx, f, k, d_in, d_minus, d_plus, d_out, algo, nullptr, 0.0f, nullptr);
+}
+
+bool jfa_can_start_from_mask(const Frame& f, int algo) { return algo == VP_ALGO_TILED && f.n >= 256 && f.n % 128 == 0; }
+
+// First pass from the whole-grid border mask (see jfa_first_pass).
+int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, uint32_t* d_out)
+{
+    ProfScope p(ctx, VP_K_JFA_PASS);
+    hipLaunchKernelGGL(jfa_first_pass, dim3((f.n + 255) / 256, f.n / kFirstRows, f.z1 - f.z0), dim3(256), 0, ctx->stream, f, f.n / 2,
+                       d_border, d_out);
+    VP_HIP(hipGetLastError());
+    return 0;
 }
 
 bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo)

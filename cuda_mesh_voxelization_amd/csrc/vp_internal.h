@@ -93,6 +93,8 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_i
 bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo);
 int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
                        const uint32_t* d_plus, uint32_t* d_out, int algo, const uint32_t* d_words, float fill, float* d_sdf);
+bool jfa_can_start_from_mask(const Frame& f, int algo);
+int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, uint32_t* d_out);
 int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* d_ids,
                      float fill, float* d_sdf);
 

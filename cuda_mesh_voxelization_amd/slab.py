@@ -77,6 +77,15 @@ class HipSlabBackend:
         src, minus, plus, dst = self._global_ptrs(region, k, src_full, dst_full)
         self.ctx.jfa_pass(region, k, src, minus, plus, dst, algo)
 
+    def can_start_from_mask(self, frame, algo):
+        return self.ctx.jfa_can_start_from_mask(frame, algo)
+
+    def surface(self, frame, words, border):
+        self.ctx.surface(frame, words.data_ptr(), None, None, border.data_ptr())
+
+    def jfa_first_pass_global(self, region, border_full, dst_full):
+        self.ctx.jfa_first_pass(region, border_full.data_ptr(), dst_full.data_ptr() + region.z0 * region.n * region.n * 4)
+
     def jfa_last_pass_global(self, region, src_full, scratch_full, words_region, fill, sdf, algo):
         src, minus, plus, scratch = self._global_ptrs(region, 1, src_full, scratch_full)
         self.ctx.jfa_last_pass(region, src, minus, plus, scratch, words_region.data_ptr(), fill, sdf.data_ptr(), algo)
@@ -242,6 +251,7 @@ class GhostSlabPipeline:
         self.ids = [self.be.empty_u32(frame.voxels), self.be.empty_u32(frame.voxels)]
         self.sdf = self.be.empty_f32(self.frame.voxels)             # own slab only
         self.planes_computed = sum(b1 - b0 for _, b0, b1 in self.regions)
+        self.border = None
 
     def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
         out = self.words if out is None else out
@@ -255,10 +265,21 @@ class GhostSlabPipeline:
     def jfa(self, algo=ALGO_TILED, fill=-math.inf, out=None):
         out = self.sdf if out is None else out
         a, b = self.ids
-        self.be.jfa_init(self.global_frame, self.words, None, None, a)
         last = len(self.regions) - 1
+        mask_start = last > 0 and hasattr(self.be, "can_start_from_mask") and self.be.can_start_from_mask(self.global_frame, algo)
+        if mask_start:
+            # border mask of the whole grid -> first pass directly (no init id volume), see vp_jfa_first_pass
+            if self.border is None:
+                self.border = self.be.empty_u32(self.global_frame.words)
+            self.be.surface(self.global_frame, self.words, self.border)
+        else:
+            self.be.jfa_init(self.global_frame, self.words, None, None, a)
         for i, (k, b0, b1) in enumerate(self.regions):
             region = self.global_frame.slab(b0, b1)
+            if i == 0 and mask_start:
+                self.be.jfa_first_pass_global(region, self.border, b)
+                a, b = b, a
+                continue
             if i == last:
                 pw = self.global_frame.n * self.global_frame.n // 32
                 self.be.jfa_last_pass_global(region, a, b, self.words[b0 * pw:b1 * pw], fill, out, algo)

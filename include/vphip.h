@@ -112,7 +112,7 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
  * vp_jfa runs init + all passes + finalize on one device for a whole-grid frame.
  *   fill_unset  value the caller pre-filled the sdf with (apps/cli/main.cpp:200 uses -INFINITY);
  *               must be +-infinity (a finite fill is undefined behaviour in the reference).
- *   d_work      scratch of vp_jfa_workspace_bytes(f) bytes (two id volumes).
+ *   d_work      scratch of vp_jfa_workspace_bytes(f) bytes (two id volumes + border mask).
  *   algo        VP_ALGO_NAIVE: direct kernel; VP_ALGO_TILED: LDS-table kernel.  Same results. */
 size_t vp_jfa_workspace_bytes(const vp_frame* f);
 int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
@@ -137,6 +137,14 @@ int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, con
 int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_in, const uint32_t* d_minus,
                      const uint32_t* d_plus, uint32_t* d_scratch, const uint32_t* d_words, float fill_unset,
                      float* d_sdf, int algo);
+
+/* Sparse start (n >= 256, n % 128 == 0, VP_ALGO_TILED; vp_jfa uses it internally).  Before any pass a border
+ * voxel's seed is itself and nothing else has one (jfa/sequential.cpp:55-60), so the first pass (k = n/2) can run
+ * straight from the border bitmask of the WHOLE grid (vp_surface on a whole-grid frame): no init id volume is
+ * written or read.  vp_jfa_first_pass produces the ids after step n/2 for the planes of f; the result is
+ * identical to vp_jfa_init + vp_jfa_pass(k = n/2). */
+int vp_jfa_can_start_from_mask(const vp_frame* f, int algo);
+int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, uint32_t* d_out);
 
 /* "Surface" output (README.md:9): the border-voxel mask that JFA seeds
  * from (jfa/sequential.cpp:24-64), as a bitmask with the grid's layout. */
