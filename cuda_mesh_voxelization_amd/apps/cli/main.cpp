@@ -11,7 +11,8 @@
 //     -b, --block-size B     tiled block size hint (multiple of 16; accepted for compatibility)
 //     -m, --benckmark M      iterations; M > 1 = benchmark mode (mesh 0 only, CSG against an empty grid)
 //     -o, --output NAME      output name (default out.obj)
-//     -e, --export           export phases as OBJ (not built in this round: prints a notice)
+//     -e, --export           export phases as OBJ into out/ (created if missing): per-mesh grids, the CSG result,
+//                            sdf-coloured cubes and point cloud -- file names as in the reference
 //     -d, --dump PREFIX      (extension) write PREFIX.grid.u32 and PREFIX.sdf.f32 raw little-endian dumps
 //     -h, --help
 #include <cmath>
@@ -19,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
 #include <map>
 #include <span>
 #include <string>
@@ -29,6 +31,7 @@
 #include "debug_utils.h"
 #include "grid/voxels_grid.h"
 #include "jfa/jfa.h"
+#include "mesh/grid_to_mesh.h"
 #include "mesh/mesh.h"
 #include "mesh/mesh_io.h"
 #include "proc_utils.h"
@@ -180,6 +183,8 @@ int main(int argc, char** argv)
 
     HostVoxelsGrid<gridType> emptyGrid(N, voxelSize);       // benchmark-mode CSG operand (main.cpp:89,127)
     HostGrid<float> sdf;
+    const std::string typeName = GetTypesString(TYPE);
+    if (EXPORT) std::filesystem::create_directories("out");
 
     for (unsigned iter = 0; iter < opt.iterations; ++iter) {
         for (size_t i = 0; i < meshes.size(); ++i) {
@@ -191,6 +196,12 @@ int main(int argc, char** argv)
                 case Types::OPENMP: Voxelize<Types::SEQUENTIAL>(opt.blockSize, grid, meshes[i]); break;   // main.cpp:99-103
                 case Types::NAIVE:  Voxelize<Types::NAIVE>(opt.blockSize, grid, meshes[i]); break;
                 case Types::TILED:  Voxelize<Types::TILED>(opt.blockSize, grid, meshes[i]); break;
+            }
+            if (EXPORT) {                                                                               // main.cpp:118-124
+                Mesh outMesh;
+                VoxelsGridToMeshCompressed(grid.View(), outMesh);
+                cpuAssert(ExportMesh("out/" + typeName + "_" + GetFilename(opt.filenames[i]), outMesh),
+                          "Error in " + typeName + " " + opt.filenames[i] + " export");
             }
             if (i > 0 || BENCHMARK) {
                 HostVoxelsGrid<gridType>& operand = BENCHMARK ? emptyGrid : grid;
@@ -204,6 +215,12 @@ int main(int argc, char** argv)
             if (BENCHMARK) break;
         }
 
+        if (EXPORT && OPERATION != CSG::Op::VOID) {                                                     // main.cpp:192-197
+            Mesh outMesh;
+            VoxelsGridToMeshCompressed(grids[0].View(), outMesh);
+            cpuAssert(ExportMesh("out/csg_vox_" + typeName + "_" + opt.output, outMesh), "Error in " + opt.output + " export (csg)");
+        }
+
         if (opt.sdf) {
             sdf = HostGrid<float>(N, -INFINITY);                                                        // main.cpp:200
             switch (TYPE) {
@@ -212,11 +229,16 @@ int main(int argc, char** argv)
                 case Types::NAIVE:      JFA::Compute<Types::NAIVE>(grids[0], sdf); break;
                 case Types::TILED:      JFA::Compute<Types::TILED>(grids[0], sdf); break;
             }
+            if (EXPORT) {                                                                               // main.cpp:220-230
+                Mesh outMesh;
+                VoxelsGridToMesh(grids[0].View(), sdf.View(), outMesh);
+                cpuAssert(ExportMesh("out/sdf_" + typeName + "_" + opt.output, outMesh), "Error in " + opt.output + " export (sdf)");
+                VoxelsGridToPointCloud(grids[0].View(), sdf.View(), outMesh);
+                cpuAssert(ExportMesh("out/sdf_point_cloud_" + typeName + "_" + opt.output, outMesh),
+                          "Error in " + opt.output + " export (sdf)");
+            }
         }
     }
-
-    if (EXPORT)
-        std::printf("export (-e) of grid meshes / point clouds is not part of this build (see DESIGN.md, out of scope rows)\n");
 
     if (!opt.dump.empty()) {
         WriteRaw(opt.dump + ".grid.u32", grids[0].View().Data(), grids[0].View().StorageSize() * sizeof(gridType));

@@ -4,6 +4,7 @@
 #include "vox/vox.h"
 
 #include <cmath>
+#include <cstdio>
 
 #include "debug_utils.h"
 #include "profiling.h"
@@ -96,12 +97,30 @@ void Device(int algo, const char* label, uint32_t* words, size_t n, float vs, co
         gpuAssert(vp_upload(ctx, dXyz, mesh.Coords.data(), nverts * sizeof(Position)));
         gpuAssert(vp_upload(ctx, dTri, mesh.FacesCoords.data(), ntris * 3 * sizeof(uint32_t)));
     }
+#if PROFILING
+    gpuAssert(vp_prof_reset(ctx));
+    gpuAssert(vp_prof_enable(ctx, 1));
+#endif
     {
         PROFILING_SCOPE(L + "::Processing");
         gpuAssert(vp_voxelize(ctx, &f, static_cast<uint32_t*>(dWords), static_cast<const float*>(dXyz), nverts,
                               static_cast<const uint32_t*>(dTri), ntris, algo, /*accumulate=*/0));
         gpuAssert(vp_ctx_sync(ctx));
     }
+#if PROFILING
+    gpuAssert(vp_prof_enable(ctx, 0));
+    if (algo == VP_ALGO_TILED) {
+        // Device time of the binning stages under the reference's TileAssignment labels (vox/tiled.cu:31-236), so
+        // that its benchmark CSV columns keep their meaning: setup = overlap test + histogram, scan = offsets,
+        // scatter = work-queue population.  Nothing is sorted or compacted here (XOR accumulation is order-free).
+        auto ms = [&](int kernel) { double t = 0; uint64_t c = 0; gpuAssert(vp_prof_get(ctx, kernel, &t, &c)); return t; };
+        std::printf("[TiledVox::TileAssignment::CalculateOverlap]: %f ms\n", ms(VP_K_VOX_SETUP));
+        std::printf("[TiledVox::TileAssignment::ExclusiveScan]: %f ms\n", ms(VP_K_VOX_SCAN));
+        std::printf("[TiledVox::TileAssignment::WorkQueuePopulation]: %f ms\n", ms(VP_K_VOX_SCATTER));
+        std::printf("[TiledVox::TileAssignment::WorkQueueSorting]: %f ms\n", 0.0);
+        std::printf("[TiledVox::TileAssignment::CompactResult]: %f ms\n", 0.0);
+    }
+#endif
     {
         PROFILING_SCOPE(L + "::Memory");
         gpuAssert(vp_download(ctx, words, dWords, gridBytes));

@@ -107,3 +107,35 @@ def test_cli_benchmark_mode(cli, tmp_path):
     x2, _ = M.import_mesh(M.asset("torus.obj"))
     origin, vs = O.frame([xyz, x2], 64)
     assert np.array_equal(np.fromfile(prefix + ".grid.u32", np.uint32), O.voxelize(xyz, tri, 64, vs, origin))
+
+
+def test_cli_export_meshes(cli, tmp_path):
+    """-e: surface mesh of the grid, sdf-coloured cubes and point cloud (apps/cli/main.cpp:118-124,192-197,220-230)."""
+    n = 32
+    p = subprocess.run([cli, M.asset("sphere.obj"), M.asset("torus.obj"), "-n", str(n), "-t", "0", "-p", "1", "-s", "-e",
+                        "-o", "res.obj", "-d", str(tmp_path / "d")], capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = tmp_path / "out"
+    names = sorted(f.name for f in out.iterdir())
+    assert names == ["csg_vox_sequential_res.obj", "sdf_point_cloud_sequential_res.obj", "sdf_sequential_res.obj",
+                     "sequential_sphere.obj", "sequential_torus.obj"]
+    words = np.fromfile(str(tmp_path / "d.grid.u32"), np.uint32)
+    sdf = np.fromfile(str(tmp_path / "d.sdf.f32"), np.float32)
+    occ = np.unpackbits(words.view(np.uint8), bitorder="little").reshape(n, n, n).astype(bool)
+    # exposed faces: set voxel next to an unset voxel or the grid boundary, per direction
+    pad = np.pad(occ, 1)
+    exposed = sum(int((occ & ~np.roll(pad, s, ax)[1:-1, 1:-1, 1:-1]).sum()) for ax in range(3) for s in (1, -1))
+    xyz, tri = M.import_mesh(str(out / "csg_vox_sequential_res.obj"))
+    assert tri.shape[0] == 2 * exposed
+    assert len(np.unique(xyz, axis=0)) == xyz.shape[0]                     # vertices are shared, not duplicated
+    # closed surface: every edge is used by an even number of triangles, and with consistent orientation
+    t = tri.astype(np.int64)
+    e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]], 0)
+    key = e[:, 0] * (t.max() + 1) + e[:, 1]
+    rkey = e[:, 1] * (t.max() + 1) + e[:, 0]
+    assert np.array_equal(np.sort(key), np.sort(rkey))                     # each directed edge has its opposite
+    pc_xyz, _ = M.import_mesh(str(out / "sdf_point_cloud_sequential_res.obj"))
+    assert pc_xyz.shape[0] == int(occ.sum())
+    cubes_xyz, cubes_tri = M.import_mesh(str(out / "sdf_sequential_res.obj"))
+    finite_set = int((occ.reshape(-1) & np.isfinite(sdf)).sum())
+    assert cubes_xyz.shape[0] == 8 * finite_set and cubes_tri.shape[0] == 12 * finite_set
