@@ -3,6 +3,7 @@ table, and size-independent properties at the benchmark size.  Bar: bit-exact fo
 the SDF is compared bit-exactly too (tolerance of the north star: 1e-4 relative -- asserted as
 well, so a future non-bit-exact kernel still has a written bound)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -236,3 +237,37 @@ def test_headline_size_properties(engine):
     # every distance is at least the exact distance to the nearest border voxel along x (cheap lower bound 0) and
     # at most the squared grid diagonal
     assert float(np.abs(s).max()) <= 3.0 * (512 * float(vs)) ** 2
+
+
+def test_config2_bunny_x3_n256(engine):
+    """BASELINE config 2: bunny refined x3 (168,516 faces), n = 256, tiled voxelize + JFA -- against the oracle."""
+    xyz, tri = M.bunny(3)
+    assert tri.shape[0] == 168516
+    fr, origin, vs = _frame([(xyz, tri)], 256)
+    exp_w = O.voxelize(xyz, tri, 256, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    g = engine.voxelize(fr, dx, dt, algo=ALGO_TILED)
+    assert np.array_equal(engine.words_to_numpy(g), exp_w)
+    _assert_sdf_equal(engine.jfa(fr, g, algo=ALGO_TILED).cpu().numpy(), O.jfa(exp_w, 256, vs, origin))
+
+
+def test_config4_bunny_x24_n1024(engine):
+    """BASELINE config 4 on one GPU: 1,348,128 faces, n = 1024.  Bitmask against the oracle; the SDF against the
+    oracle too when the host has the memory for the reference's 32 B/voxel state (34 GB), else JFA kernels
+    against each other."""
+    import psutil
+    xyz, tri = M.bunny(24)
+    n = 1024
+    fr, origin, vs = _frame([(xyz, tri)], n)
+    exp_w = O.voxelize(xyz, tri, n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    g = engine.voxelize(fr, dx, dt, algo=ALGO_TILED)
+    assert np.array_equal(engine.words_to_numpy(g), exp_w)
+    s = engine.jfa(fr, g, algo=ALGO_TILED)
+    if psutil.virtual_memory().available > 80 * 2**30 and (os.cpu_count() or 1) >= 32:
+        exp = O.jfa(exp_w, n, vs, origin)
+        got = s.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    else:
+        s2 = engine.jfa(fr, g, algo=ALGO_NAIVE)
+        assert torch.equal(s.view(torch.int32), s2.view(torch.int32))
