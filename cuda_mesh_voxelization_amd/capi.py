@@ -19,7 +19,7 @@ KERNELS = ["vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox
 SYMBOLS = [
     "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_stream", "vp_ctx_sync", "vp_last_error", "vp_abi_version",
     "vp_malloc", "vp_free", "vp_memset", "vp_upload", "vp_download", "vp_grid_words", "vp_grid_voxels",
-    "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa", "vp_jfa_init", "vp_jfa_pass",
+    "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa", "vp_jfa_init", "vp_jfa_pass",
     "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass",
     "vp_surface", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
@@ -95,6 +95,7 @@ def lib():
         "vp_voxelize": (ctypes.c_int, [_vp, fp, _vp, _vp, _sz, _vp, _sz, ctypes.c_int, ctypes.c_int]),
         "vp_csg": (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int]),
         "vp_jfa_workspace_bytes": (_sz, [fp]),
+        "vp_jfa_id_bytes": (_sz, [fp]),
         "vp_jfa": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_float, _vp, _vp, _sz, ctypes.c_int]),
         "vp_jfa_init": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
         "vp_jfa_pass": (ctypes.c_int, [_vp, fp, ctypes.c_uint32, _vp, _vp, _vp, _vp, ctypes.c_int]),
@@ -179,6 +180,10 @@ class Context:
 
     def jfa_workspace_bytes(self, frame: Frame) -> int:
         return int(lib().vp_jfa_workspace_bytes(ctypes.byref(frame)))
+
+    def jfa_id_bytes(self, frame: Frame) -> int:
+        """Bytes of JFA state per voxel: 4 for n <= 1024, 8 for n <= 2048."""
+        return int(lib().vp_jfa_id_bytes(ctypes.byref(frame)))
 
     def jfa(self, frame: Frame, d_words: int, fill: float, d_sdf: int, d_work: int, work_bytes: int,
             algo: int = ALGO_TILED):

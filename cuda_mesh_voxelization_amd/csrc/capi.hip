@@ -80,8 +80,8 @@ static int prof_fold(vp_ctx* ctx)
 static int check_frame(const vp_frame* f, const char* who, bool whole)
 {
     if (!f) return set_error(VP_ERR_INVALID, "%s: null frame", who);
-    if (f->n < 32 || f->n > 1024 || (f->n % 32) != 0)
-        return set_error(VP_ERR_UNSUPPORTED, "%s: n=%u unsupported (need 32 <= n <= 1024, n %% 32 == 0)", who, f->n);
+    if (f->n < 32 || f->n > 2048 || (f->n % 32) != 0)
+        return set_error(VP_ERR_UNSUPPORTED, "%s: n=%u unsupported (need 32 <= n <= 2048, n %% 32 == 0)", who, f->n);
     if (!(f->z0 < f->z1) || f->z1 > f->n || (f->z0 % 8) != 0 || (f->z1 % 8) != 0)
         return set_error(VP_ERR_INVALID, "%s: bad slab [%u,%u) for n=%u (multiples of 8 required)", who, f->z0, f->z1, f->n);
     if (whole && !(f->z0 == 0 && f->z1 == f->n))
@@ -130,7 +130,7 @@ int vp_ctx_destroy(vp_ctx* ctx)
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buffer* bufs[] = { &ctx->rec, &ctx->tile_cnt, &ctx->tile_off, &ctx->tile_cur, &ctx->pairs, &ctx->scratch, &ctx->zorder, &ctx->none_row };
+    Buffer* bufs[] = { &ctx->rec, &ctx->tile_cnt, &ctx->tile_off, &ctx->tile_cur, &ctx->pairs, &ctx->scratch, &ctx->none_row };
     for (Buffer* b : bufs) if (b->ptr) (void)hipFree(b->ptr);
     for (auto& s : ctx->prof_pending) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
@@ -220,8 +220,10 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
 size_t vp_jfa_workspace_bytes(const vp_frame* f)
 {
     // two id volumes + border mask
-    return f ? 2 * vp_grid_voxels(f) * sizeof(uint32_t) + vp_grid_words(f) * 4 : 0;
+    return f ? 2 * vp_grid_voxels(f) * vp_jfa_id_bytes(f) + vp_grid_words(f) * 4 : 0;
 }
+
+size_t vp_jfa_id_bytes(const vp_frame* f) { return (f && f->n > 1024) ? 8 : 4; }
 
 static int check_fill(float fill, const char* who)
 {
@@ -230,7 +232,7 @@ static int check_fill(float fill, const char* who)
 }
 
 int vp_jfa_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const uint32_t* d_plane_below,
-                const uint32_t* d_plane_above, uint32_t* d_ids)
+                const uint32_t* d_plane_above, void* d_ids)
 {
     if (!ctx || !d_words || !d_ids) return set_error(VP_ERR_INVALID, "vp_jfa_init: null argument");
     VP_TRY(check_frame(f, "vp_jfa_init", false));
@@ -245,8 +247,8 @@ int vp_surface(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const ui
     return launch_jfa_init(ctx, make_frame(f), d_words, d_plane_below, d_plane_above, nullptr, d_border_words);
 }
 
-int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
-                const uint32_t* d_plus, uint32_t* d_out, int algo)
+int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const void* d_in, const void* d_minus,
+                const void* d_plus, void* d_out, int algo)
 {
     if (!ctx || !d_in || !d_out || d_in == d_out) return set_error(VP_ERR_INVALID, "vp_jfa_pass: bad buffers");
     VP_TRY(check_frame(f, "vp_jfa_pass", false));
@@ -258,7 +260,7 @@ int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const uint32_t* d_in
     return launch_jfa_pass(ctx, make_frame(f), k, d_in, d_minus, d_plus, d_out, algo);
 }
 
-int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const uint32_t* d_ids,
+int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const void* d_ids,
                     float fill_unset, float* d_sdf)
 {
     if (!ctx || !d_words || !d_ids || !d_sdf) return set_error(VP_ERR_INVALID, "vp_jfa_finalize: null argument");
@@ -276,12 +278,13 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_jfa: algo %d", algo);
     if (work_bytes < vp_jfa_workspace_bytes(f)) return set_error(VP_ERR_INVALID, "vp_jfa: workspace too small");
     const Frame fr = make_frame(f);
-    uint32_t* a = (uint32_t*)d_work;
-    uint32_t* b = a + vp_grid_voxels(f);
+    const size_t volBytes = vp_grid_voxels(f) * vp_jfa_id_bytes(f);
+    char* a = (char*)d_work;
+    char* b = a + volBytes;
     uint32_t k = f->n / 2;                                         // jfa/sequential.cpp:72
     if (jfa_can_start_from_mask(fr, algo) && k > 1) {
         // border mask -> first pass directly (no init id volume)
-        uint32_t* border = b + vp_grid_voxels(f);
+        uint32_t* border = (uint32_t*)(b + volBytes);
         VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, nullptr, border));
         VP_TRY(launch_jfa_first_pass(ctx, fr, border, a));
         k /= 2;
@@ -292,7 +295,7 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
         if (k == 1 && jfa_pass_can_fuse_final(fr, k, algo))        // last pass writes the sdf itself
             return launch_jfa_pass_ex(ctx, fr, k, a, nullptr, nullptr, b, algo, d_words, fill_unset, d_sdf);
         VP_TRY(launch_jfa_pass(ctx, fr, k, a, nullptr, nullptr, b, algo));
-        uint32_t* t = a; a = b; b = t;
+        char* t = a; a = b; b = t;
     }
     return launch_jfa_final(ctx, fr, d_words, a, fill_unset, d_sdf);
 }
@@ -302,7 +305,7 @@ int vp_jfa_can_start_from_mask(const vp_frame* f, int algo)
     return (f && check_frame(f, "vp_jfa_can_start_from_mask", false) == 0 && jfa_can_start_from_mask(make_frame(f), algo)) ? 1 : 0;
 }
 
-int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, uint32_t* d_out)
+int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out)
 {
     if (!ctx || !d_border_grid || !d_out) return set_error(VP_ERR_INVALID, "vp_jfa_first_pass: null argument");
     VP_TRY(check_frame(f, "vp_jfa_first_pass", false));
@@ -312,8 +315,8 @@ int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_g
     return launch_jfa_first_pass(ctx, fr, d_border_grid, d_out);
 }
 
-int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_in, const uint32_t* d_minus, const uint32_t* d_plus,
-                     uint32_t* d_scratch, const uint32_t* d_words, float fill_unset, float* d_sdf, int algo)
+int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const void* d_minus, const void* d_plus,
+                     void* d_scratch, const uint32_t* d_words, float fill_unset, float* d_sdf, int algo)
 {
     if (!ctx || !d_in || !d_scratch || !d_words || !d_sdf || d_in == d_scratch)
         return set_error(VP_ERR_INVALID, "vp_jfa_last_pass: bad buffers");

@@ -6,20 +6,21 @@
 // same float expressions for positions (:79-81) and distances (jfa/jfa.h:19-20), Jacobi update.
 //
 // State: the reference keeps float sdf + float3 seed position per voxel (16 B, two copies, plus a
-// deep copy per pass, :123-124).  Here the state is ONE uint32 per voxel -- the packed voxel
-// coordinates of the best seed so far (scr(y)<<2 | x<<12 | scr(z)<<22, 0xFFFFFFFF = none).  The seed position
-// and the distance are recomputed from it with the reference's expressions, which gives the same
-// floats because the reference's stored sdf is itself the result of exactly that expression.
+// deep copy per pass, :123-124).  Here the state is ONE packed id per voxel -- the voxel coordinates of
+// the best seed so far (4 bytes for n <= 1024, 8 bytes for n <= 2048; "none" = all ones).  The seed
+// position and the distance are recomputed from it with the reference's expressions, which gives the
+// same floats because the reference's stored sdf is itself the result of exactly that expression.
 // Ping-pong between two id volumes; the last step converts ids to floats.
 //
-// Kernels
-//   jfa_init      bitmask -> ids (and/or border bitmask).  One lane = one 32-voxel word: the 26-
-//                 neighbourhood test is 27 word loads + shifts/ANDs; ids leave as coalesced 16-B
-//                 stores after a wave shuffle transposes word-per-lane into voxels-per-lane.
-//   jfa_pass_direct   (VP_ALGO_NAIVE) one thread per voxel, everything recomputed inline.
-//   jfa_pass_chain    (VP_ALGO_TILED, n >= 256) LDS coordinate tables + register sliding window over
-//                 rows k apart; jfa_pass_table is the small-n variant of the table idea.
-//   jfa_final     ids + bitmask -> float sdf.
+// Kernels (all templated on the id format)
+//   jfa_init        bitmask -> ids (and/or border bitmask).  One lane = one 32-voxel word: the 26-
+//                   neighbourhood test is 27 word loads + shifts/ANDs; ids leave as coalesced 16-B
+//                   stores after a wave shuffle transposes word-per-lane into voxels-per-lane.
+//   jfa_first_pass  step k = n/2 straight from the border bitmask (no init id volume).
+//   jfa_pass_direct (VP_ALGO_NAIVE) one thread per voxel, everything recomputed inline.
+//   jfa_pass_zchain (VP_ALGO_TILED, n >= 256) LDS coordinate tables + register sliding window over
+//                   planes k apart; jfa_pass_table is the small-n variant of the table idea.
+//   jfa_final       ids + bitmask -> float sdf.
 //
 // Built with -ffp-contract=off (an FMA changes the result).
 #include "vp_internal.h"
@@ -30,26 +31,56 @@ namespace vp {
 
 namespace {
 
-// id layout: bits [2..11] scr(y), [12..21] x, [22..31] scr(z), bits [0,1] zero -- every field is already
-// a byte offset into a float table after one shift+mask.  y sits in the low field because its table is
-// the one looked up once per candidate AND chain step (a single AND); x and z are decoded once per id.
-// kNone has bits 0,1 set.
-// The y and z fields hold scr(y), scr(z): the low five bits XORed with the next five.  Seeds reached
-// by jumps of 2^j >= 32 differ from the voxel only in high coordinate bits; unscrambled they would all
-// index the same LDS bank of the TY/TZ tables (measured: passes k = 32, 16 ran 2x slower).  scr is an
+// The y and z fields of an id hold scr(y), scr(z): the low five bits XORed with the next five.  Seeds
+// reached by jumps of 2^j >= 32 differ from the voxel only in high coordinate bits; unscrambled they would
+// all index the same LDS bank of the TY/TZ tables (measured: passes k = 32, 16 ran 2x slower).  scr is an
 // involution and stays inside [0, n) because n % 32 == 0.
 __device__ __forceinline__ uint32_t scr(uint32_t i) { return i ^ ((i >> 5) & 31u); }
-__device__ __forceinline__ uint32_t pack_id(uint32_t x, uint32_t y, uint32_t z) { return (scr(y) << 2) | (x << 12) | (scr(z) << 22); }
+
+// Id formats.  Every coordinate field is stored pre-multiplied by 4, i.e. it already is a byte offset into
+// a float table after one shift+mask.  z sits in the lowest field because its table is the one looked up once
+// per candidate AND chain step (a single AND); x and y are decoded once per id.  A real id has bits 0,1 of its
+// first word clear, "none" has them set.
+struct Id32 {                     // n <= 1024: bits [2..11] scr(z), [12..21] x, [22..31] scr(y)
+    using T = uint32_t;
+    static constexpr int kTab = 1024;             // table entries: any 10-bit field (also those of none) stays in bounds
+    static constexpr uint32_t kMask = 0xFFCu;
+    __device__ static __forceinline__ T none() { return 0xFFFFFFFFu; }
+    __device__ static __forceinline__ bool is_none(T a) { return a == 0xFFFFFFFFu; }
+    __device__ static __forceinline__ T pack(uint32_t x, uint32_t y, uint32_t z) { return (scr(z) << 2) | (x << 12) | (scr(y) << 22); }
+    __device__ static __forceinline__ T add_x(T a, uint32_t dx) { return a + (dx << 12); }
+    __device__ static __forceinline__ uint32_t zoff(T a) { return a & kMask; }
+    __device__ static __forceinline__ uint32_t xoff(T a) { return (a >> 10) & kMask; }
+    __device__ static __forceinline__ uint32_t yoff(T a) { return (a >> 20) & kMask; }
+    __device__ static __forceinline__ T sel(bool c, T a, T b) { return c ? a : b; }
+    __device__ static __forceinline__ T shfl(T a, int src) { return (T)__shfl((int)a, src); }
+};
+
+struct Id64 {                     // n <= 2048: .x = scr(z)<<2 | x<<13, .y = scr(y)<<2
+    using T = uint2;
+    static constexpr int kTab = 2048;
+    static constexpr uint32_t kMask = 0x1FFCu;
+    __device__ static __forceinline__ T none() { return make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu); }
+    __device__ static __forceinline__ bool is_none(T a) { return a.x == 0xFFFFFFFFu; }
+    __device__ static __forceinline__ T pack(uint32_t x, uint32_t y, uint32_t z) { return make_uint2((scr(z) << 2) | (x << 13), scr(y) << 2); }
+    __device__ static __forceinline__ T add_x(T a, uint32_t dx) { return make_uint2(a.x + (dx << 13), a.y); }
+    __device__ static __forceinline__ uint32_t zoff(T a) { return a.x & kMask; }
+    __device__ static __forceinline__ uint32_t xoff(T a) { return (a.x >> 11) & kMask; }
+    __device__ static __forceinline__ uint32_t yoff(T a) { return a.y & kMask; }
+    __device__ static __forceinline__ T sel(bool c, T a, T b) { return make_uint2(c ? a.x : b.x, c ? a.y : b.y); }
+    __device__ static __forceinline__ T shfl(T a, int src) { return make_uint2((uint32_t)__shfl((int)a.x, src), (uint32_t)__shfl((int)a.y, src)); }
+};
 
 // jfa/sequential.cpp:79-81 / :32-34 : voxel corner position along one axis
 __device__ __forceinline__ float axis_pos(float o, uint32_t i, float vs) { return o + ((float)(int)i * vs); }
 
 // jfa/jfa.h:19-20 with p1 = seed position decoded from `id`, p0 = (px,py,pz)
-__device__ __forceinline__ float seed_distance(const Frame& f, uint32_t id, float px, float py, float pz)
+template <class ID>
+__device__ __forceinline__ float seed_distance(const Frame& f, typename ID::T id, float px, float py, float pz)
 {
-    const float sx = axis_pos(f.ox, (id >> 12) & 1023u, f.vs);
-    const float sy = axis_pos(f.oy, scr((id >> 2) & 1023u), f.vs);
-    const float sz = axis_pos(f.oz, scr(id >> 22), f.vs);
+    const float sx = axis_pos(f.ox, ID::xoff(id) >> 2, f.vs);
+    const float sy = axis_pos(f.oy, scr(ID::yoff(id) >> 2), f.vs);
+    const float sz = axis_pos(f.oz, scr(ID::zoff(id) >> 2), f.vs);
     return ((sx - px) * (sx - px)) + ((sy - py) * (sy - py)) + ((sz - pz) * (sz - pz));
 }
 
@@ -67,11 +98,23 @@ __device__ __forceinline__ uint32_t grid_word(const Frame& f, const uint32_t* __
     return words[(size_t)(zg - (int)f.z0) * f.n * f.w + inPlane];
 }
 
-template <bool IDS, bool MASK>
+__device__ __forceinline__ void store4(uint32_t* base, size_t quad, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    reinterpret_cast<uint4*>(base)[quad] = make_uint4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(uint2* base, size_t quad, uint2 a, uint2 b, uint2 c, uint2 d)
+{
+    uint4* p = reinterpret_cast<uint4*>(base) + quad * 2;
+    p[0] = make_uint4(a.x, a.y, b.x, b.y);
+    p[1] = make_uint4(c.x, c.y, d.x, d.y);
+}
+
+template <class ID, bool IDS, bool MASK>
 __global__ void __launch_bounds__(256)
 jfa_init(Frame f, const uint32_t* __restrict__ words, const uint32_t* __restrict__ below,
-         const uint32_t* __restrict__ above, uint32_t* __restrict__ ids, uint32_t* __restrict__ border_words)
+         const uint32_t* __restrict__ above, typename ID::T* __restrict__ ids, uint32_t* __restrict__ border_words)
 {
+    using T = typename ID::T;
     const int lane = threadIdx.x & 63;
     const size_t wbase = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;   // first word of this wave
     const size_t wi = wbase + lane;
@@ -98,28 +141,25 @@ jfa_init(Frame f, const uint32_t* __restrict__ words, const uint32_t* __restrict
     }
     if (MASK) border_words[wi] = border;
     if (IDS) {
-        const uint32_t mybase = pack_id((uint32_t)xw * 32u, (uint32_t)y, (uint32_t)zg);
+        const T mybase = ID::pack((uint32_t)xw * 32u, (uint32_t)y, (uint32_t)zg);
         const int sub = (lane & 7) * 4;
-        uint4* out = reinterpret_cast<uint4*>(ids + wbase * 32);
+        T* out = ids + wbase * 32;
 #pragma unroll 4
         for (int j = 0; j < 8; ++j) {
             const int src = j * 8 + (lane >> 3);
             const uint32_t b = (__shfl(border, src) >> sub) & 0xFu;
-            const uint32_t id0 = __shfl(mybase, src) + ((uint32_t)sub << 12);
-            uint4 v;
-            v.x = (b & 1u) ? id0 : kNone;
-            v.y = (b & 2u) ? id0 + (1u << 12) : kNone;
-            v.z = (b & 4u) ? id0 + (2u << 12) : kNone;
-            v.w = (b & 8u) ? id0 + (3u << 12) : kNone;
-            out[j * 64 + lane] = v;
+            const T id0 = ID::add_x(ID::shfl(mybase, src), (uint32_t)sub);
+            store4(out, (size_t)j * 64 + lane,
+                   ID::sel(b & 1u, id0, ID::none()), ID::sel(b & 2u, ID::add_x(id0, 1u), ID::none()),
+                   ID::sel(b & 4u, ID::add_x(id0, 2u), ID::none()), ID::sel(b & 8u, ID::add_x(id0, 3u), ID::none()));
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------ pass
 // Plane of global z `zg` among the three id buffers of a slab (see vphip.h, vp_jfa_pass).
-__device__ __forceinline__ const uint32_t* id_plane(const Frame& f, uint32_t k, const uint32_t* in,
-                                                    const uint32_t* minus, const uint32_t* plus, int zg)
+template <class T>
+__device__ __forceinline__ const T* id_plane(const Frame& f, uint32_t k, const T* in, const T* minus, const T* plus, int zg)
 {
     const size_t plane = (size_t)f.n * f.n;
     if (zg < (int)f.z0) return minus + (size_t)(zg - ((int)f.z0 - (int)k)) * plane;
@@ -130,25 +170,27 @@ __device__ __forceinline__ const uint32_t* id_plane(const Frame& f, uint32_t k, 
     return in + (size_t)(zg - (int)f.z0) * plane;
 }
 
+template <class ID>
 __global__ void __launch_bounds__(256)
-jfa_pass_direct(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
-                const uint32_t* __restrict__ plus, uint32_t* __restrict__ out)
+jfa_pass_direct(Frame f, uint32_t k, const typename ID::T* __restrict__ in, const typename ID::T* __restrict__ minus,
+                const typename ID::T* __restrict__ plus, typename ID::T* __restrict__ out)
 {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)f.n * f.n * (f.z1 - f.z0);
-    if (gid >= total) return;
+    using T = typename ID::T;
+    // grid = (n*n/256, planes): n*n is a multiple of 1024, and 2-D keeps the thread count per dimension < 2^32 at n = 2048
+    const uint32_t inPlane = blockIdx.x * 256u + threadIdx.x;
+    const size_t gid = (size_t)blockIdx.y * f.n * f.n + inPlane;
     const int N = (int)f.n;
-    const int x = (int)(gid % f.n);
-    const int y = (int)((gid / f.n) % f.n);
-    const int zg = (int)(gid / ((size_t)f.n * f.n)) + (int)f.z0;
+    const int x = (int)(inPlane % f.n);
+    const int y = (int)(inPlane / f.n);
+    const int zg = (int)blockIdx.y + (int)f.z0;
     const float px = axis_pos(f.ox, x, f.vs), py = axis_pos(f.oy, y, f.vs), pz = axis_pos(f.oz, zg, f.vs);
 
-    uint32_t best = in[gid];
-    float bestd = (best == kNone) ? INFINITY : seed_distance(f, best, px, py, pz);   // = fabs(sdf), :84
+    T best = in[gid];
+    float bestd = ID::is_none(best) ? INFINITY : seed_distance<ID>(f, best, px, py, pz);   // = fabs(sdf), :84
     for (int dz = -1; dz <= 1; ++dz) {
         const int nz = zg + dz * (int)k;
         if (nz < 0 || nz >= N) continue;
-        const uint32_t* pl = id_plane(f, k, in, minus, plus, nz);
+        const T* pl = id_plane(f, k, in, minus, plus, nz);
         for (int dy = -1; dy <= 1; ++dy) {
             const int ny = y + dy * (int)k;
             if (ny < 0 || ny >= N) continue;
@@ -156,9 +198,9 @@ jfa_pass_direct(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint
                 if (dx == 0 && dy == 0 && dz == 0) continue;
                 const int nx = x + dx * (int)k;
                 if (nx < 0 || nx >= N) continue;
-                const uint32_t c = pl[(size_t)ny * N + nx];
-                if (c != kNone) {                                  // fabs(seed) < INFINITY, :102
-                    const float d = seed_distance(f, c, px, py, pz);
+                const T c = pl[(size_t)ny * N + nx];
+                if (!ID::is_none(c)) {                             // fabs(seed) < INFINITY, :102
+                    const float d = seed_distance<ID>(f, c, px, py, pz);
                     if (d < bestd) { bestd = d; best = c; }        // :106-110
                 }
             }
@@ -170,19 +212,21 @@ jfa_pass_direct(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint
 // First pass (k = n/2) straight from the border bitmask.  Before any pass the state is trivial: a border
 // voxel's seed is itself, everything else is none (sequential.cpp:55-60), so the first pass needs no id
 // volume at all -- a candidate exists iff its border bit is set and its id is its own coordinates.  This
-// drops the 4 n^3-byte id volume jfa_init would write and this pass would read back.
+// drops the id volume jfa_init would write and this pass would read back.
 // One wave = one 64-voxel x-segment.  Requires n % 128 == 0, so k is a multiple of 64 and every candidate
 // segment of a wave is exactly two aligned mask words.  Lane q of the wave fetches the words of candidate
-// segment q -- ONE vector load instruction per wave (the vector-memory instruction rate, not bytes, is
-// what limits these kernels; one scalar load per segment was measured 10x slower: the scalar cache thrashes
-// on 16 lines per wave) -- and v_readlane distributes the 27 masks as wave-uniform values, so segments
-// without border bits are skipped with scalar branches.  The pass is a pure store stream: 4 n^3 bytes out.
+// segment q -- ONE vector load instruction per wave and row (the vector-memory instruction rate, not bytes,
+// is what limits these kernels; one scalar load per segment was measured 10x slower: the scalar cache
+// thrashes on 16 lines per wave) -- and v_readlane distributes the masks as wave-uniform values, so
+// segments without border bits are skipped with scalar branches.  The pass is a pure store stream.
 // `border` is the border mask of the WHOLE grid (vp_surface); the kernel produces the planes of `f`.
 constexpr int kFirstRows = 8;     // rows per wave: their mask loads are all in flight before the first is used
 
+template <class ID>
 __global__ void __launch_bounds__(256)
-jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, uint32_t* __restrict__ out)
+jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out)
 {
+    using T = typename ID::T;
     const int N = (int)f.n;
     const int lane = threadIdx.x & 63;
     const int x0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 256u + (threadIdx.x & ~63u)));   // segment start
@@ -192,8 +236,6 @@ jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, uint32_
     const int zl = blockIdx.z;
     const int zg = zl + (int)f.z0;
 
-    // Lane q (< 27) fetches the two mask words of candidate segment q, so the whole wave issues ONE vector
-    // load per row; v_readlane then hands every lane all 27 segment masks as wave-uniform values.
     const int q = lane;
     const int qz = zg + (q / 9 - 1) * (int)k, qdy = ((q / 3) % 3 - 1) * (int)k, qx0 = x0 + (q % 3 - 1) * (int)k;
     const bool qin = q < 27 && qz >= 0 && qz < N && qx0 >= 0 && qx0 < N;
@@ -211,9 +253,9 @@ jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, uint32_
         const int y = ybase + r;
         const unsigned long long own = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].x, 13) |
                                        ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].y, 13) << 32);
-        uint32_t best = kNone;
+        T best = ID::none();
         float bestd = INFINITY;
-        if ((own >> lane) & 1ull) { best = pack_id(x, y, zg); bestd = 0.0f; }            // own seed: distance 0 (:56)
+        if ((own >> lane) & 1ull) { best = ID::pack(x, y, zg); bestd = 0.0f; }           // own seed: distance 0 (:56)
         // one ballot tells whether ANY neighbour segment holds a border voxel; for most waves none does
         if (__any(lane != 13 && (mine[r].x | mine[r].y) != 0u)) {
             const float py = axis_pos(f.oy, y, f.vs);
@@ -225,26 +267,26 @@ jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, uint32_
                 if (m == 0ull) continue;                           // scalar branch
                 const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
                 const bool has = (m >> lane) & 1ull;
-                const uint32_t id = pack_id((uint32_t)(x + dx * (int)k), (uint32_t)(y + dy * (int)k), (uint32_t)(zg + dz * (int)k));
-                const float d = seed_distance(f, id, px, py, pz);
+                const T id = ID::pack((uint32_t)(x + dx * (int)k), (uint32_t)(y + dy * (int)k), (uint32_t)(zg + dz * (int)k));
+                const float d = seed_distance<ID>(f, id, px, py, pz);
                 const bool take = has & (d < bestd);
                 bestd = take ? d : bestd;
-                best = take ? id : best;
+                best = ID::sel(take, id, best);
             }
         }
         out[((size_t)zl * N + y) * N + x] = best;
     }
 }
 
-// Table variant.  Workgroup = RY consecutive x-rows of one z (RY = 1 when n >= 256).
+// Table variant for small grids (n < 256, 32-bit ids).  Workgroup = RY consecutive x-rows of one z.
 // LDS: PX[i] = ox + i*vs; TZ[i] = (PZ[i]-pz)^2 for this z; TY[r][i] = (PY[i]-py_r)^2 for row r.
 // dist = ((PX[ix]-px)^2 + TY[iy]) + TZ[iz]  -- the same float operations as seed_distance().
-constexpr int kTab = 1024;     // table stride: any 10-bit field (also those of kNone) stays in bounds
-
 __global__ void __launch_bounds__(256)
 jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
-               const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, int RY, const uint32_t* __restrict__ zorder)
+               const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, int RY)
 {
+    using ID = Id32;
+    constexpr int kTab = ID::kTab;
     extern __shared__ float lds[];
     float* PX = lds;
     float* TZ = lds + kTab;
@@ -252,7 +294,7 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 
     const int N = (int)f.n;
     const int tid = threadIdx.x;
-    const int zl = zorder ? (int)zorder[blockIdx.y] : (int)blockIdx.y;
+    const int zl = (int)blockIdx.y;
     const int zg = zl + (int)f.z0;
     const int y0 = blockIdx.x * RY;
     const float pz = axis_pos(f.oz, zg, f.vs);
@@ -269,9 +311,8 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
     }
     __syncthreads();
 
-    int r, xs, xstep;
-    if (N >= 256) { r = 0; xs = tid; xstep = 256; }
-    else          { r = tid / N; xs = tid - r * N; xstep = N; if (r >= RY) return; }
+    const int r = tid / N, xs = tid - r * N;
+    if (r >= RY) return;
     const int y = y0 + r;
     if (y >= N) return;
     const char* ty = reinterpret_cast<const char*>(TY + r * kTab);
@@ -293,7 +334,7 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
     }
     uint32_t* orow = out + ((size_t)zl * N + y) * N;
 
-    for (int x = xs; x < N; x += xstep) {
+    for (int x = xs; x < N; x += N) {
         const float px = PX[x];
         const int xm = x - (int)k, xp = x + (int)k;
         const bool hasM = xm >= 0, hasP = xp < N;
@@ -313,9 +354,9 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
             // own state first (it wins ties: acceptance is strict, sequential.cpp:106), then scan order
             const int q = (j == 0) ? 13 : (j <= 13 ? j - 1 : j);
             const uint32_t id = c[q];
-            const float sx = *reinterpret_cast<const float*>(tx + ((id >> 10) & 0xFFCu));
-            const float dy2 = *reinterpret_cast<const float*>(ty + (id & 0xFFCu));
-            const float dz2 = *reinterpret_cast<const float*>(tz + ((id >> 20) & 0xFFCu));
+            const float sx = *reinterpret_cast<const float*>(tx + ID::xoff(id));
+            const float dy2 = *reinterpret_cast<const float*>(ty + ID::yoff(id));
+            const float dz2 = *reinterpret_cast<const float*>(tz + ID::zoff(id));
             const float dxv = sx - px;
             const float d = ((dxv * dxv) + dy2) + dz2;
             const bool take = (id != kNone) && (d < bestd);
@@ -326,170 +367,175 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
     }
 }
 
-// Fast path for n >= 256 ("chain" kernel).  A workgroup owns kChain rows of one plane that are k
-// apart: y_j = r + (j0 + j) * k.  Row y_j reads rows y_j - k, y_j, y_j + k, i.e. its chain
-// neighbours, so a thread walks the chain with a sliding 3-row window of candidate ids in registers
-// and loads only ONE new row triple (9 ids) per voxel instead of 27 -- the L1/TA path, not HBM, was
-// the limiter of the straightforward version (measured: 27 loads/voxel cost 43 % of the pass).
-// Per-row LDS tables at fixed addresses turn a candidate id into (seed x, dy^2, dz^2) with 5 VALU
-// ops + 3 ds_read_b32.
+// Fast path for n >= 256 ("chain" kernel).  A workgroup owns ONE x-row position (y fixed) in kChain planes that
+// are k apart, z_j = z0 + r + (j0 + j) * k.  Plane z_j reads planes z_j - k, z_j, z_j + k, i.e. its chain
+// neighbours, so a thread walks the chain with a sliding window of three planes' candidate ids in registers
+// (each plane contributes rows y-k, y, y+k x {x-k, x, x+k}) and loads only ONE new plane triple (9 ids) per
+// voxel instead of 27 -- the vector-memory instruction rate, not HBM, limits this kernel (measured: 27
+// loads/voxel cost 43 % of the pass; every load per voxel costs ~0.02 ms per pass at n = 512).
+// LDS tables at fixed addresses turn id fields into (seed x, dy^2, dz^2).  Because x AND y are the same for every
+// step of the walk, the first association of the distance, fl(dx^2 + dy^2), is a per-id constant that the compiler
+// keeps in ONE register across the three steps an id is used in; only dz^2 (table of the step's plane) is looked
+// up per candidate-step:
+//     per candidate-step   1 AND + 1 ds_read + 1 add + compare + 2 selects          (5 VALU)
+//     per loaded id        x, y decode + 2 ds_read + sub, mul, add                   (7 VALU)
+//     registers per window id   id + fl(dx^2 + dy^2)
+// (A y-chain with per-row TY tables was 7 % slower: 6 VALU per candidate-step and 3 registers per id.)
 //   SKIP = true   (early passes, k >= n/4: sparse state, many rows outside the grid) rows / planes outside
 //                 the grid are skipped with wave-uniform branches and a candidate column in which no lane
 //                 of the wave holds a seed is skipped after a ballot.  (A table-free per-voxel kernel and
 //                 the branch-free variant were both measured slower for these passes.)
-//   SKIP = false  the voxel loop is branch-free (rows outside the grid read a row of kNone through a uniform
+//   SKIP = false  the voxel loop is branch-free (rows outside the grid read a row of "none" through a uniform
 //                 pointer select), so the scheduler overlaps the table reads of all candidates.
-//   CHECK_NONE = false (n < 1024): table slot 1023 can never be a real scrambled coordinate; it
-//                 holds +inf, so a kNone candidate yields d = inf/NaN and loses without a compare.
+//   CHECK_NONE = false (n < table size): the last table slot can never be a real scrambled coordinate; its
+//                 dz^2 entry holds +inf, so a "none" candidate yields d = inf/NaN and loses without a compare.
 //   FINAL = true  last pass (k = 1) fused with the id -> sdf conversion of jfa_final: the winning
 //                 distance is already in a register, so the pass writes floats instead of ids and the
 //                 separate read+write of the id volume disappears.
+// A 4th window slot prefetches the plane of the NEXT step before the current step is evaluated.
 constexpr int kChain = 4;
 
-// launch_bounds: 5 waves/SIMD (<= 96 VGPRs) measured best -- 4 (99 VGPRs) is 6 % slower, 6 spills.
-template <bool SKIP, bool CHECK_NONE, bool FINAL>
-__global__ void __launch_bounds__(256, 5)
-jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
-               const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, const uint32_t* __restrict__ zorder,
-               const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
+// No waves-per-SIMD request: left alone the compiler settles at ~93 VGPRs (5 waves/SIMD, no spills), which
+// measured faster than forcing 5 (86 VGPRs) or 6 (80 VGPRs + scratch).
+template <class ID, bool SKIP, bool CHECK_NONE, bool FINAL>
+__global__ void __launch_bounds__(256)
+jfa_pass_zchain(Frame f, uint32_t k, const typename ID::T* __restrict__ in, const typename ID::T* __restrict__ minus,
+                const typename ID::T* __restrict__ plus, typename ID::T* __restrict__ out,
+                const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
 {
+    using T = typename ID::T;
+    constexpr int kTab = ID::kTab;
     __shared__ float PX[kTab];
-    __shared__ float TZ[kTab];
-    __shared__ float TY[kChain][kTab];
+    __shared__ float TY[kTab];
+    __shared__ float TZ[kChain][kTab];
 
     const int N = (int)f.n;
+    const int nzl = (int)(f.z1 - f.z0);                            // planes in this slab
     const uint32_t tid = threadIdx.x;
-    const int r = (int)(blockIdx.x % k);
-    const int j0 = (int)(blockIdx.x / k) * kChain;
-    const int ybase = r + j0 * (int)k;                           // row of chain element 0 of this workgroup
-    const int zl = zorder ? (int)zorder[blockIdx.y] : (int)blockIdx.y;
-    const int zg = zl + (int)f.z0;
+    const int y = blockIdx.x;
+    const int nres = min((int)k, nzl);                             // residue classes of local plane index mod k
+    const int r = (int)(blockIdx.y % nres);
+    const int j0 = (int)(blockIdx.y / nres) * kChain;
+    const int lbase = r + j0 * (int)k;                             // local plane of chain element 0
+    if (lbase >= nzl) return;
+    const int zbase = lbase + (int)f.z0;                           // global plane
     {
-        const float pz = axis_pos(f.oz, zg, f.vs);
-        float py[kChain];
+        const float py = axis_pos(f.oy, y, f.vs);
+        float pz[kChain];
 #pragma unroll
-        for (int j = 0; j < kChain; ++j) py[j] = axis_pos(f.oy, ybase + j * (int)k, f.vs);
+        for (int j = 0; j < kChain; ++j) pz[j] = axis_pos(f.oz, zbase + j * (int)k, f.vs);
         for (uint32_t i = tid; i < (uint32_t)N; i += 256) {
             const uint32_t si = scr(i);
             PX[i] = axis_pos(f.ox, i, f.vs);
-            const float dzv = axis_pos(f.oz, i, f.vs) - pz;
-            TZ[si] = dzv * dzv;
-            const float sy = axis_pos(f.oy, i, f.vs);
+            const float dyv = axis_pos(f.oy, i, f.vs) - py;
+            TY[si] = dyv * dyv;
+            const float sz = axis_pos(f.oz, i, f.vs);
 #pragma unroll
             for (int j = 0; j < kChain; ++j) {
-                const float dyv = sy - py[j];
-                TY[j][si] = dyv * dyv;
+                const float dzv = sz - pz[j];
+                TZ[j][si] = dzv * dzv;
             }
         }
         if (!CHECK_NONE && tid == 0) {
-            PX[kTab - 1] = 0.0f; TZ[kTab - 1] = INFINITY;
+            PX[kTab - 1] = 0.0f; TY[kTab - 1] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < kChain; ++j) TY[j][kTab - 1] = 0.0f;
+            for (int j = 0; j < kChain; ++j) TZ[j][kTab - 1] = INFINITY;
         }
     }
     __syncthreads();
 
     const char* tx = reinterpret_cast<const char*>(PX);
-    const char* tz = reinterpret_cast<const char*>(TZ);
-    const char* zp[3];                                             // the three source planes (byte pointers)
-    bool zv[3];
+    const char* ty = reinterpret_cast<const char*>(TY);
+    uint32_t ro[3];                                                // byte offsets of rows y-k, y, y+k inside a plane
+    bool yv[3];
+    const uint32_t rowBytes = (uint32_t)N * (uint32_t)sizeof(T);
 #pragma unroll
-    for (int dz = -1; dz <= 1; ++dz) {
-        const int nz = zg + dz * (int)k;
-        zv[dz + 1] = nz >= 0 && nz < N;
-        zp[dz + 1] = reinterpret_cast<const char*>(zv[dz + 1] ? id_plane(f, k, in, minus, plus, nz) : in + (size_t)zl * N * N);
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int ny = y + dy * (int)k;
+        yv[dy + 1] = ny >= 0 && ny < N;
+        ro[dy + 1] = (uint32_t)(yv[dy + 1] ? ny : 0) * rowBytes;
     }
-    const uint32_t rowBytes = (uint32_t)N * 4u;
+    const uint32_t kb = k * (uint32_t)sizeof(T);
 
     for (uint32_t x = tid; x < (uint32_t)N; x += 256) {
         const float px = PX[x];
         const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
-        const uint32_t xo = x * 4u, xmo = hasM ? xo - k * 4u : xo, xpo = hasP ? xo + k * 4u : xo;
-        // 9 ids of source row yy (3 planes x {x-k, x, x+k}); kNone where the row/plane is outside the grid
-        auto load_row = [&](int yy, uint32_t (&w)[9]) {
-            const bool yin = yy >= 0 && yy < N;                    // wave-uniform
-            const uint32_t ro = (uint32_t)(yin ? yy : 0) * rowBytes;
+        const uint32_t xo = x * (uint32_t)sizeof(T), xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;
+
+        // 9 ids of source plane zg (rows y-k, y, y+k x {x-k, x, x+k}); "none" where outside the grid
+        auto load_plane = [&](int zg, T (&w)[9]) {
+            const bool zin = zg >= 0 && zg < N;                    // wave-uniform
+            const char* pl = reinterpret_cast<const char*>(zin ? id_plane(f, k, in, minus, plus, zg) : in);
 #pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {
-                // uniform base + 32-bit lane offsets -> global_load ... saddr
-                if (!SKIP) {
-                    // branch-free, a row outside the grid reads from a row of kNone (uniform pointer select)
-                    const char* b = (yin && zv[dz]) ? zp[dz] + ro : reinterpret_cast<const char*>(none_row);
-                    w[dz * 3 + 0] = *reinterpret_cast<const uint32_t*>(b + xmo);
-                    w[dz * 3 + 1] = *reinterpret_cast<const uint32_t*>(b + xo);
-                    w[dz * 3 + 2] = *reinterpret_cast<const uint32_t*>(b + xpo);
-                } else if (yin && zv[dz]) {
-                    const char* b = zp[dz] + ro;
-                    w[dz * 3 + 0] = *reinterpret_cast<const uint32_t*>(b + xmo);
-                    w[dz * 3 + 1] = *reinterpret_cast<const uint32_t*>(b + xo);
-                    w[dz * 3 + 2] = *reinterpret_cast<const uint32_t*>(b + xpo);
+            for (int dy = 0; dy < 3; ++dy) {
+                if (!SKIP || (zin && yv[dy])) {
+                    const char* b = (zin && yv[dy]) ? pl + ro[dy] : reinterpret_cast<const char*>(none_row);
+                    w[dy * 3 + 0] = *reinterpret_cast<const T*>(b + xmo);
+                    w[dy * 3 + 1] = *reinterpret_cast<const T*>(b + xo);
+                    w[dy * 3 + 2] = *reinterpret_cast<const T*>(b + xpo);
                 } else {
-                    w[dz * 3 + 0] = kNone; w[dz * 3 + 1] = kNone; w[dz * 3 + 2] = kNone;
+                    w[dy * 3 + 0] = ID::none(); w[dy * 3 + 1] = ID::none(); w[dy * 3 + 2] = ID::none();
                 }
             }
         };
 
-        // one chain step: window (wm, w0, wp) = rows (y-k, y, y+k); TY table of this row at `ty`
-        auto step = [&](int y, const char* ty, const uint32_t (&wm)[9], const uint32_t (&w0)[9], const uint32_t (&wp)[9]) {
-            uint32_t best = w0[4];
+        // one chain step: window (wm, w0, wp) = planes (z-k, z, z+k); TZ table of this plane at `tz`
+        auto step = [&](int zg, const char* tz, const T (&wm)[9], const T (&w0)[9], const T (&wp)[9]) {
+            T best = w0[4];
             float bestd = INFINITY;
-            auto eval = [&](uint32_t id, bool ok) {
-#ifdef VP_EXP_NOLDS         /* timing experiment only: same VALU work, no table reads */
-                const float sx = __uint_as_float((id & 0xFFCu) | 0x3f800000u);
-                const float dy2 = __uint_as_float(((id >> 10) & 0xFFCu) | 0x3f800000u);
-                const float dz2 = __uint_as_float(((id >> 20) & 0xFFCu) | 0x3f800000u);
-#else
-                const float sx = *reinterpret_cast<const float*>(tx + ((id >> 10) & 0xFFCu));
-                const float dy2 = *reinterpret_cast<const float*>(ty + (id & 0xFFCu));
-                const float dz2 = *reinterpret_cast<const float*>(tz + ((id >> 20) & 0xFFCu));
-#endif
+            auto eval = [&](T id, bool ok) {
+                const float sx = *reinterpret_cast<const float*>(tx + ID::xoff(id));
+                const float dy2 = *reinterpret_cast<const float*>(ty + ID::yoff(id));
+                const float dz2 = *reinterpret_cast<const float*>(tz + ID::zoff(id));
                 const float dxv = sx - px;
-                const float d = ((dxv * dxv) + dy2) + dz2;
+                const float d = ((dxv * dxv) + dy2) + dz2;        // (dx^2 + dy^2) does not depend on the step: kept per id
                 bool take = ok & (d < bestd);
-                if (CHECK_NONE) take = take & (id != kNone);
+                if (CHECK_NONE) take = take & !ID::is_none(id);
                 bestd = take ? d : bestd;
-                best = take ? id : best;
+                best = ID::sel(take, id, best);
             };
-            auto cand = [&](uint32_t id, bool ok) {
-                if (SKIP) { if (__any(ok & (id != kNone))) eval(id, ok); }
+            auto cand = [&](T id, bool ok) {
+                if (SKIP) { if (__any(ok & !ID::is_none(id))) eval(id, ok); }
                 else eval(id, ok);
             };
             eval(w0[4], true);                       // own state first: it wins ties (strict '<', sequential.cpp:106)
+            // reference scan order: z, then y, then x (sequential.cpp:86-88) = plane by plane
 #pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {         // reference scan order: z, then y, then x (sequential.cpp:86-88)
-                cand(wm[dz * 3 + 0], hasM); cand(wm[dz * 3 + 1], true); cand(wm[dz * 3 + 2], hasP);
-                cand(w0[dz * 3 + 0], hasM); if (dz != 1) cand(w0[dz * 3 + 1], true); cand(w0[dz * 3 + 2], hasP);
-                cand(wp[dz * 3 + 0], hasM); cand(wp[dz * 3 + 1], true); cand(wp[dz * 3 + 2], hasP);
-            }
-            const size_t rowIdx = (size_t)zl * N + y;
+            for (int q = 0; q < 9; q += 3) { cand(wm[q], hasM); cand(wm[q + 1], true); cand(wm[q + 2], hasP); }
+#pragma unroll
+            for (int q = 0; q < 9; q += 3) { cand(w0[q], hasM); if (q != 3) cand(w0[q + 1], true); cand(w0[q + 2], hasP); }
+#pragma unroll
+            for (int q = 0; q < 9; q += 3) { cand(wp[q], hasM); cand(wp[q + 1], true); cand(wp[q + 2], hasP); }
+            const size_t rowIdx = (size_t)(zg - (int)f.z0) * N + y;
             if (FINAL) {
-                // jfa_final's rule (sequential.cpp:55-60,106-109): set voxels carry +, unset ones the sign of the
-                // caller's fill; bestd is +inf when no seed was found, which copysign turns into the fill itself.
                 const uint32_t wbits = words[rowIdx * f.w + (x >> 5)];
                 const bool set = (wbits >> (x & 31)) & 1u;
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(sdf + rowIdx * N) + xo) = set ? bestd : copysignf(bestd, fill);
+                // jfa_final's rule (sequential.cpp:55-60,106-109): set voxels carry +, unset ones the sign of the caller's fill;
+                // bestd is +inf when no seed was found, which copysign turns into the fill itself.
+                sdf[rowIdx * N + x] = set ? bestd : copysignf(bestd, fill);
             } else {
-                *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out + rowIdx * N) + xo) = best;
+                *reinterpret_cast<T*>(reinterpret_cast<char*>(out + rowIdx * N) + xo) = best;
             }
         };
 
-        // kChain = 4 steps over a 4-row register ring: the row needed by the NEXT step is requested
-        // before the current step is evaluated, so its latency hides behind ~270 VALU instructions.
-        uint32_t wa[9], wb[9], wc[9], wd[9];
+        T wa[9], wb[9], wc[9], wd[9];
         const int K = (int)k;
-        load_row(ybase - K, wa);
-        load_row(ybase, wb);
-        load_row(ybase + K, wc);
-        load_row(ybase + 2 * K, wd);
-        step(ybase, reinterpret_cast<const char*>(TY[0]), wa, wb, wc);
-        if (ybase + K < N) {
-            load_row(ybase + 3 * K, wa);
-            step(ybase + K, reinterpret_cast<const char*>(TY[1]), wb, wc, wd);
-            if (ybase + 2 * K < N) {
-                load_row(ybase + 4 * K, wb);
-                step(ybase + 2 * K, reinterpret_cast<const char*>(TY[2]), wc, wd, wa);
-                if (ybase + 3 * K < N)
-                    step(ybase + 3 * K, reinterpret_cast<const char*>(TY[3]), wd, wa, wb);
+        const int zend = (int)f.z1;                                // chain elements must be planes of this slab
+        // plane z_j + k is read only if step j exists: a prefetch must never reach past the halo of a slab
+        const bool s1 = zbase + K < zend, s2 = zbase + 2 * K < zend, s3 = zbase + 3 * K < zend;
+        load_plane(zbase - K, wa);
+        load_plane(zbase, wb);
+        load_plane(zbase + K, wc);
+        if (s1) load_plane(zbase + 2 * K, wd);
+        step(zbase, reinterpret_cast<const char*>(TZ[0]), wa, wb, wc);
+        if (s1) {
+            if (s2) load_plane(zbase + 3 * K, wa);
+            step(zbase + K, reinterpret_cast<const char*>(TZ[1]), wb, wc, wd);
+            if (s2) {
+                if (s3) load_plane(zbase + 4 * K, wb);
+                step(zbase + 2 * K, reinterpret_cast<const char*>(TZ[2]), wc, wd, wa);
+                if (s3)
+                    step(zbase + 3 * K, reinterpret_cast<const char*>(TZ[3]), wd, wa, wb);
             }
         }
     }
@@ -497,10 +543,24 @@ jfa_pass_chain(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 
 // ------------------------------------------------------------------------------------------ final
 // One lane = 4 voxels.  sequential.cpp:55-60,106-109 + apps/cli/main.cpp:200 give the sign rule.
+__device__ __forceinline__ void load4(const uint32_t* base, size_t quad, uint32_t (&o)[4])
+{
+    const uint4 v = reinterpret_cast<const uint4*>(base)[quad];
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void load4(const uint2* base, size_t quad, uint2 (&o)[4])
+{
+    const uint4* p = reinterpret_cast<const uint4*>(base) + quad * 2;
+    const uint4 a = p[0], b = p[1];
+    o[0] = make_uint2(a.x, a.y); o[1] = make_uint2(a.z, a.w); o[2] = make_uint2(b.x, b.y); o[3] = make_uint2(b.z, b.w);
+}
+
+template <class ID>
 __global__ void __launch_bounds__(256)
-jfa_final(Frame f, const uint32_t* __restrict__ words, const uint4* __restrict__ ids, float fill,
+jfa_final(Frame f, const uint32_t* __restrict__ words, const typename ID::T* __restrict__ ids, float fill,
           float4* __restrict__ sdf)
 {
+    using T = typename ID::T;
     const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total4 = (size_t)f.n * f.n * (f.z1 - f.z0) / 4;
     if (i4 >= total4) return;
@@ -509,72 +569,48 @@ jfa_final(Frame f, const uint32_t* __restrict__ words, const uint4* __restrict__
     const uint32_t y = (uint32_t)((v / f.n) % f.n);
     const uint32_t zg = (uint32_t)(v / ((size_t)f.n * f.n)) + f.z0;
     const uint32_t bits = (words[v >> 5] >> (v & 31)) & 0xFu;
-    const uint4 id = ids[i4];
+    T idv[4];
+    load4(ids, i4, idv);
     const float py = axis_pos(f.oy, y, f.vs), pz = axis_pos(f.oz, zg, f.vs);
-    const uint32_t idv[4] = { id.x, id.y, id.z, id.w };
     float o[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const bool set = (bits >> b) & 1u;
         const float init = set ? INFINITY : fill;                  // interior +inf (:59) / caller's fill
-        if (idv[b] == kNone) { o[b] = init; continue; }
-        const float d = seed_distance(f, idv[b], axis_pos(f.ox, x + b, f.vs), py, pz);
+        if (ID::is_none(idv[b])) { o[b] = init; continue; }
+        const float d = seed_distance<ID>(f, idv[b], axis_pos(f.ox, x + b, f.vs), py, pz);
         o[b] = copysignf(d, init);                                 // :108
     }
     sdf[i4] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+inline bool wide(const Frame& f) { return f.n > 1024; }           // 64-bit ids
+
 }  // namespace
+
+size_t jfa_id_bytes(const Frame& f) { return wide(f) ? 8 : 4; }
 
 // ---------------------------------------------------------------------------------------------
 int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* below,
-                    const uint32_t* above, uint32_t* d_ids, uint32_t* d_border_words)
+                    const uint32_t* above, void* d_ids, uint32_t* d_border_words)
 {
     const size_t nwords = (size_t)f.n * f.n * (f.z1 - f.z0) / 32;
     const unsigned blocks = (unsigned)(nwords / 256);             // nwords is a multiple of 256
     ProfScope p(ctx, d_ids ? VP_K_JFA_INIT : VP_K_SURFACE);
-    if (d_ids && d_border_words)
-        hipLaunchKernelGGL((jfa_init<true, true>), dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, below, above, d_ids, d_border_words);
-    else if (d_ids)
-        hipLaunchKernelGGL((jfa_init<true, false>), dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, below, above, d_ids, d_border_words);
-    else
-        hipLaunchKernelGGL((jfa_init<false, true>), dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, below, above, d_ids, d_border_words);
+#define VP_INIT(ID, I, M) hipLaunchKernelGGL((jfa_init<ID, I, M>), dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, below, above, \
+                                             (typename ID::T*)d_ids, d_border_words)
+    if (wide(f)) {
+        if (d_ids && d_border_words) VP_INIT(Id64, true, true); else if (d_ids) VP_INIT(Id64, true, false); else VP_INIT(Id64, false, true);
+    } else {
+        if (d_ids && d_border_words) VP_INIT(Id32, true, true); else if (d_ids) VP_INIT(Id32, true, false); else VP_INIT(Id32, false, true);
+    }
+#undef VP_INIT
     VP_HIP(hipGetLastError());
     return 0;
 }
 
-// Plane processing order for step k: planes z, z+k, z+2k, ... back to back, so the three planes a
-// workgroup reads (z-k, z, z+k) were touched by the immediately preceding / following workgroups
-// and are served from L2 / Infinity Cache instead of HBM.  Cached per (n, slab, k) on the device.
-static int jfa_zorder(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t** out)
-{
-    const uint32_t nz = f.z1 - f.z0;
-    *out = nullptr;
-    if (k < 16 || k >= nz) return 0;                               // natural order already reuses / nothing to gain
-    if (ctx->zorder_n != f.n || ctx->zorder_z0 != f.z0 || ctx->zorder_z1 != f.z1) {
-        std::vector<uint32_t> host;
-        ctx->zorder_k.clear();
-        for (uint32_t kk = f.n / 2; kk >= 1; kk /= 2) {
-            if (kk < 16 || kk >= nz) continue;
-            ctx->zorder_k.push_back(kk);
-            for (uint32_t r = 0; r < kk; ++r)
-                for (uint32_t zg = f.z0; zg < f.z1; ++zg)
-                    if (zg % kk == r) host.push_back(zg - f.z0);
-        }
-        VP_TRY(reserve(ctx, ctx->zorder, std::max<size_t>(host.size(), 1) * 4));
-        if (!host.empty()) {
-            VP_HIP(hipMemcpyAsync(ctx->zorder.ptr, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            VP_HIP(hipStreamSynchronize(ctx->stream));
-        }
-        ctx->zorder_n = f.n; ctx->zorder_z0 = f.z0; ctx->zorder_z1 = f.z1;
-    }
-    for (size_t i = 0; i < ctx->zorder_k.size(); ++i)
-        if (ctx->zorder_k[i] == k) { *out = (const uint32_t*)ctx->zorder.ptr + i * nz; return 0; }
-    return 0;
-}
-
-int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
-                    const uint32_t* d_plus, uint32_t* d_out, int algo)
+int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, const void* d_minus,
+                    const void* d_plus, void* d_out, int algo)
 {
     return launch_jfa_pass_ex(ctx, f, k, d_in, d_minus, d_plus, d_out, algo, nullptr, 0.0f, nullptr);
 }
@@ -582,66 +618,81 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_i
 bool jfa_can_start_from_mask(const Frame& f, int algo) { return algo == VP_ALGO_TILED && f.n >= 256 && f.n % 128 == 0; }
 
 // First pass from the whole-grid border mask (see jfa_first_pass).
-int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, uint32_t* d_out)
+int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out)
 {
     ProfScope p(ctx, VP_K_JFA_PASS);
-    hipLaunchKernelGGL(jfa_first_pass, dim3((f.n + 255) / 256, f.n / kFirstRows, f.z1 - f.z0), dim3(256), 0, ctx->stream, f, f.n / 2,
-                       d_border, d_out);
+    const dim3 grid((f.n + 255) / 256, f.n / kFirstRows, f.z1 - f.z0);
+    if (wide(f)) hipLaunchKernelGGL(jfa_first_pass<Id64>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint2*)d_out);
+    else         hipLaunchKernelGGL(jfa_first_pass<Id32>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint32_t*)d_out);
     VP_HIP(hipGetLastError());
     return 0;
 }
 
 bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo)
 {
+    (void)k;
     return algo == VP_ALGO_TILED && f.n >= 256;
+}
+
+template <class ID>
+static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, const void* d_minus, const void* d_plus,
+                        void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
+{
+    using T = typename ID::T;
+    const uint32_t nz = f.z1 - f.z0;
+    if (!ctx->none_row.ptr) {                                      // a row of "none" for out-of-grid reads (sized for 64-bit ids)
+        VP_TRY(reserve(ctx, ctx->none_row, 2048 * 8));
+        VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, 2048 * 8, ctx->stream));
+    }
+    const T* none_row = (const T*)ctx->none_row.ptr;
+    const bool skip = k * 4 >= f.n, chk = (int)f.n >= ID::kTab, fin = d_sdf != nullptr;
+    const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k; // residue classes of the local plane index, planes per class
+    const dim3 grid(f.n, nres * ((zlen + kChain - 1) / kChain));
+#define VP_LAUNCH_CHAIN(S, C, F) hipLaunchKernelGGL((jfa_pass_zchain<ID, S, C, F>), grid, dim3(256), 0, ctx->stream, f, k, (const T*)d_in, \
+                                                    (const T*)d_minus, (const T*)d_plus, (T*)d_out, none_row, d_words, fill, d_sdf)
+    if (fin)       { if (chk) VP_LAUNCH_CHAIN(false, true, true);  else VP_LAUNCH_CHAIN(false, false, true); }
+    else if (skip) { if (chk) VP_LAUNCH_CHAIN(true, true, false);  else VP_LAUNCH_CHAIN(true, false, false); }
+    else           { if (chk) VP_LAUNCH_CHAIN(false, true, false); else VP_LAUNCH_CHAIN(false, false, false); }
+#undef VP_LAUNCH_CHAIN
+    return 0;
 }
 
 // d_sdf != nullptr: this is the last pass and it writes the sdf directly (only where
 // jfa_pass_can_fuse_final() says so); otherwise ids go to d_out.
-int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
-                       const uint32_t* d_plus, uint32_t* d_out, int algo, const uint32_t* d_words, float fill, float* d_sdf)
+int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, const void* d_minus,
+                       const void* d_plus, void* d_out, int algo, const uint32_t* d_words, float fill, float* d_sdf)
 {
-    const size_t total = (size_t)f.n * f.n * (f.z1 - f.z0);
     const uint32_t nz = f.z1 - f.z0;
     ProfScope p(ctx, VP_K_JFA_PASS);
     if (algo == VP_ALGO_NAIVE) {
-        const unsigned blocks = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(jfa_pass_direct, dim3(blocks), dim3(256), 0, ctx->stream, f, k, d_in, d_minus, d_plus, d_out);
+        const dim3 blocks(f.n * f.n / 256, nz);
+        if (wide(f))
+            hipLaunchKernelGGL(jfa_pass_direct<Id64>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint2*)d_in,
+                               (const uint2*)d_minus, (const uint2*)d_plus, (uint2*)d_out);
+        else
+            hipLaunchKernelGGL(jfa_pass_direct<Id32>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
+                               (const uint32_t*)d_minus, (const uint32_t*)d_plus, (uint32_t*)d_out);
     } else if (f.n >= 256) {
-        const uint32_t* zorder = nullptr;
-        VP_TRY(jfa_zorder(ctx, f, k, &zorder));
-        if (!ctx->none_row.ptr) {                                  // a row of kNone for out-of-grid reads
-            VP_TRY(reserve(ctx, ctx->none_row, kTab * sizeof(uint32_t)));
-            VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, kTab * sizeof(uint32_t), ctx->stream));
-        }
-        const uint32_t* none_row = (const uint32_t*)ctx->none_row.ptr;
-        const uint32_t chainLen = (f.n + k - 1) / k;               // rows per residue class
-        const dim3 grid(k * ((chainLen + kChain - 1) / kChain), nz);
-        const bool skip = k * 4 >= f.n, chk = f.n >= 1024, fin = d_sdf != nullptr;
-#define VP_LAUNCH_CHAIN(S, C, F) hipLaunchKernelGGL((jfa_pass_chain<S, C, F>), grid, dim3(256), 0, ctx->stream, f, k, d_in, \
-                                                    d_minus, d_plus, d_out, zorder, none_row, d_words, fill, d_sdf)
-        if (fin)       { if (chk) VP_LAUNCH_CHAIN(false, true, true);  else VP_LAUNCH_CHAIN(false, false, true); }
-        else if (skip) { if (chk) VP_LAUNCH_CHAIN(true, true, false);  else VP_LAUNCH_CHAIN(true, false, false); }
-        else           { if (chk) VP_LAUNCH_CHAIN(false, true, false); else VP_LAUNCH_CHAIN(false, false, false); }
-#undef VP_LAUNCH_CHAIN
+        if (wide(f)) VP_TRY(launch_chain<Id64>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
+        else         VP_TRY(launch_chain<Id32>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
     } else {
         const int RY = (int)(256 / f.n);
         const dim3 grid((f.n + RY - 1) / RY, nz);
-        const size_t lds = (size_t)(2 + RY) * kTab * sizeof(float);
-        hipLaunchKernelGGL(jfa_pass_table, grid, dim3(256), lds, ctx->stream, f, k, d_in, d_minus, d_plus, d_out, RY,
-                           (const uint32_t*)nullptr);
+        const size_t lds = (size_t)(2 + RY) * Id32::kTab * sizeof(float);
+        hipLaunchKernelGGL(jfa_pass_table, grid, dim3(256), lds, ctx->stream, f, k, (const uint32_t*)d_in, (const uint32_t*)d_minus,
+                           (const uint32_t*)d_plus, (uint32_t*)d_out, RY);
     }
     VP_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* d_ids,
-                     float fill, float* d_sdf)
+int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const void* d_ids, float fill, float* d_sdf)
 {
     const size_t total4 = (size_t)f.n * f.n * (f.z1 - f.z0) / 4;
     const unsigned blocks = (unsigned)((total4 + 255) / 256);
     ProfScope p(ctx, VP_K_JFA_FINAL);
-    hipLaunchKernelGGL(jfa_final, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint4*)d_ids, fill, (float4*)d_sdf);
+    if (wide(f)) hipLaunchKernelGGL(jfa_final<Id64>, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint2*)d_ids, fill, (float4*)d_sdf);
+    else         hipLaunchKernelGGL(jfa_final<Id32>, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint32_t*)d_ids, fill, (float4*)d_sdf);
     VP_HIP(hipGetLastError());
     return 0;
 }

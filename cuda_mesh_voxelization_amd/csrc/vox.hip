@@ -227,7 +227,7 @@ vox_scatter(Frame f, const uint4* __restrict__ rec, size_t ntris, uint32_t* __re
 }
 
 constexpr int kBatch = 64;        // triangle records staged in LDS per round
-constexpr int kMaxW = 32;         // words per x-row at n = 1024
+constexpr int kMaxW = 64;         // words per x-row at n = 2048
 
 // tog: toggle grid written by vox_setup (small triangles); dst: output grid.  !ACC: dst = fill(tog ^
 // tile toggles), tog may alias dst.  ACC: dst ^= fill(...), tog is a separate scratch grid.

@@ -44,10 +44,7 @@ struct vp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only workspaces
-    vp::Buffer rec, tile_cnt, tile_off, tile_cur, pairs, scratch, zorder, none_row;
-    // cached JFA plane orders (see jfa_zorder)
-    uint32_t zorder_n = 0, zorder_z0 = 0, zorder_z1 = 0;
-    std::vector<uint32_t> zorder_k;
+    vp::Buffer rec, tile_cnt, tile_off, tile_cur, pairs, scratch, none_row;
     // profiling
     bool prof_on = false;
     std::vector<vp::ProfSpan> prof_pending;
@@ -86,16 +83,17 @@ struct ProfScope {
 int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float* d_xyz, size_t nverts,
                     const uint32_t* d_tri, size_t ntris, int algo, int accumulate);
 int launch_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int op);
+size_t jfa_id_bytes(const Frame& f);                              // 4 (n <= 1024) or 8
 int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* below,
-                    const uint32_t* above, uint32_t* d_ids, uint32_t* d_border_words);
-int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
-                    const uint32_t* d_plus, uint32_t* d_out, int algo);
+                    const uint32_t* above, void* d_ids, uint32_t* d_border_words);
+int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, const void* d_minus,
+                    const void* d_plus, void* d_out, int algo);
 bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo);
-int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const uint32_t* d_in, const uint32_t* d_minus,
-                       const uint32_t* d_plus, uint32_t* d_out, int algo, const uint32_t* d_words, float fill, float* d_sdf);
+int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, const void* d_minus,
+                       const void* d_plus, void* d_out, int algo, const uint32_t* d_words, float fill, float* d_sdf);
 bool jfa_can_start_from_mask(const Frame& f, int algo);
-int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, uint32_t* d_out);
-int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* d_ids,
+int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out);
+int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const void* d_ids,
                      float fill, float* d_sdf);
 
 }  // namespace vp

@@ -42,6 +42,10 @@ class HipSlabBackend:
     def empty_f32(self, n):
         return torch.empty(int(n), dtype=torch.float32, device=self.device)
 
+    def id_words(self, frame):
+        """uint32 words of JFA state per voxel (1 for n <= 1024, 2 above)."""
+        return self.ctx.jfa_id_bytes(frame) // 4
+
     @staticmethod
     def _p(t):
         return t.data_ptr() if t is not None else None
@@ -66,9 +70,8 @@ class HipSlabBackend:
                                fill, sdf.data_ptr(), algo)
 
     # -- whole-grid id buffers addressed by global plane (GhostSlabPipeline) --------------------
-    @staticmethod
-    def _global_ptrs(region, k, src_full, dst_full):
-        pb = region.n * region.n * 4                                # bytes per id plane
+    def _global_ptrs(self, region, k, src_full, dst_full):
+        pb = region.n * region.n * self.ctx.jfa_id_bytes(region)    # bytes per id plane
         s, d = src_full.data_ptr(), dst_full.data_ptr()
         # vphip.h / vp_jfa_pass: plane p of d_minus is global plane z0-k+p, d_plus starts at max(z1, z0+k)
         return (s + region.z0 * pb, s + (region.z0 - k) * pb, s + max(region.z1, region.z0 + k) * pb, d + region.z0 * pb)
@@ -84,7 +87,8 @@ class HipSlabBackend:
         self.ctx.surface(frame, words.data_ptr(), None, None, border.data_ptr())
 
     def jfa_first_pass_global(self, region, border_full, dst_full):
-        self.ctx.jfa_first_pass(region, border_full.data_ptr(), dst_full.data_ptr() + region.z0 * region.n * region.n * 4)
+        self.ctx.jfa_first_pass(region, border_full.data_ptr(),
+                                dst_full.data_ptr() + region.z0 * region.n * region.n * self.ctx.jfa_id_bytes(region))
 
     def jfa_last_pass_global(self, region, src_full, scratch_full, words_region, fill, sdf, algo):
         src, minus, plus, scratch = self._global_ptrs(region, 1, src_full, scratch_full)
@@ -127,15 +131,16 @@ class SlabPipeline:
         self.z0, self.z1 = slab_range(frame.n, rank, world)
         self.frame = frame.slab(self.z0, self.z1)
         n = frame.n
-        self.plane_ids = n * n                    # ids per plane
+        idw = self.be.id_words(frame) if hasattr(self.be, "id_words") else 1
+        self.plane_ids = n * n * idw              # uint32 words of id state per plane
         self.plane_words = n * n // 32            # bitmask words per plane
         self.nz = self.z1 - self.z0
         self.words = self.be.empty_u32(self.frame.words)
-        self.ids = [self.be.empty_u32(self.frame.voxels), self.be.empty_u32(self.frame.voxels)]
+        self.ids = [self.be.empty_u32(self.frame.voxels * idw), self.be.empty_u32(self.frame.voxels * idw)]
         self.sdf = self.be.empty_f32(self.frame.voxels)
         # halo buffers, sized for the largest request (a whole slab)
-        self.minus = self.be.empty_u32(self.frame.voxels) if world > 1 else None
-        self.plus = self.be.empty_u32(self.frame.voxels) if world > 1 else None
+        self.minus = self.be.empty_u32(self.frame.voxels * idw) if world > 1 else None
+        self.plus = self.be.empty_u32(self.frame.voxels * idw) if world > 1 else None
         self.below = self.be.empty_u32(self.plane_words) if rank > 0 else None
         self.above = self.be.empty_u32(self.plane_words) if rank < world - 1 else None
         self.bytes_received = 0
@@ -248,7 +253,8 @@ class GhostSlabPipeline:
         self.frame = frame.slab(self.z0, self.z1)
         self.regions = ghost_regions(frame.n, rank, world)
         self.words = self.be.empty_u32(frame.words)                 # whole grid
-        self.ids = [self.be.empty_u32(frame.voxels), self.be.empty_u32(frame.voxels)]
+        idw = self.be.id_words(frame) if hasattr(self.be, "id_words") else 1
+        self.ids = [self.be.empty_u32(frame.voxels * idw), self.be.empty_u32(frame.voxels * idw)]
         self.sdf = self.be.empty_f32(self.frame.voxels)             # own slab only
         self.planes_computed = sum(b1 - b0 for _, b0, b1 in self.regions)
         self.border = None

@@ -133,8 +133,8 @@ void Device(int algo, const char* label, const uint32_t* words, size_t n, float 
         gpuAssert(vp_malloc(ctx, vp_jfa_workspace_bytes(&f), &dWork));
         gpuAssert(vp_upload(ctx, dWords, words, gridBytes));
     }
-    uint32_t* a = static_cast<uint32_t*>(dWork);
-    uint32_t* b = a + voxels;
+    char* a = static_cast<char*>(dWork);                           // two opaque id volumes
+    char* b = a + voxels * vp_jfa_id_bytes(&f);
     {
         PROFILING_SCOPE(L + "::Initialization");
         gpuAssert(vp_jfa_init(ctx, &f, static_cast<const uint32_t*>(dWords), nullptr, nullptr, a));

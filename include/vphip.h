@@ -49,7 +49,7 @@ enum { VP_OP_VOID = 0, VP_OP_UNION = 1, VP_OP_INTERSECTION = 2, VP_OP_DIFFERENCE
 /* Grid frame: what VoxelsGrid carries besides its words (voxels_grid.h:39-43,160-169),
  * plus the Z-slab this buffer holds. */
 typedef struct vp_frame {
-    uint32_t n;           /* voxels per side of the GLOBAL grid (n % 32 == 0, 32 <= n <= 1024) */
+    uint32_t n;           /* voxels per side of the GLOBAL grid (n % 32 == 0, 32 <= n <= 2048) */
     float    voxel_size;
     float    origin[3];
     uint32_t z0, z1;      /* planes held: z0 <= z < z1; multiples of 8 */
@@ -105,9 +105,10 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
  * (vplib/src/jfa/jfa.h:42-43, jfa/naive.cu:121-180, jfa/tiled.cu:244-337); results are those of
  * the sequential path (jfa/sequential.cpp:7-127): signed SQUARED distance, +inside, -outside.
  *
- * State between passes is one uint32 per voxel: the packed coordinates of the nearest seed
- * found so far (x<<2 | y<<12 | z<<22, 0xFFFFFFFF = none) instead of the reference's float sdf +
- * float3 position; distances are recomputed from it with the reference's expressions.
+ * State between passes is one packed id per voxel: the coordinates of the nearest seed found so far
+ * (vp_jfa_id_bytes(f) = 4 bytes for n <= 1024, 8 bytes for n <= 2048; all ones = none) instead of the
+ * reference's float sdf + float3 position; distances are recomputed from it with the reference's
+ * expressions.  Id buffers are opaque (void*): vp_grid_voxels(f) * vp_jfa_id_bytes(f) bytes per volume.
  *
  * vp_jfa runs init + all passes + finalize on one device for a whole-grid frame.
  *   fill_unset  value the caller pre-filled the sdf with (apps/cli/main.cpp:200 uses -INFINITY);
@@ -115,6 +116,7 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
  *   d_work      scratch of vp_jfa_workspace_bytes(f) bytes (two id volumes + border mask).
  *   algo        VP_ALGO_NAIVE: direct kernel; VP_ALGO_TILED: LDS-table kernel.  Same results. */
 size_t vp_jfa_workspace_bytes(const vp_frame* f);
+size_t vp_jfa_id_bytes(const vp_frame* f);
 int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
            float* d_sdf, void* d_work, size_t work_bytes, int algo);
 
@@ -126,16 +128,16 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
  *          start (plane p of d_minus is global plane z0-k+p).
  *   finalize: ids -> float sdf for the slab. */
 int vp_jfa_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words,
-                const uint32_t* d_plane_below, const uint32_t* d_plane_above, uint32_t* d_ids);
-int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const uint32_t* d_in,
-                const uint32_t* d_minus, const uint32_t* d_plus, uint32_t* d_out, int algo);
-int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const uint32_t* d_ids,
+                const uint32_t* d_plane_below, const uint32_t* d_plane_above, void* d_ids);
+int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const void* d_in,
+                const void* d_minus, const void* d_plus, void* d_out, int algo);
+int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const void* d_ids,
                     float fill_unset, float* d_sdf);
 /* The last pass (step k = 1) and the finalize in one call: where the kernel supports it the pass writes
  * the sdf directly and the id volume is neither written nor re-read; d_scratch (one id volume) is used
  * only when it does not.  Same result as vp_jfa_pass(k = 1) + vp_jfa_finalize. */
-int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_in, const uint32_t* d_minus,
-                     const uint32_t* d_plus, uint32_t* d_scratch, const uint32_t* d_words, float fill_unset,
+int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const void* d_minus,
+                     const void* d_plus, void* d_scratch, const uint32_t* d_words, float fill_unset,
                      float* d_sdf, int algo);
 
 /* Sparse start (n >= 256, n % 128 == 0, VP_ALGO_TILED; vp_jfa uses it internally).  Before any pass a border
@@ -144,7 +146,7 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_in, const
  * written or read.  vp_jfa_first_pass produces the ids after step n/2 for the planes of f; the result is
  * identical to vp_jfa_init + vp_jfa_pass(k = n/2). */
 int vp_jfa_can_start_from_mask(const vp_frame* f, int algo);
-int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, uint32_t* d_out);
+int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out);
 
 /* "Surface" output (README.md:9): the border-voxel mask that JFA seeds
  * from (jfa/sequential.cpp:24-64), as a bitmask with the grid's layout. */

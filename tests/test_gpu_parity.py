@@ -271,3 +271,33 @@ def test_config4_bunny_x24_n1024(engine):
     else:
         s2 = engine.jfa(fr, g, algo=ALGO_NAIVE)
         assert torch.equal(s.view(torch.int32), s2.view(torch.int32))
+
+
+def test_config5_scale_n2048_wide_ids(engine):
+    """n = 2048 (BASELINE config 5's grid; the reference itself overflows there, grid/grid.h:89-92): JFA state is
+    64-bit.  Bitmask against the oracle (64-bit indices); the two JFA kernels bit-identical to each other; zero set
+    = border mask.  (The full sdf was compared once against the oracle on the GPU box's host: tests/golden/
+    own_oracle_runs.json.)"""
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 230 * 2**30:
+        pytest.skip("needs ~200 GiB of free HBM")
+    xyz, tri = M.bunny(24)
+    n = 2048
+    fr, origin, vs = _frame([(xyz, tri)], n)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    g = engine.voxelize(fr, dx, dt, algo=ALGO_TILED)
+    got = engine.words_to_numpy(g)
+    assert np.array_equal(got, O.voxelize(xyz, tri, n, vs, origin))
+    assert np.array_equal(engine.words_to_numpy(engine.voxelize(fr, dx, dt, algo=ALGO_NAIVE)), got)
+    s_t = engine.jfa(fr, g, algo=ALGO_TILED).clone()
+    s_n = engine.jfa(fr, g, algo=ALGO_NAIVE)
+    assert torch.equal(s_t.view(torch.int32), s_n.view(torch.int32))
+    del s_n
+    border = engine.surface(fr, g)
+    zeros = sum(int((s_t[i:i + (1 << 30)] == 0).sum().item()) for i in range(0, s_t.numel(), 1 << 30))
+    assert zeros == O.popcount(engine.words_to_numpy(border))
+    del s_t, border, g
+    engine._work = None
+    gc.collect(); torch.cuda.empty_cache()
