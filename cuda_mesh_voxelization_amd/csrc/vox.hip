@@ -141,7 +141,8 @@ constexpr int kSmallCells = 16;   // triangles whose y/z voxel range holds at mo
 
 __global__ void __launch_bounds__(256)
 vox_setup(Frame f, const float* __restrict__ xyz, size_t nverts, const uint32_t* __restrict__ tri, size_t ntris,
-          uint4* __restrict__ rec, uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ toggles)
+          uint4* __restrict__ rec, uint32_t rec_cap, uint32_t* __restrict__ nbig, uint32_t* __restrict__ tile_cnt,
+          uint32_t* __restrict__ toggles)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int tilesY = f.n / kTile;
@@ -162,17 +163,18 @@ vox_setup(Frame f, const float* __restrict__ xyz, size_t nverts, const uint32_t*
             }
         }
     }
+    // large triangles are rare in fine meshes: their records go to a COMPACT list (small ones write nothing at all --
+    // a 16-byte marker per triangle cost 0.4 ms on the 10.8M-face mesh)
     const bool big = valid && !small;
-    if (t < ntris) {
-        uint4* dst = rec + t * 5;
-        if (big) {
+    if (big) {
+        const uint32_t slot = atomicAdd(nbig, 1u);
+        if (slot < rec_cap) {                                     // host re-runs with a larger list if this overflows
+            uint4* dst = rec + (size_t)slot * 5;
             dst[0] = make_uint4(__float_as_uint(r[0]),  __float_as_uint(r[1]),  __float_as_uint(r[2]),  __float_as_uint(r[3]));
             dst[1] = make_uint4(__float_as_uint(r[4]),  __float_as_uint(r[5]),  __float_as_uint(r[6]),  __float_as_uint(r[7]));
             dst[2] = make_uint4(__float_as_uint(r[8]),  __float_as_uint(r[9]),  __float_as_uint(r[10]), __float_as_uint(r[11]));
             dst[3] = make_uint4(__float_as_uint(r[12]), __float_as_uint(r[13]), __float_as_uint(r[14]), __float_as_uint(r[15]));
             dst[4] = make_uint4((uint32_t)sy | ((uint32_t)ey << 16), (uint32_t)sz | ((uint32_t)ez << 16), (uint32_t)t, 0u);
-        } else {
-            dst[4] = make_uint4(0u, 0u, (uint32_t)t, 0u);         // empty range: vox_scatter skips it
         }
     }
     const int ty0 = sy / kTile, ty1 = big ? (ey - 1) / kTile : 0;
@@ -206,9 +208,10 @@ vox_scan(const uint32_t* __restrict__ cnt, uint32_t m, uint32_t* __restrict__ of
 }
 
 __global__ void __launch_bounds__(256)
-vox_scatter(Frame f, const uint4* __restrict__ rec, size_t ntris, uint32_t* __restrict__ cur,
+vox_scatter(Frame f, const uint4* __restrict__ rec, size_t nrec, uint32_t* __restrict__ cur,
             uint32_t* __restrict__ pairs, uint32_t cap)
 {
+    const size_t ntris = nrec;                                     // one thread per record of the compact large-triangle list
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int tilesY = f.n / kTile;
     const int tzBase = f.z0 / kTile;
@@ -465,29 +468,41 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
     // ---- TILED (hybrid) ----
     const uint32_t tilesY = f.n / kTile;
     const uint32_t numTiles = tilesY * (uint32_t)(nz / kTile);
-    VP_TRY(reserve(ctx, ctx->rec, std::max<size_t>(ntris, 1) * kRecDwords * 4));
-    VP_TRY(reserve(ctx, ctx->tile_cnt, (size_t)numTiles * 4));
+    VP_TRY(reserve(ctx, ctx->tile_cnt, ((size_t)numTiles + 1) * 4));
     VP_TRY(reserve(ctx, ctx->tile_off, ((size_t)numTiles + 1) * 4));
     VP_TRY(reserve(ctx, ctx->tile_cur, (size_t)numTiles * 4));
-    uint4* rec = (uint4*)ctx->rec.ptr;
+    uint4* rec = nullptr;
     uint32_t* cnt = (uint32_t*)ctx->tile_cnt.ptr;
     uint32_t* off = (uint32_t*)ctx->tile_off.ptr;
     uint32_t* cur = (uint32_t*)ctx->tile_cur.ptr;
 
-    uint32_t total = 0;
+    // The record list holds only large triangles.  Its capacity is a guess (what the previous call needed, at least
+    // 64 Ki); if a mesh has more, the setup is repeated once with the exact size.
+    uint32_t total = 0, nbig = 0;
+    uint32_t* d_nbig = cnt + numTiles;                             // one extra counter after the tile histogram
     if (ntris) {
-        VP_HIP(hipMemsetAsync(cnt, 0, (size_t)numTiles * 4, st));
-        {
-            ProfScope p(ctx, VP_K_VOX_SETUP);
-            hipLaunchKernelGGL(vox_setup, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, rec, cnt, tog);
+        size_t cap = std::min<size_t>(ntris, std::max<size_t>(ctx->rec.bytes / (kRecDwords * 4), 65536));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            VP_TRY(reserve(ctx, ctx->rec, cap * kRecDwords * 4));
+            rec = (uint4*)ctx->rec.ptr;
+            if (attempt) VP_HIP(hipMemsetAsync(tog, 0, nwords * 4, st));   // setup toggles small triangles: start over
+            VP_HIP(hipMemsetAsync(cnt, 0, ((size_t)numTiles + 1) * 4, st));
+            {
+                ProfScope p(ctx, VP_K_VOX_SETUP);
+                hipLaunchKernelGGL(vox_setup, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, rec, (uint32_t)cap,
+                                   d_nbig, cnt, tog);
+            }
+            {
+                ProfScope p(ctx, VP_K_VOX_SCAN);
+                hipLaunchKernelGGL(vox_scan, dim3(1), dim3(1024), 0, st, cnt, numTiles, off, cur);
+            }
+            // sizes of the large-triangle list and of its work queue: two 4-byte read-backs (both 0 for fine meshes)
+            VP_HIP(hipMemcpyAsync(&total, off + numTiles, 4, hipMemcpyDeviceToHost, st));
+            VP_HIP(hipMemcpyAsync(&nbig, d_nbig, 4, hipMemcpyDeviceToHost, st));
+            VP_HIP(hipStreamSynchronize(st));
+            if (nbig <= cap) break;
+            cap = nbig;
         }
-        {
-            ProfScope p(ctx, VP_K_VOX_SCAN);
-            hipLaunchKernelGGL(vox_scan, dim3(1), dim3(1024), 0, st, cnt, numTiles, off, cur);
-        }
-        // size of the large-triangle work queue: one 4-byte read-back (0 for fine meshes)
-        VP_HIP(hipMemcpyAsync(&total, off + numTiles, 4, hipMemcpyDeviceToHost, st));
-        VP_HIP(hipStreamSynchronize(st));
     }
     if (total == 0) {                                              // nothing binned: plain streaming fill
         VP_TRY(launch_fill(ctx, f, tog, d_words, accumulate));
@@ -498,7 +513,7 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
     uint32_t* pairs = (uint32_t*)ctx->pairs.ptr;
     {
         ProfScope p(ctx, VP_K_VOX_SCATTER);
-        hipLaunchKernelGGL(vox_scatter, dim3(tblocks), dim3(256), 0, st, f, rec, ntris, cur, pairs, total);
+        hipLaunchKernelGGL(vox_scatter, dim3((nbig + 255) / 256), dim3(256), 0, st, f, rec, (size_t)nbig, cur, pairs, total);
     }
     {
         ProfScope p(ctx, VP_K_VOX_TILE);
