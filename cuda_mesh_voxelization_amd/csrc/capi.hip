@@ -91,6 +91,14 @@ static int check_frame(const vp_frame* f, const char* who, bool whole)
     return 0;
 }
 
+// Work must land on the context's device even if the calling thread's current HIP device changed in between
+// (the null stream in particular belongs to the CURRENT device).
+static int bind_device(vp_ctx* ctx)
+{
+    VP_HIP(hipSetDevice(ctx->device));
+    return 0;
+}
+
 static const char* kNames[VP_K_COUNT] = {
     "vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
     "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface"
@@ -142,6 +150,7 @@ int vp_ctx_destroy(vp_ctx* ctx)
 int vp_ctx_set_stream(vp_ctx* ctx, void* hip_stream, int external)
 {
     if (!ctx) return set_error(VP_ERR_INVALID, "vp_ctx_set_stream: null ctx");
+    VP_TRY(bind_device(ctx));
     VP_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stream = external ? (hipStream_t)hip_stream : ctx->own_stream;
     return 0;
@@ -150,6 +159,7 @@ int vp_ctx_set_stream(vp_ctx* ctx, void* hip_stream, int external)
 int vp_ctx_sync(vp_ctx* ctx)
 {
     if (!ctx) return set_error(VP_ERR_INVALID, "vp_ctx_sync: null ctx");
+    VP_TRY(bind_device(ctx));
     VP_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -165,6 +175,7 @@ int vp_malloc(vp_ctx* ctx, size_t bytes, void** d_out)
 int vp_free(vp_ctx* ctx, void* d_ptr)
 {
     if (!ctx) return set_error(VP_ERR_INVALID, "vp_free: null ctx");
+    VP_TRY(bind_device(ctx));
     if (d_ptr) { VP_HIP(hipStreamSynchronize(ctx->stream)); VP_HIP(hipFree(d_ptr)); }
     return 0;
 }
@@ -172,6 +183,7 @@ int vp_free(vp_ctx* ctx, void* d_ptr)
 int vp_memset(vp_ctx* ctx, void* d_ptr, int byte_value, size_t bytes)
 {
     if (!ctx || (!d_ptr && bytes)) return set_error(VP_ERR_INVALID, "vp_memset: null argument");
+    VP_TRY(bind_device(ctx));
     if (bytes) VP_HIP(hipMemsetAsync(d_ptr, byte_value, bytes, ctx->stream));
     return 0;
 }
@@ -179,6 +191,7 @@ int vp_memset(vp_ctx* ctx, void* d_ptr, int byte_value, size_t bytes)
 int vp_upload(vp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes)
 {
     if (!ctx || ((!d_dst || !h_src) && bytes)) return set_error(VP_ERR_INVALID, "vp_upload: null argument");
+    VP_TRY(bind_device(ctx));
     if (bytes) {
         VP_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
         VP_HIP(hipStreamSynchronize(ctx->stream));
@@ -189,6 +202,7 @@ int vp_upload(vp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes)
 int vp_download(vp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 {
     if (!ctx || ((!h_dst || !d_src) && bytes)) return set_error(VP_ERR_INVALID, "vp_download: null argument");
+    VP_TRY(bind_device(ctx));
     if (bytes) {
         VP_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         VP_HIP(hipStreamSynchronize(ctx->stream));
@@ -203,6 +217,7 @@ int vp_voxelize(vp_ctx* ctx, const vp_frame* f, uint32_t* d_words, const float* 
                 const uint32_t* d_tri, size_t ntris, int algo, int accumulate)
 {
     if (!ctx || !d_words) return set_error(VP_ERR_INVALID, "vp_voxelize: null argument");
+    VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_voxelize", false));
     if (ntris && (!d_xyz || !d_tri || !nverts)) return set_error(VP_ERR_INVALID, "vp_voxelize: null mesh arrays");
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_voxelize: algo %d", algo);
@@ -213,6 +228,7 @@ int vp_voxelize(vp_ctx* ctx, const vp_frame* f, uint32_t* d_words, const float* 
 int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int op)
 {
     if (!ctx || ((!d_a || !d_b) && nwords)) return set_error(VP_ERR_INVALID, "vp_csg: null argument");
+    VP_TRY(bind_device(ctx));
     if (op < VP_OP_VOID || op > VP_OP_DIFFERENCE) return set_error(VP_ERR_INVALID, "vp_csg: unknown op %d", op);
     return launch_csg(ctx, d_a, d_b, nwords, op);
 }
@@ -235,6 +251,7 @@ int vp_jfa_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const u
                 const uint32_t* d_plane_above, void* d_ids)
 {
     if (!ctx || !d_words || !d_ids) return set_error(VP_ERR_INVALID, "vp_jfa_init: null argument");
+    VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_init", false));
     return launch_jfa_init(ctx, make_frame(f), d_words, d_plane_below, d_plane_above, d_ids, nullptr);
 }
@@ -243,6 +260,7 @@ int vp_surface(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const ui
                const uint32_t* d_plane_above, uint32_t* d_border_words)
 {
     if (!ctx || !d_words || !d_border_words) return set_error(VP_ERR_INVALID, "vp_surface: null argument");
+    VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_surface", false));
     return launch_jfa_init(ctx, make_frame(f), d_words, d_plane_below, d_plane_above, nullptr, d_border_words);
 }
@@ -251,6 +269,7 @@ int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const void* d_in, co
                 const void* d_plus, void* d_out, int algo)
 {
     if (!ctx || !d_in || !d_out || d_in == d_out) return set_error(VP_ERR_INVALID, "vp_jfa_pass: bad buffers");
+    VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_pass", false));
     if (k == 0 || k >= f->n) return set_error(VP_ERR_INVALID, "vp_jfa_pass: step %u out of range", k);
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_jfa_pass: algo %d", algo);
@@ -264,6 +283,7 @@ int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, con
                     float fill_unset, float* d_sdf)
 {
     if (!ctx || !d_words || !d_ids || !d_sdf) return set_error(VP_ERR_INVALID, "vp_jfa_finalize: null argument");
+    VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_finalize", false));
     VP_TRY(check_fill(fill_unset, "vp_jfa_finalize"));
     return launch_jfa_final(ctx, make_frame(f), d_words, d_ids, fill_unset, d_sdf);
@@ -273,6 +293,7 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
            void* d_work, size_t work_bytes, int algo)
 {
     if (!ctx || !d_words || !d_sdf || !d_work) return set_error(VP_ERR_INVALID, "vp_jfa: null argument");
+    VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa", true));
     VP_TRY(check_fill(fill_unset, "vp_jfa"));
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_jfa: algo %d", algo);
@@ -308,6 +329,7 @@ int vp_jfa_can_start_from_mask(const vp_frame* f, int algo)
 int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out)
 {
     if (!ctx || !d_border_grid || !d_out) return set_error(VP_ERR_INVALID, "vp_jfa_first_pass: null argument");
+    VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_first_pass", false));
     const Frame fr = make_frame(f);
     if (!jfa_can_start_from_mask(fr, VP_ALGO_TILED))
@@ -320,6 +342,7 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
 {
     if (!ctx || !d_in || !d_scratch || !d_words || !d_sdf || d_in == d_scratch)
         return set_error(VP_ERR_INVALID, "vp_jfa_last_pass: bad buffers");
+    VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_last_pass", false));
     VP_TRY(check_fill(fill_unset, "vp_jfa_last_pass"));
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_jfa_last_pass: algo %d", algo);
@@ -394,6 +417,7 @@ int vp_jfa_host(vp_ctx* ctx, const vp_frame* f, const uint32_t* h_words, float f
 int vp_prof_enable(vp_ctx* ctx, int on)
 {
     if (!ctx) return set_error(VP_ERR_INVALID, "vp_prof_enable: null ctx");
+    VP_TRY(bind_device(ctx));
     if (!on) VP_TRY(prof_fold(ctx));
     ctx->prof_on = on != 0;
     return 0;
@@ -402,6 +426,7 @@ int vp_prof_enable(vp_ctx* ctx, int on)
 int vp_prof_reset(vp_ctx* ctx)
 {
     if (!ctx) return set_error(VP_ERR_INVALID, "vp_prof_reset: null ctx");
+    VP_TRY(bind_device(ctx));
     VP_TRY(prof_fold(ctx));
     for (int i = 0; i < VP_K_COUNT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
     return 0;
@@ -410,6 +435,7 @@ int vp_prof_reset(vp_ctx* ctx)
 int vp_prof_get(vp_ctx* ctx, int kernel, double* total_ms, uint64_t* launches)
 {
     if (!ctx || kernel < 0 || kernel >= VP_K_COUNT) return set_error(VP_ERR_INVALID, "vp_prof_get: bad argument");
+    VP_TRY(bind_device(ctx));
     VP_TRY(prof_fold(ctx));
     if (total_ms) *total_ms = ctx->prof_ms[kernel];
     if (launches) *launches = ctx->prof_n[kernel];
