@@ -18,8 +18,8 @@
 //                   stores after a wave shuffle transposes word-per-lane into voxels-per-lane.
 //   jfa_first_pass  step k = n/2 straight from the border bitmask (no init id volume).
 //   jfa_pass_direct (VP_ALGO_NAIVE) one thread per voxel, everything recomputed inline.
-//   jfa_pass_zchain (VP_ALGO_TILED, n >= 256) LDS coordinate tables + register sliding window over
-//                   planes k apart; jfa_pass_table is the small-n variant of the table idea.
+//   jfa_pass_zstream (VP_ALGO_TILED, n >= 256) LDS coordinate tables; chains of planes k apart, each plane read
+//                   once and scattered into its three outputs; jfa_pass_table is the small-n variant.
 //   jfa_final       ids + bitmask -> float sdf.
 //
 // Built with -ffp-contract=off (an FMA changes the result).
@@ -367,63 +367,93 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
     }
 }
 
-// Fast path for n >= 256 ("chain" kernel).  A workgroup owns ONE x-row position (y fixed) in kChain planes that
-// are k apart, z_j = z0 + r + (j0 + j) * k.  Plane z_j reads planes z_j - k, z_j, z_j + k, i.e. its chain
-// neighbours, so a thread walks the chain with a sliding window of three planes' candidate ids in registers
-// (each plane contributes rows y-k, y, y+k x {x-k, x, x+k}) and loads only ONE new plane triple (9 ids) per
-// voxel instead of 27 -- the vector-memory instruction rate, not HBM, limits this kernel (measured: 27
-// loads/voxel cost 43 % of the pass; every load per voxel costs ~0.02 ms per pass at n = 512).
-// LDS tables at fixed addresses turn id fields into (seed x, dy^2, dz^2).  Because x AND y are the same for every
-// step of the walk, the first association of the distance, fl(dx^2 + dy^2), is a per-id constant that the compiler
-// keeps in ONE register across the three steps an id is used in; only dz^2 (table of the step's plane) is looked
-// up per candidate-step:
-//     per candidate-step   1 AND + 1 ds_read + 1 add + compare + 2 selects          (5 VALU)
-//     per loaded id        x, y decode + 2 ds_read + sub, mul, add                   (7 VALU)
-//     registers per window id   id + fl(dx^2 + dy^2)
-// (A y-chain with per-row TY tables was 7 % slower: 6 VALU per candidate-step and 3 registers per id.)
+// ------------------------------------------------------------------------------------------ z-stream
+// Fast path for n >= 256.  A workgroup owns ONE x-row position (y fixed) in kChain planes that are k apart,
+// z_j = z0 + r + (j0 + j) * k.  Output plane z_j takes its candidates from planes z_j - k, z_j, z_j + k, i.e. from
+// its chain neighbours, so the kChain + 2 planes of the chain are each read ONCE (rows y-k, y, y+k x columns
+// {x-k, x, x+k} = 9 ids per thread) and serve three outputs: 13.5 loads per voxel instead of 27.
+// The kernel is input-stationary: every plane of 9 ids is decoded once and scattered into the running
+// (best id, distance) pairs of the three outputs it is a candidate for (z_{P-1} as their "+k" plane, z_P as its
+// own plane, z_{P+1} as their "-k" plane).  Planes arrive in increasing z and ids in (y, x) order, so each
+// output still sees its 27 candidates in the reference's scan order (sequential.cpp:86-88).  The voxel's own
+// state no longer comes first; it wins ties instead by being merged with '<=' (a leftmost minimum with "own"
+// leftmost is the same thing: candidates before it were taken with '<', later ones need '<' to replace it).
+// LDS tables at fixed addresses turn id fields into (seed x, dy^2, dz^2 per output plane); fl(dx^2 + dy^2) is
+// computed once per id and shared by its three outputs, which keeps the reference's association
+// ((dx^2 + dy^2) + dz^2) (jfa/jfa.h:19-20).
+//     per candidate-step   1 ds_read + 1 add + compare + 2 selects
+//     per loaded id        x, y, z decode (5 VALU) + 2 ds_read + sub, mul, add
+//     registers            9 ids of the plane in flight + 9 prefetched + 3 running pairs: ~75 VGPRs, 6 waves / SIMD
+// (The output-stationary predecessor kept a 3-plane window of ids + partial distances per thread: 96 VGPRs,
+// 5 waves, one more VALU per candidate-step.)  Measured on MI355X the kernel is balanced, not bound by one unit:
+// removing all LDS lookups or 15 % of the VALU instructions does not change its time, removing the global loads
+// gains 20 %.  v_pk_*_f32 runs at half the rate of the scalar forms here, so pairing ids buys issue slots only.
 //   SKIP = true   (early passes, k >= n/4: sparse state, many rows outside the grid) rows / planes outside
 //                 the grid are skipped with wave-uniform branches and a candidate column in which no lane
-//                 of the wave holds a seed is skipped after a ballot.  (A table-free per-voxel kernel and
-//                 the branch-free variant were both measured slower for these passes.)
+//                 of the wave holds a seed is skipped after a ballot.
 //   SKIP = false  the voxel loop is branch-free (rows outside the grid read a row of "none" through a uniform
-//                 pointer select), so the scheduler overlaps the table reads of all candidates.
+//                 base select) and the float work of two ids at a time is written on 2-vectors.
 //   CHECK_NONE = false (n < table size): the last table slot can never be a real scrambled coordinate; its
-//                 dz^2 entry holds +inf, so a "none" candidate yields d = inf/NaN and loses without a compare.
+//                 dz^2 entry holds +inf, so a "none" candidate yields d = inf and loses without a compare.
 //   FINAL = true  last pass (k = 1) fused with the id -> sdf conversion of jfa_final: the winning
-//                 distance is already in a register, so the pass writes floats instead of ids and the
-//                 separate read+write of the id volume disappears.
-// A 4th window slot prefetches the plane of the NEXT step before the current step is evaluated.
+//                 distance is already in a register, so the pass writes floats instead of ids.
 constexpr int kChain = 4;
 
-// No waves-per-SIMD request: left alone the compiler settles at ~93 VGPRs (5 waves/SIMD, no spills), which
-// measured faster than forcing 5 (86 VGPRs) or 6 (80 VGPRs + scratch).
+// Row loads go through a buffer resource (base in SGPRs + one 32-bit VGPR byte offset that is the same for every
+// row of the thread), which costs no VALU address arithmetic; plain pointer loads from a selected base compiled
+// to a 64-bit VALU add per load.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_resource(const void* row, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(row), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void row_load(uint32_t& o, __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    o = __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void row_load(uint2& o, __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+    o = make_uint2(v[0], v[1]);
+}
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lds_f32(const char* p) { return *reinterpret_cast<const float*>(p); }
+// An empty asm that "modifies" a running value: everything feeding it has to be computed here.  Without it the
+// compiler sinks the compare/select chains of a whole chain towards the stores and keeps every distance live
+// (132 VGPRs instead of 75).
+__device__ __forceinline__ void pin(float& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin(uint32_t& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin(uint2& a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
+
 template <class ID, bool SKIP, bool CHECK_NONE, bool FINAL>
 __global__ void __launch_bounds__(256)
-jfa_pass_zchain(Frame f, uint32_t k, const typename ID::T* __restrict__ in, const typename ID::T* __restrict__ minus,
-                const typename ID::T* __restrict__ plus, typename ID::T* __restrict__ out,
-                const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
+jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, const typename ID::T* __restrict__ minus,
+                 const typename ID::T* __restrict__ plus, typename ID::T* __restrict__ out,
+                 const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
 {
     using T = typename ID::T;
     constexpr int kTab = ID::kTab;
+    constexpr int CH = kChain;
     __shared__ float PX[kTab];
     __shared__ float TY[kTab];
-    __shared__ float TZ[kChain][kTab];
+    __shared__ float TZ[CH][kTab];
 
     const int N = (int)f.n;
     const int nzl = (int)(f.z1 - f.z0);                            // planes in this slab
     const uint32_t tid = threadIdx.x;
-    const int y = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous band of rows, so that the rows
+    // neighbouring workgroups share (y-k, y, y+k) meet in one L2.  (n % 8 == 0.)
+    const int y = (int)(blockIdx.x & 7u) * (N >> 3) + (int)(blockIdx.x >> 3);
     const int nres = min((int)k, nzl);                             // residue classes of local plane index mod k
     const int r = (int)(blockIdx.y % nres);
-    const int j0 = (int)(blockIdx.y / nres) * kChain;
+    const int j0 = (int)(blockIdx.y / nres) * CH;
     const int lbase = r + j0 * (int)k;                             // local plane of chain element 0
     if (lbase >= nzl) return;
     const int zbase = lbase + (int)f.z0;                           // global plane
     {
         const float py = axis_pos(f.oy, y, f.vs);
-        float pz[kChain];
+        float pz[CH];
 #pragma unroll
-        for (int j = 0; j < kChain; ++j) pz[j] = axis_pos(f.oz, zbase + j * (int)k, f.vs);
+        for (int j = 0; j < CH; ++j) pz[j] = axis_pos(f.oz, zbase + j * (int)k, f.vs);
         for (uint32_t i = tid; i < (uint32_t)N; i += 256) {
             const uint32_t si = scr(i);
             PX[i] = axis_pos(f.ox, i, f.vs);
@@ -431,7 +461,7 @@ jfa_pass_zchain(Frame f, uint32_t k, const typename ID::T* __restrict__ in, cons
             TY[si] = dyv * dyv;
             const float sz = axis_pos(f.oz, i, f.vs);
 #pragma unroll
-            for (int j = 0; j < kChain; ++j) {
+            for (int j = 0; j < CH; ++j) {
                 const float dzv = sz - pz[j];
                 TZ[j][si] = dzv * dzv;
             }
@@ -439,13 +469,14 @@ jfa_pass_zchain(Frame f, uint32_t k, const typename ID::T* __restrict__ in, cons
         if (!CHECK_NONE && tid == 0) {
             PX[kTab - 1] = 0.0f; TY[kTab - 1] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < kChain; ++j) TZ[j][kTab - 1] = INFINITY;
+            for (int j = 0; j < CH; ++j) TZ[j][kTab - 1] = INFINITY;
         }
     }
     __syncthreads();
 
     const char* tx = reinterpret_cast<const char*>(PX);
     const char* ty = reinterpret_cast<const char*>(TY);
+    const char* tz = reinterpret_cast<const char*>(TZ);
     uint32_t ro[3];                                                // byte offsets of rows y-k, y, y+k inside a plane
     bool yv[3];
     const uint32_t rowBytes = (uint32_t)N * (uint32_t)sizeof(T);
@@ -456,87 +487,117 @@ jfa_pass_zchain(Frame f, uint32_t k, const typename ID::T* __restrict__ in, cons
         ro[dy + 1] = (uint32_t)(yv[dy + 1] ? ny : 0) * rowBytes;
     }
     const uint32_t kb = k * (uint32_t)sizeof(T);
+    const int K = (int)k;
+    // Outputs of this chain that exist: planes zbase + j*k inside the slab.  Plane P of the chain (P = -1 .. nout)
+    // is read only if one of its three outputs exists, so a prefetch never reaches past the halo of a slab.
+    int nout = 1;
+#pragma unroll
+    for (int j = 1; j < CH; ++j) nout += (zbase + j * K < (int)f.z1) ? 1 : 0;
 
     for (uint32_t x = tid; x < (uint32_t)N; x += 256) {
         const float px = PX[x];
         const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
+        // A column outside the grid reads the centre column instead: the same id as the neighbouring candidate in
+        // scan order, which cannot change the winner, so no validity mask is needed.
         const uint32_t xo = x * (uint32_t)sizeof(T), xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;
 
-        // 9 ids of source plane zg (rows y-k, y, y+k x {x-k, x, x+k}); "none" where outside the grid
-        auto load_plane = [&](int zg, T (&w)[9]) {
-            const bool zin = zg >= 0 && zg < N;                    // wave-uniform
+        // 9 ids of source plane zg (rows y-k, y, y+k x {x-k, x, x+k}); "none" where outside the grid or not needed
+        auto load_plane = [&](int zg, T (&w)[9], bool needed) {
+            const bool zin = needed && zg >= 0 && zg < N;          // wave-uniform
             const char* pl = reinterpret_cast<const char*>(zin ? id_plane(f, k, in, minus, plus, zg) : in);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 if (!SKIP || (zin && yv[dy])) {
-                    const char* b = (zin && yv[dy]) ? pl + ro[dy] : reinterpret_cast<const char*>(none_row);
-                    w[dy * 3 + 0] = *reinterpret_cast<const T*>(b + xmo);
-                    w[dy * 3 + 1] = *reinterpret_cast<const T*>(b + xo);
-                    w[dy * 3 + 2] = *reinterpret_cast<const T*>(b + xpo);
+                    const __amdgpu_buffer_rsrc_t b =
+                        row_resource((zin && yv[dy]) ? pl + ro[dy] : reinterpret_cast<const char*>(none_row), rowBytes);
+                    row_load(w[dy * 3 + 0], b, xmo);
+                    row_load(w[dy * 3 + 1], b, xo);
+                    row_load(w[dy * 3 + 2], b, xpo);
                 } else {
                     w[dy * 3 + 0] = ID::none(); w[dy * 3 + 1] = ID::none(); w[dy * 3 + 2] = ID::none();
                 }
             }
         };
 
-        // one chain step: window (wm, w0, wp) = planes (z-k, z, z+k); TZ table of this plane at `tz`
-        auto step = [&](int zg, const char* tz, const T (&wm)[9], const T (&w0)[9], const T (&wp)[9]) {
-            T best = w0[4];
-            float bestd = INFINITY;
-            auto eval = [&](T id, bool ok) {
-                const float sx = *reinterpret_cast<const float*>(tx + ID::xoff(id));
-                const float dy2 = *reinterpret_cast<const float*>(ty + ID::yoff(id));
-                const float dz2 = *reinterpret_cast<const float*>(tz + ID::zoff(id));
-                const float dxv = sx - px;
-                const float d = ((dxv * dxv) + dy2) + dz2;        // (dx^2 + dy^2) does not depend on the step: kept per id
-                bool take = ok & (d < bestd);
-                if (CHECK_NONE) take = take & !ID::is_none(id);
-                bestd = take ? d : bestd;
-                best = ID::sel(take, id, best);
-            };
-            auto cand = [&](T id, bool ok) {
-                if (SKIP) { if (__any(ok & !ID::is_none(id))) eval(id, ok); }
-                else eval(id, ok);
-            };
-            eval(w0[4], true);                       // own state first: it wins ties (strict '<', sequential.cpp:106)
-            // reference scan order: z, then y, then x (sequential.cpp:86-88) = plane by plane
+        T best[CH];
+        float bestd[CH];
 #pragma unroll
-            for (int q = 0; q < 9; q += 3) { cand(wm[q], hasM); cand(wm[q + 1], true); cand(wm[q + 2], hasP); }
+        for (int j = 0; j < CH; ++j) { best[j] = ID::none(); bestd[j] = INFINITY; }
+
+        auto update = [&](int o, T id, float d, bool own, bool real) {
+            bool take = own ? (d <= bestd[o]) : (d < bestd[o]);    // strict '<' of sequential.cpp:106; own: see header
+            if (CHECK_NONE) take = take & real;
+            bestd[o] = take ? d : bestd[o];
+            best[o] = ID::sel(take, id, best[o]);
+        };
+        // plane P of the chain (global plane zbase + P*k) scattered into outputs P-1, P, P+1
+        auto scatter = [&](int P, const T (&w)[9]) {
+            if constexpr (SKIP) {
 #pragma unroll
-            for (int q = 0; q < 9; q += 3) { cand(w0[q], hasM); if (q != 3) cand(w0[q + 1], true); cand(w0[q + 2], hasP); }
+                for (int q = 0; q < 9; ++q) {
+                    const T id = w[q];
+                    if (__any(!ID::is_none(id))) {
+                        const float sx = lds_f32(tx + ID::xoff(id));
+                        const float dy2 = lds_f32(ty + ID::yoff(id));
+                        const float dxv = sx - px;
+                        const float pre = (dxv * dxv) + dy2;
+                        const uint32_t zo = ID::zoff(id);
+                        const bool real = CHECK_NONE ? !ID::is_none(id) : true;
 #pragma unroll
-            for (int q = 0; q < 9; q += 3) { cand(wp[q], hasM); cand(wp[q + 1], true); cand(wp[q + 2], hasP); }
-            const size_t rowIdx = (size_t)(zg - (int)f.z0) * N + y;
+                        for (int o = P - 1; o <= P + 1; ++o)
+                            if (o >= 0 && o < CH) update(o, id, pre + lds_f32(tz + o * (kTab * 4) + zo), o == P && q == 4, real);
+                    }
+                }
+            } else {
+                const v2f px2 = {px, px};
+#pragma unroll
+                for (int q = 0; q < 9; q += 2) {
+                    const bool two = q + 1 < 9;
+                    const T ia = w[q], ib = w[two ? q + 1 : q];
+                    const v2f sx = {lds_f32(tx + ID::xoff(ia)), lds_f32(tx + ID::xoff(ib))};
+                    const v2f dy2 = {lds_f32(ty + ID::yoff(ia)), lds_f32(ty + ID::yoff(ib))};
+                    const v2f dxv = sx - px2;
+                    const v2f pre = (dxv * dxv) + dy2;
+                    const uint32_t za = ID::zoff(ia), zb = ID::zoff(ib);
+                    const bool ra = CHECK_NONE ? !ID::is_none(ia) : true, rb = CHECK_NONE ? !ID::is_none(ib) : true;
+#pragma unroll
+                    for (int o = P - 1; o <= P + 1; ++o) {
+                        if (o < 0 || o >= CH) continue;
+                        const v2f dz2 = {lds_f32(tz + o * (kTab * 4) + za), lds_f32(tz + o * (kTab * 4) + zb)};
+                        const v2f d = pre + dz2;
+                        update(o, ia, d[0], o == P && q == 4, ra);
+                        if (two) update(o, ib, d[1], false, rb);   // q + 1 is never the own voxel (q is even, own = 4)
+                    }
+                }
+            }
+        };
+        auto store = [&](int j) {
+            const size_t rowIdx = (size_t)(zbase + j * K - (int)f.z0) * N + y;
             if (FINAL) {
                 const uint32_t wbits = words[rowIdx * f.w + (x >> 5)];
                 const bool set = (wbits >> (x & 31)) & 1u;
                 // jfa_final's rule (sequential.cpp:55-60,106-109): set voxels carry +, unset ones the sign of the caller's fill;
                 // bestd is +inf when no seed was found, which copysign turns into the fill itself.
-                sdf[rowIdx * N + x] = set ? bestd : copysignf(bestd, fill);
+                sdf[rowIdx * N + x] = set ? bestd[j] : copysignf(bestd[j], fill);
             } else {
-                *reinterpret_cast<T*>(reinterpret_cast<char*>(out + rowIdx * N) + xo) = best;
+                *reinterpret_cast<T*>(reinterpret_cast<char*>(out + rowIdx * N) + xo) = best[j];
             }
         };
 
-        T wa[9], wb[9], wc[9], wd[9];
-        const int K = (int)k;
-        const int zend = (int)f.z1;                                // chain elements must be planes of this slab
-        // plane z_j + k is read only if step j exists: a prefetch must never reach past the halo of a slab
-        const bool s1 = zbase + K < zend, s2 = zbase + 2 * K < zend, s3 = zbase + 3 * K < zend;
-        load_plane(zbase - K, wa);
-        load_plane(zbase, wb);
-        load_plane(zbase + K, wc);
-        if (s1) load_plane(zbase + 2 * K, wd);
-        step(zbase, reinterpret_cast<const char*>(TZ[0]), wa, wb, wc);
-        if (s1) {
-            if (s2) load_plane(zbase + 3 * K, wa);
-            step(zbase + K, reinterpret_cast<const char*>(TZ[1]), wb, wc, wd);
-            if (s2) {
-                if (s3) load_plane(zbase + 4 * K, wb);
-                step(zbase + 2 * K, reinterpret_cast<const char*>(TZ[2]), wc, wd, wa);
-                if (s3)
-                    step(zbase + 3 * K, reinterpret_cast<const char*>(TZ[3]), wd, wa, wb);
-            }
+        T wa[9], wb[9];
+        load_plane(zbase - K, wa, true);
+        // No branch on `nout` around the planes: a plane that is not needed reads the row of "none" (never memory past
+        // the slab's halo) and its outputs are simply not stored, so the whole chain stays one basic block.
+#pragma unroll
+        for (int P = -1; P <= CH; ++P) {
+            T (&cur)[9] = ((P + 1) & 1) ? wb : wa;                 // P = -1 -> wa, 0 -> wb, ...
+            T (&nxt)[9] = ((P + 1) & 1) ? wa : wb;
+            if (P + 1 <= CH) load_plane(zbase + (P + 1) * K, nxt, P + 1 <= nout);   // in flight while P is evaluated
+            scatter(P, cur);
+            if (P >= 1 && P - 1 < nout) store(P - 1);
+#pragma unroll
+            for (int o = P; o <= P + 1; ++o)
+                if (o >= 0 && o < CH) { pin(bestd[o]); pin(best[o]); }
         }
     }
 }
@@ -648,7 +709,7 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     const bool skip = k * 4 >= f.n, chk = (int)f.n >= ID::kTab, fin = d_sdf != nullptr;
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k; // residue classes of the local plane index, planes per class
     const dim3 grid(f.n, nres * ((zlen + kChain - 1) / kChain));
-#define VP_LAUNCH_CHAIN(S, C, F) hipLaunchKernelGGL((jfa_pass_zchain<ID, S, C, F>), grid, dim3(256), 0, ctx->stream, f, k, (const T*)d_in, \
+#define VP_LAUNCH_CHAIN(S, C, F) hipLaunchKernelGGL((jfa_pass_zstream<ID, S, C, F>), grid, dim3(256), 0, ctx->stream, f, k, (const T*)d_in, \
                                                     (const T*)d_minus, (const T*)d_plus, (T*)d_out, none_row, d_words, fill, d_sdf)
     if (fin)       { if (chk) VP_LAUNCH_CHAIN(false, true, true);  else VP_LAUNCH_CHAIN(false, false, true); }
     else if (skip) { if (chk) VP_LAUNCH_CHAIN(true, true, false);  else VP_LAUNCH_CHAIN(true, false, false); }
