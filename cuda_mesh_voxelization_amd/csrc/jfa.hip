@@ -18,12 +18,14 @@
 //                   stores after a wave shuffle transposes word-per-lane into voxels-per-lane.
 //   jfa_first_pass  step k = n/2 straight from the border bitmask (no init id volume).
 //   jfa_pass_direct (VP_ALGO_NAIVE) one thread per voxel, everything recomputed inline.
-//   jfa_pass_zstream (VP_ALGO_TILED, n >= 256) LDS coordinate tables; chains of planes k apart, each plane read
-//                   once and scattered into its three outputs; jfa_pass_table is the small-n variant.
+//   jfa_pass_zstream (VP_ALGO_TILED, n >= 256) LDS coordinate tables; a workgroup owns a tile of rows x planes that
+//                   are k apart, reads every source plane once and scatters each id into the outputs it is a
+//                   candidate for; jfa_pass_table is the small-n variant.
 //   jfa_final       ids + bitmask -> float sdf.
 //
 // Built with -ffp-contract=off (an FMA changes the result).
 #include "vp_internal.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -368,36 +370,41 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 }
 
 // ------------------------------------------------------------------------------------------ z-stream
-// Fast path for n >= 256.  A workgroup owns ONE x-row position (y fixed) in kChain planes that are k apart,
-// z_j = z0 + r + (j0 + j) * k.  Output plane z_j takes its candidates from planes z_j - k, z_j, z_j + k, i.e. from
-// its chain neighbours, so the kChain + 2 planes of the chain are each read ONCE (rows y-k, y, y+k x columns
-// {x-k, x, x+k} = 9 ids per thread) and serve three outputs: 13.5 loads per voxel instead of 27.
-// The kernel is input-stationary: every plane of 9 ids is decoded once and scattered into the running
-// (best id, distance) pairs of the three outputs it is a candidate for (z_{P-1} as their "+k" plane, z_P as its
-// own plane, z_{P+1} as their "-k" plane).  Planes arrive in increasing z and ids in (y, x) order, so each
-// output still sees its 27 candidates in the reference's scan order (sequential.cpp:86-88).  The voxel's own
-// state no longer comes first; it wins ties instead by being merged with '<=' (a leftmost minimum with "own"
-// leftmost is the same thing: candidates before it were taken with '<', later ones need '<' to replace it).
-// LDS tables at fixed addresses turn id fields into (seed x, dy^2, dz^2 per output plane); fl(dx^2 + dy^2) is
-// computed once per id and shared by its three outputs, which keeps the reference's association
+// Fast path for n >= 256.  A workgroup owns a TILE of RY output rows x CH output planes, both k apart:
+// rows y_a = y0 + a*k, planes z_j = z0 + j*k.  Output (y_a, z_j) takes its candidates from rows y_a - k, y_a,
+// y_a + k of planes z_j - k, z_j, z_j + k, i.e. from the tile's own rows / planes and one halo row / plane on each
+// side.  Every source plane of the tile is therefore read ONCE -- (RY+2) rows x columns {x-k, x, x+k} per thread --
+// and serves up to 3 output rows x 3 output planes: 3(RY+2)(CH+2)/(RY*CH) = 6.75 loads per voxel for the 4x4 tile
+// instead of 27, and each row segment comes from L2 2.25 times instead of 9.
+// The kernel is input-stationary: every id is decoded once and scattered into the running (best id, distance)
+// pairs of the outputs it is a candidate for.  Planes arrive in increasing z, rows in increasing y and columns in
+// increasing x, so each output still sees its 27 candidates in the reference's scan order (sequential.cpp:86-88).
+// The voxel's own state no longer comes first; it wins ties instead by being merged with '<=' (a leftmost minimum
+// with "own" leftmost is the same thing: candidates before it were taken with '<', later ones need '<' to replace
+// it).  LDS tables at fixed addresses turn id fields into seed x, dy^2 per output row and dz^2 per output plane;
+// dx^2 is computed once per id, fl(dx^2 + dy^2) once per (id, output row), which keeps the reference's association
 // ((dx^2 + dy^2) + dz^2) (jfa/jfa.h:19-20).
-//     per candidate-step   1 ds_read + 1 add + compare + 2 selects
-//     per loaded id        x, y, z decode (5 VALU) + 2 ds_read + sub, mul, add
-//     registers            9 ids of the plane in flight + 9 prefetched + 3 running pairs: ~75 VGPRs, 6 waves / SIMD
-// (The output-stationary predecessor kept a 3-plane window of ids + partial distances per thread: 96 VGPRs,
-// 5 waves, one more VALU per candidate-step.)  Measured on MI355X the kernel is balanced, not bound by one unit:
-// removing all LDS lookups or 15 % of the VALU instructions does not change its time, removing the global loads
-// gains 20 %.  v_pk_*_f32 runs at half the rate of the scalar forms here, so pairing ids buys issue slots only.
+//     per candidate-step   1 add + compare + 2 selects; the dz^2 lookup is shared by the output rows
+//     per loaded id        x, y, z decode (5 VALU) + x lookup + sub, mul
+//     registers            (RY+2)*3 ids of the plane in flight + as many prefetched + RY*3 running pairs: 80 VGPRs
+// What limits it (MI355X counters, profiles/): the vector-memory pipe -- TCP busy 97 %, TD busy 95 %, 62 % of that
+// stalled on L2 returns -- while VALU and LDS sit at 60-70 %; removing all LDS lookups or 15 % of the VALU
+// instructions changed nothing, fewer loads and fewer L2 requests per voxel (bigger tiles) did:
+// 1x4 0.68 ms, 2x4 0.57, 3x4 0.56, 2x8 0.54, 4x4 0.52 per dense pass at n = 512; n = 1024: 2x4 4.8 ms, 4x4 4.65.
+//   TAB           table entries.  512 for n <= 512 (2-KB tables: 18 KB of LDS per workgroup), else the id format's
+//                 field range; fields are masked to it.
 //   SKIP = true   (early passes, k >= n/4: sparse state, many rows outside the grid) rows / planes outside
 //                 the grid are skipped with wave-uniform branches and a candidate column in which no lane
 //                 of the wave holds a seed is skipped after a ballot.
-//   SKIP = false  the voxel loop is branch-free (rows outside the grid read a row of "none" through a uniform
-//                 base select) and the float work of two ids at a time is written on 2-vectors.
-//   CHECK_NONE = false (n < table size): the last table slot can never be a real scrambled coordinate; its
+//   SKIP = false  the voxel loop is branch-free: rows outside the grid read a row of "none" through a uniform
+//                 base select.
+//   CHECK_NONE = false (n < TAB): the last table slot can never be a real scrambled coordinate; its
 //                 dz^2 entry holds +inf, so a "none" candidate yields d = inf and loses without a compare.
 //   FINAL = true  last pass (k = 1) fused with the id -> sdf conversion of jfa_final: the winning
 //                 distance is already in a register, so the pass writes floats instead of ids.
-constexpr int kChain = 4;
+// The wide-id format has 8-KB tables and takes a smaller tile to keep four workgroups per CU.
+constexpr int kRows = 4, kPlanes = 4;
+constexpr int kRowsWide = 2, kPlanesWide = 2;
 
 // Row loads go through a buffer resource (base in SGPRs + one 32-bit VGPR byte offset that is the same for every
 // row of the thread), which costs no VALU address arithmetic; plain pointer loads from a selected base compiled
@@ -415,7 +422,6 @@ __device__ __forceinline__ void row_load(uint2& o, __amdgpu_buffer_rsrc_t r, uin
     const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
     o = make_uint2(v[0], v[1]);
 }
-typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float lds_f32(const char* p) { return *reinterpret_cast<const float*>(p); }
 // An empty asm that "modifies" a running value: everything feeding it has to be computed here.  Without it the
 // compiler sinks the compare/select chains of a whole chain towards the stores and keeps every distance live
@@ -424,41 +430,49 @@ __device__ __forceinline__ void pin(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(uint32_t& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(uint2& a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
 
-template <class ID, bool SKIP, bool CHECK_NONE, bool FINAL>
+template <class ID, int TAB, int RY, int CH, bool SKIP, bool CHECK_NONE, bool FINAL>
 __global__ void __launch_bounds__(256)
 jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, const typename ID::T* __restrict__ minus,
                  const typename ID::T* __restrict__ plus, typename ID::T* __restrict__ out,
                  const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
 {
     using T = typename ID::T;
-    constexpr int kTab = ID::kTab;
-    constexpr int CH = kChain;
+    constexpr int kTab = TAB;                                      // table entries; fields are masked to it
+    constexpr uint32_t kField = (uint32_t)(TAB - 1) * 4u;
+    constexpr int NR = RY + 2;                                     // source rows of a plane: ybase - k .. ybase + RY*k
+    constexpr int NI = NR * 3;                                     // ids per thread and plane
     __shared__ float PX[kTab];
-    __shared__ float TY[kTab];
+    __shared__ float TY[RY][kTab];
     __shared__ float TZ[CH][kTab];
 
     const int N = (int)f.n;
+    const int K = (int)k;
     const int nzl = (int)(f.z1 - f.z0);                            // planes in this slab
     const uint32_t tid = threadIdx.x;
-    // Workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous band of rows, so that the rows
-    // neighbouring workgroups share (y-k, y, y+k) meet in one L2.  (n % 8 == 0.)
-    const int y = (int)(blockIdx.x & 7u) * (N >> 3) + (int)(blockIdx.x >> 3);
-    const int nres = min((int)k, nzl);                             // residue classes of local plane index mod k
-    const int r = (int)(blockIdx.y % nres);
-    const int j0 = (int)(blockIdx.y / nres) * CH;
-    const int lbase = r + j0 * (int)k;                             // local plane of chain element 0
-    if (lbase >= nzl) return;
-    const int zbase = lbase + (int)f.z0;                           // global plane
+    // y: residue classes of the row index mod k, RY consecutive chain elements (rows k apart) per workgroup
+    const int nresY = min(K, N);
+    const uint32_t bx = blockIdx.x;                                // (an XCD-aware remap of the tile index measured no gain)
+    const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
+    // z: the same over the local plane index of the slab
+    const int nres = min(K, nzl);
+    const int lbase = (int)(blockIdx.y % nres) + (int)(blockIdx.y / nres) * CH * K;
+    if (ybase >= N || lbase >= nzl) return;
+    const int zbase = lbase + (int)f.z0;                           // global plane of chain element 0
     {
-        const float py = axis_pos(f.oy, y, f.vs);
-        float pz[CH];
+        float py[RY], pz[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) pz[j] = axis_pos(f.oz, zbase + j * (int)k, f.vs);
+        for (int j = 0; j < RY; ++j) py[j] = axis_pos(f.oy, ybase + j * K, f.vs);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) pz[j] = axis_pos(f.oz, zbase + j * K, f.vs);
         for (uint32_t i = tid; i < (uint32_t)N; i += 256) {
             const uint32_t si = scr(i);
             PX[i] = axis_pos(f.ox, i, f.vs);
-            const float dyv = axis_pos(f.oy, i, f.vs) - py;
-            TY[si] = dyv * dyv;
+            const float sy = axis_pos(f.oy, i, f.vs);
+#pragma unroll
+            for (int j = 0; j < RY; ++j) {
+                const float dyv = sy - py[j];
+                TY[j][si] = dyv * dyv;
+            }
             const float sz = axis_pos(f.oz, i, f.vs);
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
@@ -467,7 +481,9 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
             }
         }
         if (!CHECK_NONE && tid == 0) {
-            PX[kTab - 1] = 0.0f; TY[kTab - 1] = 0.0f;
+            PX[kTab - 1] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < RY; ++j) TY[j][kTab - 1] = 0.0f;
 #pragma unroll
             for (int j = 0; j < CH; ++j) TZ[j][kTab - 1] = INFINITY;
         }
@@ -477,22 +493,23 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
     const char* tx = reinterpret_cast<const char*>(PX);
     const char* ty = reinterpret_cast<const char*>(TY);
     const char* tz = reinterpret_cast<const char*>(TZ);
-    uint32_t ro[3];                                                // byte offsets of rows y-k, y, y+k inside a plane
-    bool yv[3];
     const uint32_t rowBytes = (uint32_t)N * (uint32_t)sizeof(T);
+    // Output rows / planes of this workgroup that exist.  A source row or plane is read only if one of its outputs
+    // exists, so nothing is fetched past the grid or past the halo of a slab.
+    int yout = 1, nout = 1;
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-        const int ny = y + dy * (int)k;
-        yv[dy + 1] = ny >= 0 && ny < N;
-        ro[dy + 1] = (uint32_t)(yv[dy + 1] ? ny : 0) * rowBytes;
-    }
-    const uint32_t kb = k * (uint32_t)sizeof(T);
-    const int K = (int)k;
-    // Outputs of this chain that exist: planes zbase + j*k inside the slab.  Plane P of the chain (P = -1 .. nout)
-    // is read only if one of its three outputs exists, so a prefetch never reaches past the halo of a slab.
-    int nout = 1;
+    for (int j = 1; j < RY; ++j) yout += (ybase + j * K < N) ? 1 : 0;
 #pragma unroll
     for (int j = 1; j < CH; ++j) nout += (zbase + j * K < (int)f.z1) ? 1 : 0;
+    uint32_t ro[NR];                                               // byte offsets of the source rows inside a plane
+    bool yv[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        const int ny = ybase + (rr - 1) * K;
+        yv[rr] = ny >= 0 && ny < N && max(rr - 2, 0) < yout;       // row rr serves output rows rr-2 .. rr
+        ro[rr] = (uint32_t)(yv[rr] ? ny : 0) * rowBytes;
+    }
+    const uint32_t kb = k * (uint32_t)sizeof(T);
 
     for (uint32_t x = tid; x < (uint32_t)N; x += 256) {
         const float px = PX[x];
@@ -501,103 +518,101 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
         // scan order, which cannot change the winner, so no validity mask is needed.
         const uint32_t xo = x * (uint32_t)sizeof(T), xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;
 
-        // 9 ids of source plane zg (rows y-k, y, y+k x {x-k, x, x+k}); "none" where outside the grid or not needed
-        auto load_plane = [&](int zg, T (&w)[9], bool needed) {
+        // ids of source plane zg: rows ybase-k .. ybase+RY*k x columns {x-k, x, x+k}; "none" where outside the grid or not needed
+        auto load_plane = [&](int zg, T (&w)[NI], bool needed) {
             const bool zin = needed && zg >= 0 && zg < N;          // wave-uniform
             const char* pl = reinterpret_cast<const char*>(zin ? id_plane(f, k, in, minus, plus, zg) : in);
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                if (!SKIP || (zin && yv[dy])) {
+            for (int rr = 0; rr < NR; ++rr) {
+                if (!SKIP || (zin && yv[rr])) {
                     const __amdgpu_buffer_rsrc_t b =
-                        row_resource((zin && yv[dy]) ? pl + ro[dy] : reinterpret_cast<const char*>(none_row), rowBytes);
-                    row_load(w[dy * 3 + 0], b, xmo);
-                    row_load(w[dy * 3 + 1], b, xo);
-                    row_load(w[dy * 3 + 2], b, xpo);
+                        row_resource((zin && yv[rr]) ? pl + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
+                    row_load(w[rr * 3 + 0], b, xmo);
+                    row_load(w[rr * 3 + 1], b, xo);
+                    row_load(w[rr * 3 + 2], b, xpo);
                 } else {
-                    w[dy * 3 + 0] = ID::none(); w[dy * 3 + 1] = ID::none(); w[dy * 3 + 2] = ID::none();
+                    w[rr * 3 + 0] = ID::none(); w[rr * 3 + 1] = ID::none(); w[rr * 3 + 2] = ID::none();
                 }
             }
         };
 
-        T best[CH];
-        float bestd[CH];
+        T best[RY][CH];
+        float bestd[RY][CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) { best[j] = ID::none(); bestd[j] = INFINITY; }
+        for (int a = 0; a < RY; ++a)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { best[a][j] = ID::none(); bestd[a][j] = INFINITY; }
 
-        auto update = [&](int o, T id, float d, bool own, bool real) {
-            bool take = own ? (d <= bestd[o]) : (d < bestd[o]);    // strict '<' of sequential.cpp:106; own: see header
-            if (CHECK_NONE) take = take & real;
-            bestd[o] = take ? d : bestd[o];
-            best[o] = ID::sel(take, id, best[o]);
-        };
-        // plane P of the chain (global plane zbase + P*k) scattered into outputs P-1, P, P+1
-        auto scatter = [&](int P, const T (&w)[9]) {
-            if constexpr (SKIP) {
+        // plane P of the chain (global plane zbase + P*k) scattered into output planes P-1, P, P+1 of every output row
+        auto scatter = [&](int P, const T (&w)[NI]) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) {
-                    const T id = w[q];
-                    if (__any(!ID::is_none(id))) {
-                        const float sx = lds_f32(tx + ID::xoff(id));
-                        const float dy2 = lds_f32(ty + ID::yoff(id));
-                        const float dxv = sx - px;
-                        const float pre = (dxv * dxv) + dy2;
-                        const uint32_t zo = ID::zoff(id);
-                        const bool real = CHECK_NONE ? !ID::is_none(id) : true;
+            for (int q = 0; q < NI; ++q) {
+                const int rr = q / 3, c = q % 3;
+                const T id = w[q];
+                auto body = [&]() {
+                    const float sx = lds_f32(tx + (ID::xoff(id) & kField));
+                    const float dxv = sx - px;
+                    const float dx2 = dxv * dxv;
+                    const uint32_t yo = ID::yoff(id) & kField, zo = ID::zoff(id) & kField;
+                    const bool real = CHECK_NONE ? !ID::is_none(id) : true;
+#pragma unroll
+                    for (int a = rr - 2; a <= rr; ++a) {           // output rows this source row is a candidate for
+                        if (a < 0 || a >= RY) continue;
+                        const float pre = dx2 + lds_f32(ty + a * (kTab * 4) + yo);
+                        const bool ownRow = (rr == a + 1) && (c == 1);
+#pragma unroll
+                        for (int o = P - 1; o <= P + 1; ++o) {
+                            if (o < 0 || o >= CH) continue;
+                            const float d = pre + lds_f32(tz + o * (kTab * 4) + zo);
+                            // strict '<' of sequential.cpp:106; the voxel's own state wins ties (see header)
+                            bool take = (ownRow && o == P) ? (d <= bestd[a][o]) : (d < bestd[a][o]);
+                            if (CHECK_NONE) take = take & real;
+                            bestd[a][o] = take ? d : bestd[a][o];
+                            best[a][o] = ID::sel(take, id, best[a][o]);
+                        }
+                    }
+                };
+                if (SKIP) { if (__any(!ID::is_none(id))) body(); }  // a candidate column in which no lane holds a seed
+                else body();
+                if (!SKIP && c == 2) {                             // end of a source row: finish its updates before the next row's decode
+#pragma unroll
+                    for (int a = rr - 2; a <= rr; ++a)
 #pragma unroll
                         for (int o = P - 1; o <= P + 1; ++o)
-                            if (o >= 0 && o < CH) update(o, id, pre + lds_f32(tz + o * (kTab * 4) + zo), o == P && q == 4, real);
-                    }
-                }
-            } else {
-                const v2f px2 = {px, px};
-#pragma unroll
-                for (int q = 0; q < 9; q += 2) {
-                    const bool two = q + 1 < 9;
-                    const T ia = w[q], ib = w[two ? q + 1 : q];
-                    const v2f sx = {lds_f32(tx + ID::xoff(ia)), lds_f32(tx + ID::xoff(ib))};
-                    const v2f dy2 = {lds_f32(ty + ID::yoff(ia)), lds_f32(ty + ID::yoff(ib))};
-                    const v2f dxv = sx - px2;
-                    const v2f pre = (dxv * dxv) + dy2;
-                    const uint32_t za = ID::zoff(ia), zb = ID::zoff(ib);
-                    const bool ra = CHECK_NONE ? !ID::is_none(ia) : true, rb = CHECK_NONE ? !ID::is_none(ib) : true;
-#pragma unroll
-                    for (int o = P - 1; o <= P + 1; ++o) {
-                        if (o < 0 || o >= CH) continue;
-                        const v2f dz2 = {lds_f32(tz + o * (kTab * 4) + za), lds_f32(tz + o * (kTab * 4) + zb)};
-                        const v2f d = pre + dz2;
-                        update(o, ia, d[0], o == P && q == 4, ra);
-                        if (two) update(o, ib, d[1], false, rb);   // q + 1 is never the own voxel (q is even, own = 4)
-                    }
+                            if (a >= 0 && a < RY && o >= 0 && o < CH) { pin(bestd[a][o]); pin(best[a][o]); }
                 }
             }
         };
-        auto store = [&](int j) {
-            const size_t rowIdx = (size_t)(zbase + j * K - (int)f.z0) * N + y;
+        auto store = [&](int a, int j) {
+            const size_t rowIdx = (size_t)(zbase + j * K - (int)f.z0) * N + (ybase + a * K);
             if (FINAL) {
                 const uint32_t wbits = words[rowIdx * f.w + (x >> 5)];
                 const bool set = (wbits >> (x & 31)) & 1u;
                 // jfa_final's rule (sequential.cpp:55-60,106-109): set voxels carry +, unset ones the sign of the caller's fill;
                 // bestd is +inf when no seed was found, which copysign turns into the fill itself.
-                sdf[rowIdx * N + x] = set ? bestd[j] : copysignf(bestd[j], fill);
+                sdf[rowIdx * N + x] = set ? bestd[a][j] : copysignf(bestd[a][j], fill);
             } else {
-                *reinterpret_cast<T*>(reinterpret_cast<char*>(out + rowIdx * N) + xo) = best[j];
+                *reinterpret_cast<T*>(reinterpret_cast<char*>(out + rowIdx * N) + xo) = best[a][j];
             }
         };
 
-        T wa[9], wb[9];
+        T wa[NI], wb[NI];
         load_plane(zbase - K, wa, true);
         // No branch on `nout` around the planes: a plane that is not needed reads the row of "none" (never memory past
         // the slab's halo) and its outputs are simply not stored, so the whole chain stays one basic block.
 #pragma unroll
         for (int P = -1; P <= CH; ++P) {
-            T (&cur)[9] = ((P + 1) & 1) ? wb : wa;                 // P = -1 -> wa, 0 -> wb, ...
-            T (&nxt)[9] = ((P + 1) & 1) ? wa : wb;
+            T (&cur)[NI] = ((P + 1) & 1) ? wb : wa;                // P = -1 -> wa, 0 -> wb, ...
+            T (&nxt)[NI] = ((P + 1) & 1) ? wa : wb;
             if (P + 1 <= CH) load_plane(zbase + (P + 1) * K, nxt, P + 1 <= nout);   // in flight while P is evaluated
             scatter(P, cur);
-            if (P >= 1 && P - 1 < nout) store(P - 1);
 #pragma unroll
-            for (int o = P; o <= P + 1; ++o)
-                if (o >= 0 && o < CH) { pin(bestd[o]); pin(best[o]); }
+            for (int a = 0; a < RY; ++a) {
+                if (P >= 1 && P - 1 < nout && a < yout) store(a, P - 1);
+#pragma unroll
+                for (int o = P; o <= P + 1; ++o)
+                    if (o >= 0 && o < CH) { pin(bestd[a][o]); pin(best[a][o]); }
+            }
         }
     }
 }
@@ -706,14 +721,26 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
         VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, 2048 * 8, ctx->stream));
     }
     const T* none_row = (const T*)ctx->none_row.ptr;
-    const bool skip = k * 4 >= f.n, chk = (int)f.n >= ID::kTab, fin = d_sdf != nullptr;
+    const bool skip = k * 4 >= f.n, fin = d_sdf != nullptr;
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k; // residue classes of the local plane index, planes per class
-    const dim3 grid(f.n, nres * ((zlen + kChain - 1) / kChain));
-#define VP_LAUNCH_CHAIN(S, C, F) hipLaunchKernelGGL((jfa_pass_zstream<ID, S, C, F>), grid, dim3(256), 0, ctx->stream, f, k, (const T*)d_in, \
-                                                    (const T*)d_minus, (const T*)d_plus, (T*)d_out, none_row, d_words, fill, d_sdf)
-    if (fin)       { if (chk) VP_LAUNCH_CHAIN(false, true, true);  else VP_LAUNCH_CHAIN(false, false, true); }
-    else if (skip) { if (chk) VP_LAUNCH_CHAIN(true, true, false);  else VP_LAUNCH_CHAIN(true, false, false); }
-    else           { if (chk) VP_LAUNCH_CHAIN(false, true, false); else VP_LAUNCH_CHAIN(false, false, false); }
+    const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
+    // Tile = RY rows x CH planes per workgroup and the table size; "none" needs an explicit check when the tables have no
+    // spare slot for it (n == table size).
+#define VP_LAUNCH_CHAIN(TAB, RY, CH, S, C, F)                                                                                        \
+    hipLaunchKernelGGL((jfa_pass_zstream<ID, TAB, RY, CH, S, C, F>),                                                                 \
+                       dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(256), 0, ctx->stream, f, k,         \
+                       (const T*)d_in, (const T*)d_minus, (const T*)d_plus, (T*)d_out, none_row, d_words, fill, d_sdf)
+#define VP_LAUNCH_TILE(TAB, RY, CH)                                                                                                  \
+    do {                                                                                                                             \
+        const bool chk = (int)f.n >= TAB;                                                                                            \
+        if (fin)       { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, false, true, true);  else VP_LAUNCH_CHAIN(TAB, RY, CH, false, false, true); }  \
+        else if (skip) { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, true, true, false);  else VP_LAUNCH_CHAIN(TAB, RY, CH, true, false, false); }  \
+        else           { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, false, true, false); else VP_LAUNCH_CHAIN(TAB, RY, CH, false, false, false); } \
+    } while (0)
+    if constexpr (std::is_same<ID, Id64>::value) VP_LAUNCH_TILE(Id64::kTab, kRowsWide, kPlanesWide);
+    else if (f.n <= 512) VP_LAUNCH_TILE(512, kRows, kPlanes);   // 2-KB tables
+    else VP_LAUNCH_TILE(Id32::kTab, kRows, kPlanes);
+#undef VP_LAUNCH_TILE
 #undef VP_LAUNCH_CHAIN
     return 0;
 }
