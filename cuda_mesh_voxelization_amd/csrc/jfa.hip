@@ -403,6 +403,10 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 //   FINAL = true  last pass (k = 1) fused with the id -> sdf conversion of jfa_final: the winning
 //                 distance is already in a register, so the pass writes floats instead of ids.
 // The wide-id format has 8-KB tables and takes a smaller tile to keep four workgroups per CU.
+// Tried and measured slower: taking columns x-k / x+k from an LDS row buffer filled by one coalesced load per row
+// (2.25 global loads per voxel, but +18 LDS operations per thread and plane and two barriers: 0.60 ms vs 0.52);
+// computing the seed x from the id instead of looking it up (more VALU: 0.59); skipping the selects of a candidate
+// that no lane takes (branches: 0.86); v_pk_*_f32 on pairs of ids (half rate on this part: no change).
 constexpr int kRows = 4, kPlanes = 4;
 constexpr int kRowsWide = 2, kPlanesWide = 2;
 
