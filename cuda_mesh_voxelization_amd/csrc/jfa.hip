@@ -258,15 +258,16 @@ jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, typenam
         T best = ID::none();
         float bestd = INFINITY;
         if ((own >> lane) & 1ull) { best = ID::pack(x, y, zg); bestd = 0.0f; }           // own seed: distance 0 (:56)
-        // one ballot tells whether ANY neighbour segment holds a border voxel; for most waves none does
-        if (__any(lane != 13 && (mine[r].x | mine[r].y) != 0u)) {
+        // One ballot gives the set of neighbour segments that hold a border voxel at all; only those are visited, in
+        // ascending candidate index = reference scan order z, y, x (sequential.cpp:86-88).
+        unsigned long long todo = __ballot(lane != 13 && lane < 27 && (mine[r].x | mine[r].y) != 0u);
+        if (todo) {
             const float py = axis_pos(f.oy, y, f.vs);
-#pragma unroll
-            for (int c = 0; c < 27; ++c) {                         // reference scan order z, y, x (sequential.cpp:86-88)
-                if (c == 13) continue;
+            do {
+                const int c = __builtin_ctzll(todo);               // wave-uniform
+                todo &= todo - 1;
                 const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].x, c) |
                                              ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].y, c) << 32);
-                if (m == 0ull) continue;                           // scalar branch
                 const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
                 const bool has = (m >> lane) & 1ull;
                 const T id = ID::pack((uint32_t)(x + dx * (int)k), (uint32_t)(y + dy * (int)k), (uint32_t)(zg + dz * (int)k));
@@ -274,7 +275,7 @@ jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, typenam
                 const bool take = has & (d < bestd);
                 bestd = take ? d : bestd;
                 best = ID::sel(take, id, best);
-            }
+            } while (todo);
         }
         out[((size_t)zl * N + y) * N + x] = best;
     }
@@ -590,8 +591,15 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
         auto store = [&](int a, int j) {
             const size_t rowIdx = (size_t)(zbase + j * K - (int)f.z0) * N + (ybase + a * K);
             if (FINAL) {
-                const uint32_t wbits = words[rowIdx * f.w + (x >> 5)];
-                const bool set = (wbits >> (x & 31)) & 1u;
+                bool set;
+                if (f.w & 1u) {                                    // n % 64 != 0: the last wave of a row has only one word
+                    set = (words[rowIdx * f.w + (x >> 5)] >> (x & 31)) & 1u;
+                } else {
+                    // the 64 voxels of a wave sit in two mask words at a wave-uniform address: one scalar load instead of a vector load
+                    const uint32_t xw = (uint32_t)__builtin_amdgcn_readfirstlane((int)x) >> 5;   // even: lane 0's x is a multiple of 64
+                    const uint2 wp = *reinterpret_cast<const uint2*>(words + rowIdx * f.w + xw);
+                    set = (((x & 32u) ? wp.y : wp.x) >> (x & 31)) & 1u;
+                }
                 // jfa_final's rule (sequential.cpp:55-60,106-109): set voxels carry +, unset ones the sign of the caller's fill;
                 // bestd is +inf when no seed was found, which copysign turns into the fill itself.
                 sdf[rowIdx * N + x] = set ? bestd[a][j] : copysignf(bestd[a][j], fill);
