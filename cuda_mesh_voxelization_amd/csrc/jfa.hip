@@ -449,6 +449,9 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
     __shared__ float PX[kTab];
     __shared__ float TY[RY][kTab];
     __shared__ float TZ[CH][kTab];
+    // FINAL: the bitmask words of the tile's output rows, fetched with one coalesced load while the tables are built
+    // (a load at store time waits behind the prefetched ids of the next plane: +0.13 ms at n = 512)
+    __shared__ uint32_t WM[FINAL ? RY * CH * (TAB / 32) : 1];
 
     const int N = (int)f.n;
     const int K = (int)k;
@@ -483,6 +486,13 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
             for (int j = 0; j < CH; ++j) {
                 const float dzv = sz - pz[j];
                 TZ[j][si] = dzv * dzv;
+            }
+        }
+        if (FINAL) {
+            for (uint32_t i = tid; i < (uint32_t)(RY * CH) * f.w; i += 256) {
+                const int o = (int)(i / f.w), a = o / CH, j = o % CH;
+                const int oy = ybase + a * K, oz = zbase + j * K;
+                WM[o * (TAB / 32) + i % f.w] = (oy < N && oz < (int)f.z1) ? words[((size_t)(oz - (int)f.z0) * N + oy) * f.w + i % f.w] : 0u;
             }
         }
         if (!CHECK_NONE && tid == 0) {
@@ -591,15 +601,7 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
         auto store = [&](int a, int j) {
             const size_t rowIdx = (size_t)(zbase + j * K - (int)f.z0) * N + (ybase + a * K);
             if (FINAL) {
-                bool set;
-                if (f.w & 1u) {                                    // n % 64 != 0: the last wave of a row has only one word
-                    set = (words[rowIdx * f.w + (x >> 5)] >> (x & 31)) & 1u;
-                } else {
-                    // the 64 voxels of a wave sit in two mask words at a wave-uniform address: one scalar load instead of a vector load
-                    const uint32_t xw = (uint32_t)__builtin_amdgcn_readfirstlane((int)x) >> 5;   // even: lane 0's x is a multiple of 64
-                    const uint2 wp = *reinterpret_cast<const uint2*>(words + rowIdx * f.w + xw);
-                    set = (((x & 32u) ? wp.y : wp.x) >> (x & 31)) & 1u;
-                }
+                const bool set = (WM[(a * CH + j) * (TAB / 32) + (x >> 5)] >> (x & 31)) & 1u;
                 // jfa_final's rule (sequential.cpp:55-60,106-109): set voxels carry +, unset ones the sign of the caller's fill;
                 // bestd is +inf when no seed was found, which copysign turns into the fill itself.
                 sdf[rowIdx * N + x] = set ? bestd[a][j] : copysignf(bestd[a][j], fill);

@@ -37,3 +37,11 @@ for algo in [int(x) for x in a.algos.split(",")]:
         p = ctx.prof()["jfa_pass"]; ms = p["ms"] / p["launches"]; tot += ms
         print("algo %d k=%4d seeded=%5.1f%%  %.3f ms  %.0f GB/s alg" % (algo, k, 100.0 * seeds / fr.voxels, ms, 8.0 * fr.voxels / ms / 1e6))
     print("algo %d total passes %.3f ms" % (algo, tot))
+    # the fused last pass (k = 1 + id -> sdf) on the true k = 1 input
+    k, st = states[-1]
+    ctx.prof_reset(); ctx.prof_enable(True)
+    for _ in range(a.reps):
+        ctx.jfa_last_pass(fr, st.data_ptr(), None, None, out.data_ptr(), g.data_ptr(), -math.inf, sdf.data_ptr(), algo)
+    ctx.prof_enable(False)
+    pr = ctx.prof()
+    print("algo %d fused last pass: %s" % (algo, {kk: round(v["ms"] / max(v["launches"], 1), 3) for kk, v in pr.items() if v["launches"]}))
