@@ -239,6 +239,29 @@ def test_headline_size_properties(engine):
     assert float(np.abs(s).max()) <= 3.0 * (512 * float(vs)) ** 2
 
 
+@pytest.mark.parametrize("n,against_oracle", [(288, True), (352, False), (544, False)])
+def test_jfa_tile_kernel_ragged_sizes(engine, n, against_oracle):
+    """n >= 256 that are not powers of two: the row x plane tiles of jfa_pass_zstream are ragged (n / k is not a
+    multiple of the tile, for n = 352 not even an integer), the first pass from the mask does not apply (n % 128 != 0)
+    and n = 544 runs the 1024-entry tables without the explicit none check.  Tiled against the naive kernel, and for
+    n = 288 against the oracle."""
+    xyz, tri = M.bunny(1)
+    fr, origin, vs = _frame([(xyz, tri)], n)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    g = engine.voxelize(fr, dx, dt, algo=ALGO_TILED)
+    s_t = engine.jfa(fr, g, algo=ALGO_TILED).clone()
+    s_n = engine.jfa(fr, g, algo=ALGO_NAIVE)
+    assert torch.equal(s_t.view(torch.int32), s_n.view(torch.int32))
+    # +inf fill through the fused last pass
+    s_p = engine.jfa(fr, g, fill=math.inf, algo=ALGO_TILED)
+    assert torch.equal(s_p.abs().view(torch.int32), s_t.abs().view(torch.int32))
+    assert bool((s_p >= 0).all())
+    if against_oracle:
+        w = engine.words_to_numpy(g)
+        assert np.array_equal(w, O.voxelize(xyz, tri, n, vs, origin))
+        _assert_sdf_equal(s_t.cpu().numpy(), O.jfa(w, n, vs, origin))
+
+
 def test_config2_bunny_x3_n256(engine):
     """BASELINE config 2: bunny refined x3 (168,516 faces), n = 256, tiled voxelize + JFA -- against the oracle."""
     xyz, tri = M.bunny(3)
