@@ -409,7 +409,7 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 // computing the seed x from the id instead of looking it up (more VALU: 0.59); skipping the selects of a candidate
 // that no lane takes (branches: 0.86); v_pk_*_f32 on pairs of ids (half rate on this part: no change).
 constexpr int kRows = 4, kPlanes = 4;
-constexpr int kRowsWide = 2, kPlanesWide = 2;
+constexpr int kRowsWide = 2, kPlanesWide = 2;     // n = 2048: 2x2 727 ms per JFA, 2x4 726, 1x4 796, 4x2 1143
 
 // Row loads go through a buffer resource (base in SGPRs + one 32-bit VGPR byte offset that is the same for every
 // row of the thread), which costs no VALU address arithmetic; plain pointer loads from a selected base compiled
