@@ -459,11 +459,16 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
     const uint32_t tid = threadIdx.x;
     // y: residue classes of the row index mod k, RY consecutive chain elements (rows k apart) per workgroup
     const int nresY = min(K, N);
-    const uint32_t bx = blockIdx.x;                                // (an XCD-aware remap of the tile index measured no gain)
+    // Every other pass walks the tiles in reverse dispatch order, so that a pass starts on the part of the volume the
+    // previous pass wrote last (still in L2 / Infinity Cache).  (An XCD-aware remap of the tile index measured no gain.)
+    // (bench step 4.52 -> 4.45 ms.)
+    const bool rev = ((31 - __builtin_clz(k)) & 1) != 0;
+    const uint32_t bx = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const uint32_t by = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
     const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
     // z: the same over the local plane index of the slab
     const int nres = min(K, nzl);
-    const int lbase = (int)(blockIdx.y % nres) + (int)(blockIdx.y / nres) * CH * K;
+    const int lbase = (int)(by % nres) + (int)(by / nres) * CH * K;
     if (ybase >= N || lbase >= nzl) return;
     const int zbase = lbase + (int)f.z0;                           // global plane of chain element 0
     {
