@@ -270,8 +270,11 @@ jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, typenam
                                              ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].y, c) << 32);
                 const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
                 const bool has = (m >> lane) & 1ull;
-                const T id = ID::pack((uint32_t)(x + dx * (int)k), (uint32_t)(y + dy * (int)k), (uint32_t)(zg + dz * (int)k));
-                const float d = seed_distance<ID>(f, id, px, py, pz);
+                // the candidate's coordinates are known without unpacking an id: y and z parts are wave-uniform
+                const uint32_t sxi = (uint32_t)(x + dx * (int)k), syi = (uint32_t)(y + dy * (int)k), szi = (uint32_t)(zg + dz * (int)k);
+                const float ddx = axis_pos(f.ox, sxi, f.vs) - px, ddy = axis_pos(f.oy, syi, f.vs) - py, ddz = axis_pos(f.oz, szi, f.vs) - pz;
+                const float d = ((ddx * ddx) + (ddy * ddy)) + (ddz * ddz);                   // jfa/jfa.h:19-20
+                const T id = ID::pack(sxi, syi, szi);
                 const bool take = has & (d < bestd);
                 bestd = take ? d : bestd;
                 best = ID::sel(take, id, best);
