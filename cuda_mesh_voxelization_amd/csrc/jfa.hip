@@ -394,7 +394,8 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 // What limits it (MI355X counters, profiles/): the vector-memory pipe -- TCP busy 97 %, TD busy 95 %, 62 % of that
 // stalled on L2 returns -- while VALU and LDS sit at 60-70 %; removing all LDS lookups or 15 % of the VALU
 // instructions changed nothing, fewer loads and fewer L2 requests per voxel (bigger tiles) did:
-// 1x4 0.68 ms, 2x4 0.57, 3x4 0.56, 2x8 0.54, 4x4 0.52 per dense pass at n = 512; n = 1024: 2x4 4.8 ms, 4x4 4.65.
+// 1x4 0.68 ms, 2x4 0.57, 3x4 0.56, 2x8 0.54, 4x4 0.52, 4x8 0.50 per dense pass at n = 512 (the sparse and the fused
+// last pass are fastest with 4x4: 0.35 / 0.55 ms); n = 1024: 2x4 4.8 ms, 4x4 4.65, 4x8 4.93.
 //   TAB           table entries.  512 for n <= 512 (2-KB tables: 18 KB of LDS per workgroup), else the id format's
 //                 field range; fields are masked to it.
 //   SKIP = true   (early passes, k >= n/4: sparse state, many rows outside the grid) rows / planes outside
@@ -412,6 +413,7 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 // computing the seed x from the id instead of looking it up (more VALU: 0.59); skipping the selects of a candidate
 // that no lane takes (branches: 0.86); v_pk_*_f32 on pairs of ids (half rate on this part: no change).
 constexpr int kRows = 4, kPlanes = 4;
+constexpr int kPlanesDense = 8;      // dense passes with 2-KB tables (n <= 512): 4x8 tiles, 5.6 loads per voxel
 constexpr int kRowsWide = 2, kPlanesWide = 2;     // n = 2048: 2x2 727 ms per JFA, 2x4 726, 1x4 796, 4x2 1143
 
 // Row loads go through a buffer resource (base in SGPRs + one 32-bit VGPR byte offset that is the same for every
@@ -431,6 +433,34 @@ __device__ __forceinline__ void row_load(uint2& o, __amdgpu_buffer_rsrc_t r, uin
     o = make_uint2(v[0], v[1]);
 }
 __device__ __forceinline__ float lds_f32(const char* p) { return *reinterpret_cast<const float*>(p); }
+__device__ __forceinline__ void row_store(uint32_t v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void row_store(float v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void row_store(uint2 v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 t = {v.x, v.y};
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, (int)byte_off, 0, 0);
+}
+// A wave-uniform value made opaque to the optimiser where it is used: the 128-bit row descriptors derived from it are
+// then built right before their loads / stores (a few SALU instructions) instead of being hoisted out of the x loop,
+// where the ~50 descriptors of a tile do not fit the SGPR file and were spilled to VGPR lanes (v_writelane/v_readlane).
+__device__ __forceinline__ const char* opaque_uniform(const char* p)
+{
+    uint64_t v = reinterpret_cast<uint64_t>(p);
+    asm volatile("" : "+s"(v));
+    return reinterpret_cast<const char*>(v);
+}
+__device__ __forceinline__ size_t opaque_uniform(size_t v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
 // An empty asm that "modifies" a running value: everything feeding it has to be computed here.  Without it the
 // compiler sinks the compare/select chains of a whole chain towards the stores and keeps every distance live
 // (132 VGPRs instead of 75).
@@ -544,7 +574,7 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
         // ids of source plane zg: rows ybase-k .. ybase+RY*k x columns {x-k, x, x+k}; "none" where outside the grid or not needed
         auto load_plane = [&](int zg, T (&w)[NI], bool needed) {
             const bool zin = needed && zg >= 0 && zg < N;          // wave-uniform
-            const char* pl = reinterpret_cast<const char*>(zin ? id_plane(f, k, in, minus, plus, zg) : in);
+            const char* pl = opaque_uniform(reinterpret_cast<const char*>(zin ? id_plane(f, k, in, minus, plus, zg) : in));
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
                 if (!SKIP || (zin && yv[rr])) {
@@ -559,12 +589,8 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
             }
         };
 
-        T best[RY][CH];
+        T best[RY][CH];                                            // output plane j is live from plane j-1 to plane j+1 only
         float bestd[RY][CH];
-#pragma unroll
-        for (int a = 0; a < RY; ++a)
-#pragma unroll
-            for (int j = 0; j < CH; ++j) { best[a][j] = ID::none(); bestd[a][j] = INFINITY; }
 
         // plane P of the chain (global plane zbase + P*k) scattered into output planes P-1, P, P+1 of every output row
         auto scatter = [&](int P, const T (&w)[NI]) {
@@ -607,14 +633,14 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
             }
         };
         auto store = [&](int a, int j) {
-            const size_t rowIdx = (size_t)(zbase + j * K - (int)f.z0) * N + (ybase + a * K);
+            const size_t rowIdx = opaque_uniform((size_t)(zbase + j * K - (int)f.z0) * N + (ybase + a * K));
             if (FINAL) {
                 const bool set = (WM[(a * CH + j) * (TAB / 32) + (x >> 5)] >> (x & 31)) & 1u;
                 // jfa_final's rule (sequential.cpp:55-60,106-109): set voxels carry +, unset ones the sign of the caller's fill;
                 // bestd is +inf when no seed was found, which copysign turns into the fill itself.
-                sdf[rowIdx * N + x] = set ? bestd[a][j] : copysignf(bestd[a][j], fill);
+                row_store(set ? bestd[a][j] : copysignf(bestd[a][j], fill), row_resource(sdf + rowIdx * N, (uint32_t)N * 4u), x * 4u);
             } else {
-                *reinterpret_cast<T*>(reinterpret_cast<char*>(out + rowIdx * N) + xo) = best[a][j];
+                row_store(best[a][j], row_resource(out + rowIdx * N, rowBytes), xo);
             }
         };
 
@@ -622,11 +648,15 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
         load_plane(zbase - K, wa, true);
         // No branch on `nout` around the planes: a plane that is not needed reads the row of "none" (never memory past
         // the slab's halo) and its outputs are simply not stored, so the whole chain stays one basic block.
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int P = -1; P <= CH; ++P) {
             T (&cur)[NI] = ((P + 1) & 1) ? wb : wa;                // P = -1 -> wa, 0 -> wb, ...
             T (&nxt)[NI] = ((P + 1) & 1) ? wa : wb;
             if (P + 1 <= CH) load_plane(zbase + (P + 1) * K, nxt, P + 1 <= nout);   // in flight while P is evaluated
+            if (P + 1 < CH) {                                      // plane P is the first candidate plane of output P + 1
+#pragma unroll
+                for (int a = 0; a < RY; ++a) { best[a][P + 1] = ID::none(); bestd[a][P + 1] = INFINITY; }
+            }
             scatter(P, cur);
 #pragma unroll
             for (int a = 0; a < RY; ++a) {
@@ -635,6 +665,9 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                 for (int o = P; o <= P + 1; ++o)
                     if (o >= 0 && o < CH) { pin(bestd[a][o]); pin(best[a][o]); }
             }
+#ifdef VP_EXP_FENCE
+            asm volatile("" ::: "memory");
+#endif
         }
     }
 }
@@ -752,16 +785,18 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     hipLaunchKernelGGL((jfa_pass_zstream<ID, TAB, RY, CH, S, C, F>),                                                                 \
                        dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(256), 0, ctx->stream, f, k,         \
                        (const T*)d_in, (const T*)d_minus, (const T*)d_plus, (T*)d_out, none_row, d_words, fill, d_sdf)
-#define VP_LAUNCH_TILE(TAB, RY, CH)                                                                                                  \
+#define VP_LAUNCH_TILE(TAB, RY, CH, CHD)                                                                                             \
     do {                                                                                                                             \
         const bool chk = (int)f.n >= TAB;                                                                                            \
+        const bool deep = zlen % CHD == 0;                        /* dense passes: longer plane chains when they divide evenly */    \
         if (fin)       { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, false, true, true);  else VP_LAUNCH_CHAIN(TAB, RY, CH, false, false, true); }  \
         else if (skip) { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, true, true, false);  else VP_LAUNCH_CHAIN(TAB, RY, CH, true, false, false); }  \
+        else if (deep) { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CHD, false, true, false); else VP_LAUNCH_CHAIN(TAB, RY, CHD, false, false, false); } \
         else           { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, false, true, false); else VP_LAUNCH_CHAIN(TAB, RY, CH, false, false, false); } \
     } while (0)
-    if constexpr (std::is_same<ID, Id64>::value) VP_LAUNCH_TILE(Id64::kTab, kRowsWide, kPlanesWide);
-    else if (f.n <= 512) VP_LAUNCH_TILE(512, kRows, kPlanes);   // 2-KB tables
-    else VP_LAUNCH_TILE(Id32::kTab, kRows, kPlanes);
+    if constexpr (std::is_same<ID, Id64>::value) VP_LAUNCH_TILE(Id64::kTab, kRowsWide, kPlanesWide, kPlanesWide);
+    else if (f.n <= 512) VP_LAUNCH_TILE(512, kRows, kPlanes, kPlanesDense);   // 2-KB tables
+    else VP_LAUNCH_TILE(Id32::kTab, kRows, kPlanes, kPlanes);   // 4-KB tables: 4x8 costs occupancy (4.93 vs 4.70 ms at n = 1024)
 #undef VP_LAUNCH_TILE
 #undef VP_LAUNCH_CHAIN
     return 0;
