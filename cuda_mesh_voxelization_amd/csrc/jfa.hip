@@ -378,8 +378,8 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 // rows y_a = y0 + a*k, planes z_j = z0 + j*k.  Output (y_a, z_j) takes its candidates from rows y_a - k, y_a,
 // y_a + k of planes z_j - k, z_j, z_j + k, i.e. from the tile's own rows / planes and one halo row / plane on each
 // side.  Every source plane of the tile is therefore read ONCE -- (RY+2) rows x columns {x-k, x, x+k} per thread --
-// and serves up to 3 output rows x 3 output planes: 3(RY+2)(CH+2)/(RY*CH) = 6.75 loads per voxel for the 4x4 tile
-// instead of 27, and each row segment comes from L2 2.25 times instead of 9.
+// and serves up to 3 output rows x 3 output planes: 3(RY+2)(CH+2)/(RY*CH) = 6.75 (4x4) or 5.6 (4x8) loads per voxel
+// instead of 27, and each row segment comes from L2 1.9 - 2.25 times instead of 9.
 // The kernel is input-stationary: every id is decoded once and scattered into the running (best id, distance)
 // pairs of the outputs it is a candidate for.  Planes arrive in increasing z, rows in increasing y and columns in
 // increasing x, so each output still sees its 27 candidates in the reference's scan order (sequential.cpp:86-88).
@@ -390,9 +390,9 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 // ((dx^2 + dy^2) + dz^2) (jfa/jfa.h:19-20).
 //     per candidate-step   1 add + compare + 2 selects; the dz^2 lookup is shared by the output rows
 //     per loaded id        x, y, z decode (5 VALU) + x lookup + sub, mul
-//     registers            (RY+2)*3 ids of the plane in flight + as many prefetched + RY*3 running pairs: 80 VGPRs
-// What limits it (MI355X counters, profiles/): the vector-memory pipe -- TCP busy 97 %, TD busy 95 %, 62 % of that
-// stalled on L2 returns -- while VALU and LDS sit at 60-70 %; removing all LDS lookups or 15 % of the VALU
+//     registers            (RY+2)*3 ids of the plane in flight + as many prefetched + RY*3 running pairs: 72-76 VGPRs
+// What limits it (MI355X counters, profiles/): the vector-memory pipe -- TCP busy 96 %, TD busy 85 %, 64 % of the
+// time stalled on L2 returns -- while VALU and LDS sit at 60-70 %; removing all LDS lookups or 15 % of the VALU
 // instructions changed nothing, fewer loads and fewer L2 requests per voxel (bigger tiles) did:
 // 1x4 0.68 ms, 2x4 0.57, 3x4 0.56, 2x8 0.54, 4x4 0.52, 4x8 0.50 per dense pass at n = 512 (the sparse and the fused
 // last pass are fastest with 4x4: 0.35 / 0.55 ms); n = 1024: 2x4 4.8 ms, 4x4 4.65, 4x8 4.93.
@@ -416,9 +416,9 @@ constexpr int kRows = 4, kPlanes = 4;
 constexpr int kPlanesDense = 8;      // dense passes with 2-KB tables (n <= 512): 4x8 tiles, 5.6 loads per voxel
 constexpr int kRowsWide = 2, kPlanesWide = 2;     // n = 2048: 2x2 727 ms per JFA, 2x4 726, 1x4 796, 4x2 1143
 
-// Row loads go through a buffer resource (base in SGPRs + one 32-bit VGPR byte offset that is the same for every
-// row of the thread), which costs no VALU address arithmetic; plain pointer loads from a selected base compiled
-// to a 64-bit VALU add per load.
+// Row loads and stores go through a buffer resource (base in SGPRs + one 32-bit VGPR byte offset that is the same
+// for every row of the thread), which costs no VALU address arithmetic; plain pointer accesses from a selected base
+// compiled to a 64-bit VALU add each.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_resource(const void* row, uint32_t bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(row), 0, (int)bytes, 0x00020000);
@@ -449,7 +449,7 @@ __device__ __forceinline__ void row_store(uint2 v, __amdgpu_buffer_rsrc_t r, uin
 }
 // A wave-uniform value made opaque to the optimiser where it is used: the 128-bit row descriptors derived from it are
 // then built right before their loads / stores (a few SALU instructions) instead of being hoisted out of the x loop,
-// where the ~50 descriptors of a tile do not fit the SGPR file and were spilled to VGPR lanes (v_writelane/v_readlane).
+// where the ~80 descriptors of a tile do not fit the SGPR file and were spilled to VGPR lanes (v_writelane/v_readlane).
 __device__ __forceinline__ const char* opaque_uniform(const char* p)
 {
     uint64_t v = reinterpret_cast<uint64_t>(p);
