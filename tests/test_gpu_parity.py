@@ -151,6 +151,34 @@ def test_jfa_random_and_edge_grids(engine):
     _assert_sdf_equal(got, exp)
 
 
+def test_jfa_tile_kernel_edge_grids(engine):
+    """The same edge cases at n = 256, where the tiled path is jfa_first_pass + jfa_pass_zstream (sparse, dense and
+    fused last variants): empty grid (everything stays +-inf), full grid (only the hull is border), one voxel,
+    1 % random voxels, dense noise -- against the oracle, both fill signs."""
+    n = 256
+    rng = np.random.default_rng(11)
+    origin = np.array([0.5, -3.0, 7.25], np.float32)
+    fr = Frame.make(n, 0.0625, tuple(float(v) for v in origin))
+    nw = O.nwords(n)
+    one = np.zeros(nw, np.uint32); one[(200 * n * n + 3 * n + 255) // 32] = 1 << ((200 * n * n + 3 * n + 255) % 32)
+    cases = {
+        "empty": np.zeros(nw, np.uint32),
+        "full": np.full(nw, 0xFFFFFFFF, np.uint32),
+        "single": one,
+        "sparse": (rng.random(nw) < 0.01).astype(np.uint32) << rng.integers(0, 32, nw).astype(np.uint32),
+        "noise": rng.integers(0, 2**32, nw, dtype=np.uint32),
+    }
+    for name, words in cases.items():
+        dw = engine.to_device(words, np.uint32)
+        exp = O.jfa(words, n, 0.0625, origin)
+        got = engine.jfa(fr, dw, algo=ALGO_TILED).cpu().numpy()
+        _assert_sdf_equal(got, exp)
+        if name in ("single", "sparse"):
+            exp_p = O.jfa(words, n, 0.0625, origin, fill=np.inf)
+            got_p = engine.jfa(fr, dw, fill=math.inf, algo=ALGO_TILED).cpu().numpy()
+            _assert_sdf_equal(got_p, exp_p)
+
+
 def test_jfa_rejects_finite_fill(engine):
     fr = Frame.make(32, 1.0, (0, 0, 0))
     dw = torch.zeros(fr.words, dtype=torch.int32, device=engine.device)
