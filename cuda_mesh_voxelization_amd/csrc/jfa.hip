@@ -602,7 +602,8 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                 auto body = [&]() {
                     const float sx = lds_f32(tx + (ID::xoff(id) & kField));
                     const float dxv = sx - px;
-                    const float dx2 = dxv * dxv;
+                    // FINAL keeps distances only: "none" is given an infinite distance here, once per id
+                    const float dx2 = (FINAL && CHECK_NONE && ID::is_none(id)) ? INFINITY : dxv * dxv;
                     const uint32_t yo = ID::yoff(id) & kField, zo = ID::zoff(id) & kField;
                     const bool real = CHECK_NONE ? !ID::is_none(id) : true;
 #pragma unroll
@@ -615,6 +616,14 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                             if (o < 0 || o >= CH) continue;
                             const float d = pre + lds_f32(tz + o * (kTab * 4) + zo);
                             // strict '<' of sequential.cpp:106; the voxel's own state wins ties (see header)
+                            if (FINAL) {
+                                // the last pass only needs the winning distance: a plain minimum (no NaNs can occur), 1 VALU
+                                // instead of compare + 2 selects; which candidate wins a tie no longer matters
+                                float nb;
+                                asm("v_min_f32 %0, %1, %2" : "=v"(nb) : "v"(bestd[a][o]), "v"(d));
+                                bestd[a][o] = nb;
+                                continue;
+                            }
                             bool take = (ownRow && o == P) ? (d <= bestd[a][o]) : (d < bestd[a][o]);
                             if (CHECK_NONE) take = take & real;
                             bestd[a][o] = take ? d : bestd[a][o];
