@@ -394,8 +394,8 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 // What limits it (MI355X counters, profiles/): the vector-memory pipe -- TCP busy 96 %, TD busy 85 %, 64 % of the
 // time stalled on L2 returns -- while VALU and LDS sit at 60-70 %; removing all LDS lookups or 15 % of the VALU
 // instructions changed nothing, fewer loads and fewer L2 requests per voxel (bigger tiles) did:
-// 1x4 0.68 ms, 2x4 0.57, 3x4 0.56, 2x8 0.54, 4x4 0.52, 4x8 0.50 per dense pass at n = 512 (the sparse and the fused
-// last pass are fastest with 4x4: 0.35 / 0.55 ms); n = 1024: 2x4 4.8 ms, 4x4 4.65, 4x8 4.93.
+// 1x4 0.68 ms, 2x4 0.57, 3x4 0.56, 2x8 0.54, 4x4 0.52, 4x8 0.50 per dense pass at n = 512 (the sparse pass is
+// fastest with 4x4: 0.35 ms; the fused last pass: 4x4 0.43, 4x8 0.41); n = 1024: 2x4 4.8 ms, 4x4 4.65, 4x8 4.93.
 //   TAB           table entries.  512 for n <= 512 (2-KB tables: 18 KB of LDS per workgroup), else the id format's
 //                 field range; fields are masked to it.
 //   SKIP = true   (early passes, k >= n/4: sparse state, many rows outside the grid) rows / planes outside
@@ -798,8 +798,9 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 #define VP_LAUNCH_TILE(TAB, RY, CH, CHD)                                                                                             \
     do {                                                                                                                             \
         const bool chk = (int)f.n >= TAB;                                                                                            \
-        const bool deep = zlen % CHD == 0;                        /* dense passes: longer plane chains when they divide evenly */    \
-        if (fin)       { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, false, true, true);  else VP_LAUNCH_CHAIN(TAB, RY, CH, false, false, true); }  \
+        const bool deep = zlen % CHD == 0;                        /* dense / last pass: longer plane chains when they divide evenly */ \
+        if (fin && deep) { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CHD, false, true, true);  else VP_LAUNCH_CHAIN(TAB, RY, CHD, false, false, true); }  \
+        else if (fin)  { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, false, true, true);  else VP_LAUNCH_CHAIN(TAB, RY, CH, false, false, true); }  \
         else if (skip) { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, true, true, false);  else VP_LAUNCH_CHAIN(TAB, RY, CH, true, false, false); }  \
         else if (deep) { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CHD, false, true, false); else VP_LAUNCH_CHAIN(TAB, RY, CHD, false, false, false); } \
         else           { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, false, true, false); else VP_LAUNCH_CHAIN(TAB, RY, CH, false, false, false); } \
