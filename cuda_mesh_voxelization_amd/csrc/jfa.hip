@@ -603,9 +603,13 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                     const float sx = lds_f32(tx + (ID::xoff(id) & kField));
                     const float dxv = sx - px;
                     // FINAL keeps distances only: "none" is given an infinite distance here, once per id
-                    const float dx2 = (FINAL && CHECK_NONE && ID::is_none(id)) ? INFINITY : dxv * dxv;
+                    // n == table size has no spare +inf table slot for "none": the dense variants give it an infinite distance
+                    // here, once per id (it then loses every '<'; as the own voxel it can only replace another "none"); the
+                    // sparse variant, where most ids are "none", is faster with the flag (0.355 vs 0.377 ms)
+                    constexpr bool kInfNone = CHECK_NONE && !SKIP;
+                    const float dx2 = (kInfNone && ID::is_none(id)) ? INFINITY : dxv * dxv;
                     const uint32_t yo = ID::yoff(id) & kField, zo = ID::zoff(id) & kField;
-                    const bool real = CHECK_NONE ? !ID::is_none(id) : true;
+                    const bool real = (CHECK_NONE && !kInfNone) ? !ID::is_none(id) : true;
 #pragma unroll
                     for (int a = rr - 2; a <= rr; ++a) {           // output rows this source row is a candidate for
                         if (a < 0 || a >= RY) continue;
@@ -625,7 +629,7 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                                 continue;
                             }
                             bool take = (ownRow && o == P) ? (d <= bestd[a][o]) : (d < bestd[a][o]);
-                            if (CHECK_NONE) take = take & real;
+                            if (CHECK_NONE && SKIP) take = take & real;
                             bestd[a][o] = take ? d : bestd[a][o];
                             best[a][o] = ID::sel(take, id, best[a][o]);
                         }
