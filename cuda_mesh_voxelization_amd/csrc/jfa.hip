@@ -412,7 +412,9 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 // (2.25 global loads per voxel, but +18 LDS operations per thread and plane and two barriers: 0.60 ms vs 0.52);
 // computing the seed x from the id instead of looking it up (more VALU: 0.59); skipping the selects of a candidate
 // that no lane takes (branches: 0.86); v_pk_*_f32 on pairs of ids (half rate on this part: no change); v_min_f32 for
-// the distance update (0.59 vs 0.51) and an all-integer compare/select (sub, ashr, bfi, min on the bit patterns: 0.68).
+// the distance update (0.59 vs 0.51), an all-integer compare/select (sub, ashr, bfi, min on the bit patterns: 0.68) and
+// v_cmpx + two v_mov under the narrowed EXEC (faster in a microbenchmark, 0.65 vs 0.50 in the kernel: the EXEC restore
+// is a SALU -> VALU dependency per candidate).
 constexpr int kRows = 4, kPlanes = 4;
 constexpr int kPlanesDense = 8;      // dense passes with 2-KB tables (n <= 512): 4x8 tiles, 5.6 loads per voxel
 constexpr int kRowsWide = 2, kPlanesWide = 2;     // n = 2048: 2x2 727 ms per JFA, 2x4 726, 1x4 796, 4x2 1143
