@@ -412,9 +412,7 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 // (2.25 global loads per voxel, but +18 LDS operations per thread and plane and two barriers: 0.60 ms vs 0.52);
 // computing the seed x from the id instead of looking it up (more VALU: 0.59); skipping the selects of a candidate
 // that no lane takes (branches: 0.86); v_pk_*_f32 on pairs of ids (half rate on this part: no change); v_min_f32 for
-// the distance update (0.59 vs 0.51), an all-integer compare/select (sub, ashr, bfi, min on the bit patterns: 0.68) and
-// v_cmpx + two v_mov under the narrowed EXEC (faster in a microbenchmark, 0.65 vs 0.50 in the kernel: the EXEC restore
-// is a SALU -> VALU dependency per candidate).
+// the distance update (0.59 vs 0.51) and an all-integer compare/select (sub, ashr, bfi, min on the bit patterns: 0.68).
 constexpr int kRows = 4, kPlanes = 4;
 constexpr int kPlanesDense = 8;      // dense passes with 2-KB tables (n <= 512): 4x8 tiles, 5.6 loads per voxel
 constexpr int kRowsWide = 2, kPlanesWide = 2;     // n = 2048: 2x2 727 ms per JFA, 2x4 726, 1x4 796, 4x2 1143
@@ -463,6 +461,37 @@ __device__ __forceinline__ size_t opaque_uniform(size_t v)
 {
     asm volatile("" : "+s"(v));
     return v;
+}
+// Candidate update "if (d < bestd) { bestd = d; best = id; }" as v_cmpx + plain moves under the narrowed EXEC mask,
+// EXEC restored afterwards: about 9 clocks per wave on this part against 16 for v_cmp + two v_cndmask
+// (tools/ubench/valu_rate.hip); the 27 candidate updates are 70 % of the dense kernel's VALU work (dense pass 0.50 ->
+// 0.47 ms).  `ex` is the wave's EXEC mask on entry (wave_exec()); it has to be ONE SGPR pair -- a ballot at each use is
+// rematerialised into fresh SGPRs and spills.  OWN = the voxel's own state: '<=' (it wins ties).
+__device__ __forceinline__ uint64_t wave_exec()
+{
+    uint64_t ex;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(ex));              // volatile: one copy, never rematerialised per use
+    return ex;
+}
+template <bool OWN>
+__device__ __forceinline__ void take_if_closer(float& bestd, uint32_t& best, float d, uint32_t id, uint64_t ex)
+{
+    if (OWN)
+        asm("v_cmpx_le_f32 exec, %2, %0\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\ts_mov_b64 exec, %4"
+            : "+v"(bestd), "+v"(best) : "v"(d), "v"(id), "s"(ex));
+    else
+        asm("v_cmpx_lt_f32 exec, %2, %0\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\ts_mov_b64 exec, %4"
+            : "+v"(bestd), "+v"(best) : "v"(d), "v"(id), "s"(ex));
+}
+template <bool OWN>
+__device__ __forceinline__ void take_if_closer(float& bestd, uint2& best, float d, uint2 id, uint64_t ex)
+{
+    if (OWN)
+        asm("v_cmpx_le_f32 exec, %3, %0\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5\n\ts_mov_b64 exec, %6"
+            : "+v"(bestd), "+v"(best.x), "+v"(best.y) : "v"(d), "v"(id.x), "v"(id.y), "s"(ex));
+    else
+        asm("v_cmpx_lt_f32 exec, %3, %0\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5\n\ts_mov_b64 exec, %6"
+            : "+v"(bestd), "+v"(best.x), "+v"(best.y) : "v"(d), "v"(id.x), "v"(id.y), "s"(ex));
 }
 // An empty asm that "modifies" a running value: everything feeding it has to be computed here.  Without it the
 // compiler sinks the compare/select chains of a whole chain towards the stores and keeps every distance live
@@ -569,6 +598,7 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
 
     for (uint32_t x = tid; x < (uint32_t)N; x += 256) {
         const float px = PX[x];
+        const uint64_t ex = wave_exec();                           // EXEC of this iteration (the last one may be partial)
         const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
         // A column outside the grid reads the centre column instead: the same id as the neighbouring candidate in
         // scan order, which cannot change the winner, so no validity mask is needed.
@@ -628,6 +658,11 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                                 float nb;
                                 asm("v_min_f32 %0, %1, %2" : "=v"(nb) : "v"(bestd[a][o]), "v"(d));
                                 bestd[a][o] = nb;
+                                continue;
+                            }
+                            if (!SKIP) {                           // dense variants: v_cmpx update (-7 %)
+                                if (ownRow && o == P) take_if_closer<true>(bestd[a][o], best[a][o], d, id, ex);
+                                else take_if_closer<false>(bestd[a][o], best[a][o], d, id, ex);
                                 continue;
                             }
                             bool take = (ownRow && o == P) ? (d <= bestd[a][o]) : (d < bestd[a][o]);
