@@ -500,7 +500,7 @@ __device__ __forceinline__ void pin(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(uint32_t& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(uint2& a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
 
-template <class ID, int TAB, int RY, int CH, bool SKIP, bool CHECK_NONE, bool FINAL>
+template <class ID, int TAB, int PXT, int RY, int CH, bool SKIP, bool CHECK_NONE, bool FINAL>
 __global__ void __launch_bounds__(256)
 jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, const typename ID::T* __restrict__ minus,
                  const typename ID::T* __restrict__ plus, typename ID::T* __restrict__ out,
@@ -509,9 +509,11 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
     using T = typename ID::T;
     constexpr int kTab = TAB;                                      // table entries; fields are masked to it
     constexpr uint32_t kField = (uint32_t)(TAB - 1) * 4u;
+    constexpr uint32_t kFieldX = (uint32_t)(PXT - 1) * 4u;          // PXT = 2*TAB: slot PXT-1 (the x field of "none") holds +inf
+    static_assert(PXT == TAB || !CHECK_NONE, "a wide x table replaces the none check");
     constexpr int NR = RY + 2;                                     // source rows of a plane: ybase - k .. ybase + RY*k
     constexpr int NI = NR * 3;                                     // ids per thread and plane
-    __shared__ float PX[kTab];
+    __shared__ float PX[PXT];
     __shared__ float TY[RY][kTab];
     __shared__ float TZ[CH][kTab];
     // FINAL: the bitmask words of the tile's output rows, fetched with one coalesced load while the tables are built
@@ -565,7 +567,8 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                 WM[o * (TAB / 32) + i % f.w] = (oy < N && oz < (int)f.z1) ? words[((size_t)(oz - (int)f.z0) * N + oy) * f.w + i % f.w] : 0u;
             }
         }
-        if (!CHECK_NONE && tid == 0) {
+        if (PXT > TAB && tid == 0) PX[PXT - 1] = INFINITY;       // n == TAB: "none" gets dx = inf through its x field
+        if (!CHECK_NONE && PXT == TAB && tid == 0) {
             PX[kTab - 1] = 0.0f;
 #pragma unroll
             for (int j = 0; j < RY; ++j) TY[j][kTab - 1] = 0.0f;
@@ -632,7 +635,7 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                 const int rr = q / 3, c = q % 3;
                 const T id = w[q];
                 auto body = [&]() {
-                    const float sx = lds_f32(tx + (ID::xoff(id) & kField));
+                    const float sx = lds_f32(tx + (ID::xoff(id) & kFieldX));
                     const float dxv = sx - px;
                     // FINAL keeps distances only: "none" is given an infinite distance here, once per id
                     // n == table size has no spare +inf table slot for "none": the dense variants give it an infinite distance
@@ -832,23 +835,27 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
     // Tile = RY rows x CH planes per workgroup and the table size; "none" needs an explicit check when the tables have no
     // spare slot for it (n == table size).
-#define VP_LAUNCH_CHAIN(TAB, RY, CH, S, C, F)                                                                                        \
-    hipLaunchKernelGGL((jfa_pass_zstream<ID, TAB, RY, CH, S, C, F>),                                                                 \
+#define VP_LAUNCH_CHAIN(TAB, PXT, RY, CH, S, C, F)                                                                                   \
+    hipLaunchKernelGGL((jfa_pass_zstream<ID, TAB, PXT, RY, CH, S, C, F>),                                                            \
                        dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(256), 0, ctx->stream, f, k,         \
                        (const T*)d_in, (const T*)d_minus, (const T*)d_plus, (T*)d_out, none_row, d_words, fill, d_sdf)
-#define VP_LAUNCH_TILE(TAB, RY, CH, CHD)                                                                                             \
+    // chk: n == table size, "none" has no spare table slot.  WIDEX: the dense variants then use an x table of twice the
+    // size whose last slot (the x field of "none") holds +inf, instead of testing every id.
+#define VP_LAUNCH_TILE(TAB, WIDEX, RY, CH, CHD)                                                                                      \
     do {                                                                                                                             \
         const bool chk = (int)f.n >= TAB;                                                                                            \
         const bool deep = zlen % CHD == 0;                        /* dense / last pass: longer plane chains when they divide evenly */ \
-        if (fin && deep) { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CHD, false, true, true);  else VP_LAUNCH_CHAIN(TAB, RY, CHD, false, false, true); }  \
-        else if (fin)  { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, false, true, true);  else VP_LAUNCH_CHAIN(TAB, RY, CH, false, false, true); }  \
-        else if (skip) { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, true, true, false);  else VP_LAUNCH_CHAIN(TAB, RY, CH, true, false, false); }  \
-        else if (deep) { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CHD, false, true, false); else VP_LAUNCH_CHAIN(TAB, RY, CHD, false, false, false); } \
-        else           { if (chk) VP_LAUNCH_CHAIN(TAB, RY, CH, false, true, false); else VP_LAUNCH_CHAIN(TAB, RY, CH, false, false, false); } \
+        constexpr int PXW = WIDEX ? 2 * TAB : TAB;                                                                                   \
+        constexpr bool CW = !WIDEX;                               /* none check of the dense variants when n == TAB */                \
+        if (skip)      { if (chk) VP_LAUNCH_CHAIN(TAB, TAB, RY, CH, true, true, false);  else VP_LAUNCH_CHAIN(TAB, TAB, RY, CH, true, false, false); }  \
+        else if (fin && deep) { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, CW, true);  else VP_LAUNCH_CHAIN(TAB, TAB, RY, CHD, false, false, true); }  \
+        else if (fin)  { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, CW, true);   else VP_LAUNCH_CHAIN(TAB, TAB, RY, CH, false, false, true); }  \
+        else if (deep) { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, CW, false); else VP_LAUNCH_CHAIN(TAB, TAB, RY, CHD, false, false, false); } \
+        else           { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, CW, false);  else VP_LAUNCH_CHAIN(TAB, TAB, RY, CH, false, false, false); } \
     } while (0)
-    if constexpr (std::is_same<ID, Id64>::value) VP_LAUNCH_TILE(Id64::kTab, kRowsWide, kPlanesWide, kPlanesWide);
-    else if (f.n <= 512) VP_LAUNCH_TILE(512, kRows, kPlanes, kPlanesDense);   // 2-KB tables
-    else VP_LAUNCH_TILE(Id32::kTab, kRows, kPlanes, kPlanes);   // 4-KB tables: 4x8 costs occupancy (4.93 vs 4.70 ms at n = 1024)
+    if constexpr (std::is_same<ID, Id64>::value) VP_LAUNCH_TILE(Id64::kTab, false, kRowsWide, kPlanesWide, kPlanesWide);
+    else if (f.n <= 512) VP_LAUNCH_TILE(512, true, kRows, kPlanes, kPlanesDense);   // 2-KB tables (x: 4 KB at n = 512, -1.5 %)
+    else VP_LAUNCH_TILE(Id32::kTab, false, kRows, kPlanes, kPlanes);   // 4-KB tables: 4x8 costs occupancy (4.93 vs 4.70 ms at n = 1024)
 #undef VP_LAUNCH_TILE
 #undef VP_LAUNCH_CHAIN
     return 0;
