@@ -407,7 +407,8 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 //                 dz^2 entry holds +inf, so a "none" candidate yields d = inf and loses without a compare.
 //   FINAL = true  last pass (k = 1) fused with the id -> sdf conversion of jfa_final: the winning
 //                 distance is already in a register, so the pass writes floats instead of ids.
-// The wide-id format has 8-KB tables and takes a smaller tile to keep four workgroups per CU.
+// The wide-id format (8-KB tables) keeps seed POSITIONS in two tables instead of squared differences per output row /
+// plane (see POS below): its LDS footprint does not grow with the tile and it runs 4x8 tiles too (n = 2048: 727 -> 472 ms).
 // Tried and measured slower: taking columns x-k / x+k from an LDS row buffer filled by one coalesced load per row
 // (2.25 global loads per voxel, but +18 LDS operations per thread and plane and two barriers: 0.60 ms vs 0.52);
 // computing the seed x from the id instead of looking it up (more VALU: 0.59); skipping the selects of a candidate
@@ -415,7 +416,7 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 // the distance update (0.59 vs 0.51) and an all-integer compare/select (sub, ashr, bfi, min on the bit patterns: 0.68).
 constexpr int kRows = 4, kPlanes = 4;
 constexpr int kPlanesDense = 8;      // dense passes with 2-KB tables (n <= 512): 4x8 tiles, 5.6 loads per voxel
-constexpr int kRowsWide = 2, kPlanesWide = 2;     // n = 2048: 2x2 727 ms per JFA, 2x4 726, 1x4 796, 4x2 1143
+constexpr int kRowsWide = 4, kPlanesWide = 8, kPlanesWideDense = 8;   // n = 2048 with position tables: 2x2 721 ms per JFA, 2x4 584, 2x8 540, 4x4 512, 4x8 472     // n = 2048: 2x2 727 ms per JFA, 2x4 726, 1x4 796, 4x2 1143
 
 // Row loads and stores go through a buffer resource (base in SGPRs + one 32-bit VGPR byte offset that is the same
 // for every row of the thread), which costs no VALU address arithmetic; plain pointer accesses from a selected base
@@ -514,8 +515,11 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
     constexpr int NR = RY + 2;                                     // source rows of a plane: ybase - k .. ybase + RY*k
     constexpr int NI = NR * 3;                                     // ids per thread and plane
     __shared__ float PX[PXT];
-    __shared__ float TY[RY][kTab];
-    __shared__ float TZ[CH][kTab];
+    // POS (wide ids, 8-KB tables): TY[0] / TZ[0] hold the seed POSITIONS along y / z (scrambled index) and the squares
+    // are formed per use (+2 VALU), which makes the LDS footprint independent of the tile: 24 KB instead of 8(1+RY+CH).
+    constexpr bool POS = std::is_same<ID, Id64>::value;            // (no gain for the 4-KB tables of n = 1024: 36.4 vs 36.2 ms)
+    __shared__ float TY[POS ? 1 : RY][kTab];
+    __shared__ float TZ[POS ? 1 : CH][kTab];
     // FINAL: the bitmask words of the tile's output rows, fetched with one coalesced load while the tables are built
     // (a load at store time waits behind the prefetched ids of the next plane: +0.13 ms at n = 512)
     __shared__ uint32_t WM[FINAL ? RY * CH * (TAB / 32) : 1];
@@ -538,26 +542,31 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
     const int lbase = (int)(by % nres) + (int)(by / nres) * CH * K;
     if (ybase >= N || lbase >= nzl) return;
     const int zbase = lbase + (int)f.z0;                           // global plane of chain element 0
+    float py[RY], pz[CH];                                          // positions of the output rows / planes (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < RY; ++j) py[j] = axis_pos(f.oy, ybase + j * K, f.vs);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) pz[j] = axis_pos(f.oz, zbase + j * K, f.vs);
     {
-        float py[RY], pz[CH];
-#pragma unroll
-        for (int j = 0; j < RY; ++j) py[j] = axis_pos(f.oy, ybase + j * K, f.vs);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) pz[j] = axis_pos(f.oz, zbase + j * K, f.vs);
         for (uint32_t i = tid; i < (uint32_t)N; i += 256) {
             const uint32_t si = scr(i);
             PX[i] = axis_pos(f.ox, i, f.vs);
             const float sy = axis_pos(f.oy, i, f.vs);
-#pragma unroll
-            for (int j = 0; j < RY; ++j) {
-                const float dyv = sy - py[j];
-                TY[j][si] = dyv * dyv;
-            }
             const float sz = axis_pos(f.oz, i, f.vs);
+            if (POS) {
+                TY[0][si] = sy;
+                TZ[0][si] = sz;
+            } else {
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const float dzv = sz - pz[j];
-                TZ[j][si] = dzv * dzv;
+                for (int j = 0; j < RY; ++j) {
+                    const float dyv = sy - py[j];
+                    TY[POS ? 0 : j][si] = dyv * dyv;
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float dzv = sz - pz[j];
+                    TZ[POS ? 0 : j][si] = dzv * dzv;
+                }
             }
         }
         if (FINAL) {
@@ -571,9 +580,9 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
         if (!CHECK_NONE && PXT == TAB && tid == 0) {
             PX[kTab - 1] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < RY; ++j) TY[j][kTab - 1] = 0.0f;
+            for (int j = 0; j < (POS ? 1 : RY); ++j) TY[j][kTab - 1] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < CH; ++j) TZ[j][kTab - 1] = INFINITY;
+            for (int j = 0; j < (POS ? 1 : CH); ++j) TZ[j][kTab - 1] = INFINITY;   // POS: an infinite position gives dz^2 = inf as well
         }
     }
     __syncthreads();
@@ -645,15 +654,27 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                     const float dx2 = (kInfNone && ID::is_none(id)) ? INFINITY : dxv * dxv;
                     const uint32_t yo = ID::yoff(id) & kField, zo = ID::zoff(id) & kField;
                     const bool real = (CHECK_NONE && !kInfNone) ? !ID::is_none(id) : true;
+                    const float sy = POS ? lds_f32(ty + yo) : 0.0f, sz = POS ? lds_f32(tz + zo) : 0.0f;
+                    float dz2v[3];                                 // dz^2 to output planes P-1, P, P+1: shared by the output rows
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int o = P - 1 + t;
+                        if (o < 0 || o >= CH) continue;
+                        if (POS) { const float dzv = sz - pz[o]; dz2v[t] = dzv * dzv; }
+                        else dz2v[t] = lds_f32(tz + o * (kTab * 4) + zo);
+                    }
 #pragma unroll
                     for (int a = rr - 2; a <= rr; ++a) {           // output rows this source row is a candidate for
                         if (a < 0 || a >= RY) continue;
-                        const float pre = dx2 + lds_f32(ty + a * (kTab * 4) + yo);
+                        float dy2;
+                        if (POS) { const float dyv = sy - py[a]; dy2 = dyv * dyv; }
+                        else dy2 = lds_f32(ty + a * (kTab * 4) + yo);
+                        const float pre = dx2 + dy2;
                         const bool ownRow = (rr == a + 1) && (c == 1);
 #pragma unroll
                         for (int o = P - 1; o <= P + 1; ++o) {
                             if (o < 0 || o >= CH) continue;
-                            const float d = pre + lds_f32(tz + o * (kTab * 4) + zo);
+                            const float d = pre + dz2v[o - (P - 1)];
                             // strict '<' of sequential.cpp:106; the voxel's own state wins ties (see header)
                             if (FINAL) {
                                 // the last pass only needs the winning distance: a plain minimum (no NaNs can occur), 1 VALU
@@ -853,7 +874,7 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
         else if (deep) { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, CW, false); else VP_LAUNCH_CHAIN(TAB, TAB, RY, CHD, false, false, false); } \
         else           { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, CW, false);  else VP_LAUNCH_CHAIN(TAB, TAB, RY, CH, false, false, false); } \
     } while (0)
-    if constexpr (std::is_same<ID, Id64>::value) VP_LAUNCH_TILE(Id64::kTab, false, kRowsWide, kPlanesWide, kPlanesWide);
+    if constexpr (std::is_same<ID, Id64>::value) VP_LAUNCH_TILE(Id64::kTab, false, kRowsWide, kPlanesWide, kPlanesWideDense);
     else if (f.n <= 512) VP_LAUNCH_TILE(512, true, kRows, kPlanes, kPlanesDense);   // 2-KB tables (x: 4 KB at n = 512, -1.5 %)
     else VP_LAUNCH_TILE(Id32::kTab, false, kRows, kPlanes, kPlanes);   // 4-KB tables: 4x8 costs occupancy (4.93 vs 4.70 ms at n = 1024)
 #undef VP_LAUNCH_TILE
