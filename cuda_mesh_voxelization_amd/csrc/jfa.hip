@@ -25,6 +25,8 @@
 //
 // Built with -ffp-contract=off (an FMA changes the result).
 #include "vp_internal.h"
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -40,19 +42,21 @@ namespace {
 __device__ __forceinline__ uint32_t scr(uint32_t i) { return i ^ ((i >> 5) & 31u); }
 
 // Id formats.  Every coordinate field is stored pre-multiplied by 4, i.e. it already is a byte offset into
-// a float table after one shift+mask.  z sits in the lowest field because its table is the one looked up once
-// per candidate AND chain step (a single AND); x and y are decoded once per id.  A real id has bits 0,1 of its
-// first word clear, "none" has them set.
-struct Id32 {                     // n <= 1024: bits [2..11] scr(z), [12..21] x, [22..31] scr(y)
+// a float table after one shift+mask.  In the 32-bit format x sits in the lowest field: its table (seed x
+// positions) has 4-byte entries, so a single AND is its byte offset, while the y / z tables of the dense kernel
+// have 16- / 32-byte entries (one entry = the squared differences to all output rows / planes of the tile, fetched
+// with one wide LDS read) and need a shift + mask anyway.  A real id has bits 0,1 of its first word clear,
+// "none" has them set.
+struct Id32 {                     // n <= 1024: bits [2..11] x, [12..21] scr(z), [22..31] scr(y)
     using T = uint32_t;
     static constexpr int kTab = 1024;             // table entries: any 10-bit field (also those of none) stays in bounds
     static constexpr uint32_t kMask = 0xFFCu;
     __device__ static __forceinline__ T none() { return 0xFFFFFFFFu; }
     __device__ static __forceinline__ bool is_none(T a) { return a == 0xFFFFFFFFu; }
-    __device__ static __forceinline__ T pack(uint32_t x, uint32_t y, uint32_t z) { return (scr(z) << 2) | (x << 12) | (scr(y) << 22); }
-    __device__ static __forceinline__ T add_x(T a, uint32_t dx) { return a + (dx << 12); }
-    __device__ static __forceinline__ uint32_t zoff(T a) { return a & kMask; }
-    __device__ static __forceinline__ uint32_t xoff(T a) { return (a >> 10) & kMask; }
+    __device__ static __forceinline__ T pack(uint32_t x, uint32_t y, uint32_t z) { return (x << 2) | (scr(z) << 12) | (scr(y) << 22); }
+    __device__ static __forceinline__ T add_x(T a, uint32_t dx) { return a + (dx << 2); }
+    __device__ static __forceinline__ uint32_t xoff(T a) { return a & kMask; }
+    __device__ static __forceinline__ uint32_t zoff(T a) { return (a >> 10) & kMask; }
     __device__ static __forceinline__ uint32_t yoff(T a) { return (a >> 20) & kMask; }
     __device__ static __forceinline__ T sel(bool c, T a, T b) { return c ? a : b; }
     __device__ static __forceinline__ T shfl(T a, int src) { return (T)__shfl((int)a, src); }
@@ -747,6 +751,331 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
     }
 }
 
+// ------------------------------------------------------------------------------------------ dense tile kernel
+// Dense passes (k < n/4) and the fused last pass for 32-bit ids: the tile / stream structure of jfa_pass_zstream with a
+// different candidate update and a different table layout.  What round 1's counters said about that kernel: it is bound
+// by VALU issue (170 lane-instructions per voxel, 27 x (add + v_cmpx + 2 moves) of them the candidate updates) with
+// the LDS pipe at 55 - 68 % behind it.
+//
+//  * Candidate update = ONE v_min_f64.  The running best of an output is the 64-bit pair (hi = bits of the distance,
+//    lo = rank of the candidate).  A non-negative float's bit pattern orders like an unsigned integer, and a bit
+//    pattern with hi <= 0x7F800000 is a finite, non-negative double whose order is that of the 64-bit pattern, so
+//    v_min_f64 on such pairs IS the lexicographic minimum of (distance, rank) -- verified bit for bit on the part,
+//    denormal range included (tools/ubench/probe.hip) -- at 4.3 clocks per wave against 9 for v_cmpx + 2 v_mov + the
+//    EXEC restore.  The rank makes the minimum the reference's "first minimum in scan order, own state first"
+//    (jfa/sequential.cpp:84-112): the own voxel has rank 0, every other candidate the byte offset of its SOURCE voxel in
+//    the id volume + 1, which increases along the scan order z, y, x.  v_add_f32 writes the distance straight into the
+//    high half of the candidate pair (the low half is set once per loaded id): a candidate-step is 2 VALU, 6.3 clocks,
+//    instead of 4 VALU + 1 SALU, 11.6 clocks.
+//    When an output is complete the seed id of its winner is fetched from where the winner was read: one gather load
+//    per voxel (an L2 hit: the tile has just streamed through those lines), issued a plane ahead of its store.
+//  * Tables with wide entries: TY[i] holds the squared y differences of seed coordinate i to ALL output rows of the tile
+//    (RY floats = one ds_read_b128), TZ[i] those to all output planes (CH floats; the three an id needs are one
+//    ds_read_b64 + one ds_read_b32).  A wide LDS read costs the same LDS cycles as a narrow one up to 8 bytes and half
+//    per byte at 16 (probe.hip: b32 2.2, b64 2.2, b128 4.2 clocks per CU), so an id's 7 lookups cost 8.6 - 10.8 LDS
+//    clocks instead of 15.4.
+//  * FINAL keeps distances only (v_min_f32) as before and shares the tables.
+// Requires the three id buffers of a slab to be contiguous in memory (one volume addressed by global plane): true for
+// whole grids and for the ghost-plane slabs; other callers take jfa_pass_zstream.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double min_f64(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));      // not fmin(): that canonicalises both operands first
+    return r;
+}
+__device__ __forceinline__ float min_f32(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void pin(double& a) { asm volatile("" : "+v"(a)); }
+
+// Table of W floats per seed coordinate, stored as W / E sub-tables of TAB entries of E floats (E = 1, 2 or 4): float j of
+// coordinate index i lives at base + (j / E) * TAB * 4E + i * 4E + (j % E) * 4; `off` = i * 4E.  Reads floats [lo, hi]
+// (compile-time constants once the plane and row loops are unrolled) with aligned b64 reads per pair (a lone float of a
+// pair table is still read as the pair: a b32 on 8-byte entries would use every other bank only) and one b128 where three
+// or four floats of an E = 4 entry are needed.  Fixed trip counts, so that everything folds after unrolling.
+template <int W, int E, int TAB>
+__device__ __forceinline__ void lds_span(const char* base, uint32_t off, int lo, int hi, float (&v)[W])
+{
+    static_assert(E == 1 || E == 2 || E == 4, "entry width");
+#pragma unroll
+    for (int g = 0; g < W / E; ++g) {
+        const char* p = base + g * (TAB * 4 * E) + off;
+        const int j0 = g * E;
+        if (E == 1) {
+            if (lo <= j0 && j0 <= hi) v[j0] = *reinterpret_cast<const float*>(p);
+            continue;
+        }
+        if (E == 4) {
+            int need = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) need += (lo <= j0 + e && j0 + e <= hi) ? 1 : 0;
+            if (need >= 3) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                f32x4 t = *reinterpret_cast<const f32x4*>(p);
+                asm volatile("" : "+v"(t));                         // all four live: a b128 (4 LDS clocks), not the b96 (8) it is narrowed to
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[j0 + e] = t[e];
+                continue;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < E / 2; ++h) {
+            const int o0 = j0 + 2 * h, o1 = o0 + 1;
+            const bool n0 = lo <= o0 && o0 <= hi, n1 = lo <= o1 && o1 <= hi;
+            if (n0 || n1) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 t = *reinterpret_cast<const f32x2*>(p + h * 8);
+                asm volatile("" : "+v"(t));
+                v[o0] = t[0]; v[o1] = t[1];
+            }
+        }
+    }
+}
+
+#ifndef VP_DENSE_WAVES
+#define VP_DENSE_WAVES 1
+#endif
+template <int TAB, int RY, int CH, int EY, int EZ, int NT, bool CHECK_NONE, bool FINAL>
+__global__ void __launch_bounds__(NT, VP_DENSE_WAVES)
+jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+               const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
+{
+    using ID = Id32;
+    using T = uint32_t;
+    constexpr int PXT = 1024;                                      // x table: every 10-bit field; slots >= n hold +inf (the x field of "none")
+    constexpr uint32_t kFieldX = (uint32_t)(PXT - 1) * 4u;
+    constexpr int YB = EY * 4, ZB = EZ * 4;                        // bytes per TY / TZ entry (EY / EZ floats: 1, 2 or 4)
+    static_assert(RY % EY == 0 && CH % EZ == 0, "sub-tables");
+    constexpr int YSH = 22 - (EY == 1 ? 2 : EY == 2 ? 3 : 4), ZSH = 12 - (EZ == 1 ? 2 : EZ == 2 ? 3 : 4);   // field position -> entry byte offset
+    constexpr uint32_t kFieldY = (uint32_t)(TAB - 1) * YB, kFieldZ = (uint32_t)(TAB - 1) * ZB;
+    constexpr int NR = RY + 2;
+    constexpr int NI = NR * 3;
+    using B = typename std::conditional<FINAL, float, double>::type;
+    __shared__ float PX[PXT];
+    __shared__ __attribute__((aligned(16))) float TY[RY / EY][TAB][EY];
+    __shared__ __attribute__((aligned(16))) float TZ[CH / EZ][TAB][EZ];
+    __shared__ uint32_t WM[FINAL ? RY * CH * (TAB / 32) : 1];
+
+    const int N = (int)f.n;
+    const int K = (int)k;
+    const int nzl = (int)(f.z1 - f.z0);
+    const uint32_t tid = threadIdx.x;
+    const int nresY = min(K, N);
+    const bool rev = ((31 - __builtin_clz(k)) & 1) != 0;          // alternate the traversal direction between passes
+    const uint32_t bx = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const uint32_t by = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+    const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
+    const int nres = min(K, nzl);
+    const int lbase = (int)(by % nres) + (int)(by / nres) * CH * K;
+    if (ybase >= N || lbase >= nzl) return;
+    const int zbase = lbase + (int)f.z0;
+    float py[RY], pz[CH];
+#pragma unroll
+    for (int j = 0; j < RY; ++j) py[j] = axis_pos(f.oy, ybase + j * K, f.vs);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) pz[j] = axis_pos(f.oz, zbase + j * K, f.vs);
+    for (uint32_t i = tid; i < (uint32_t)PXT; i += NT) PX[i] = i < (uint32_t)N ? axis_pos(f.ox, i, f.vs) : INFINITY;
+    for (uint32_t i = tid; i < (uint32_t)TAB; i += NT) {
+        if (i < (uint32_t)N) {
+            const uint32_t si = scr(i);
+            const float sy = axis_pos(f.oy, i, f.vs), sz = axis_pos(f.oz, i, f.vs);
+#pragma unroll
+            for (int j = 0; j < RY; ++j) { const float d = sy - py[j]; TY[j / EY][si][j % EY] = d * d; }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { const float d = sz - pz[j]; TZ[j / EZ][si][j % EZ] = d * d; }
+        } else {                                                   // slots no real id refers to ("none" does): finite, so inf + it = inf
+#pragma unroll
+            for (int j = 0; j < RY; ++j) TY[j / EY][i][j % EY] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) TZ[j / EZ][i][j % EZ] = 0.0f;
+        }
+    }
+    if (FINAL) {
+        for (uint32_t i = tid; i < (uint32_t)(RY * CH) * f.w; i += NT) {
+            const int o = (int)(i / f.w), a = o / CH, j = o % CH;
+            const int oy = ybase + a * K, oz = zbase + j * K;
+            WM[o * (TAB / 32) + i % f.w] = (oy < N && oz < (int)f.z1) ? words[((size_t)(oz - (int)f.z0) * N + oy) * f.w + i % f.w] : 0u;
+        }
+    }
+    __syncthreads();
+
+    const char* tx = reinterpret_cast<const char*>(PX);
+    const char* ty = reinterpret_cast<const char*>(TY);
+    const char* tz = reinterpret_cast<const char*>(TZ);
+    const uint32_t rowBytes = (uint32_t)N * 4u;
+    const size_t planeBytes = (size_t)N * rowBytes;
+    int yout = 1, nout = 1;
+#pragma unroll
+    for (int j = 1; j < RY; ++j) yout += (ybase + j * K < N) ? 1 : 0;
+#pragma unroll
+    for (int j = 1; j < CH; ++j) nout += (zbase + j * K < (int)f.z1) ? 1 : 0;
+    const uint32_t kb = k * 4u;
+    // Ranks and the gather are relative to the first source plane of the tile that lies in the grid (zlo below): at most
+    // the whole volume, 4 GiB at n = 1024, so byte offset + 1 <= 2^32 - 3 fits the low word.
+
+    const int zbase0 = zbase, lbase0 = lbase, ybase0 = ybase;
+    for (uint32_t x = tid; x < (uint32_t)N; x += NT) {
+        // The uniform bases are re-read through an empty asm in every x iteration: otherwise every address of the ~10
+        // planes of the tile is hoisted out of the x loop, does not fit the SGPR file and is spilled to VGPR lanes
+        // (v_readlane / v_writelane were 6 % of the VALU instructions of the loop).
+        const int zbase = (int)opaque_uniform((size_t)(uint32_t)zbase0), lbase = (int)opaque_uniform((size_t)(uint32_t)lbase0);
+        const int ybase = (int)opaque_uniform((size_t)(uint32_t)ybase0);
+        const int zlo = max(zbase - K, 0);
+        const char* gbase = reinterpret_cast<const char*>(in) + ((ptrdiff_t)zlo - (ptrdiff_t)f.z0) * (ptrdiff_t)planeBytes;
+        uint32_t ro[NR];
+        bool yv[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const int ny = ybase + (rr - 1) * K;
+            yv[rr] = ny >= 0 && ny < N && max(rr - 2, 0) < yout;
+            ro[rr] = (uint32_t)(yv[rr] ? ny : 0) * rowBytes;
+        }
+        const float px = PX[x];
+        const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
+        const uint32_t xo = x * 4u, xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;   // a column outside the grid reads the centre column
+
+        auto load_plane = [&](int zg, T (&w)[NI], bool needed) {
+            const bool zin = needed && zg >= 0 && zg < N;
+            const char* pl = opaque_uniform(reinterpret_cast<const char*>(in) + ((ptrdiff_t)(zin ? zg : (int)f.z0) - (ptrdiff_t)f.z0) * (ptrdiff_t)planeBytes);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const __amdgpu_buffer_rsrc_t b =
+                    row_resource((zin && yv[rr]) ? pl + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
+                row_load(w[rr * 3 + 0], b, xmo);
+                row_load(w[rr * 3 + 1], b, xo);
+                row_load(w[rr * 3 + 2], b, xpo);
+            }
+        };
+
+        B best[RY][CH];
+
+        auto scatter = [&](int P, const T (&w)[NI]) {
+            // rank of the ids of this plane: byte offset of the row inside the gather window + 1 (wave-uniform) + the column offset
+            const uint32_t prank = (uint32_t)((zbase + P * K - zlo) * (ptrdiff_t)planeBytes) + 1u;
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const int rr = q / 3, c = q % 3;
+                const T id = w[q];
+                const float sx = lds_f32(tx + (id & kFieldX));
+                const float dxv = sx - px;
+                const float dx2 = (CHECK_NONE && ID::is_none(id)) ? INFINITY : dxv * dxv;   // n == 1024: no spare x slot for "none"
+                const uint32_t yo = (id >> YSH) & kFieldY, zo = (id >> ZSH) & kFieldZ;
+                const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
+                float dy2[RY], dz2[CH];
+#if defined(VP_ABL_NOLDS)
+                for (int a = 0; a < RY; ++a) dy2[a] = __uint_as_float(yo + a);
+                for (int o = 0; o < CH; ++o) dz2[o] = __uint_as_float(zo + o);
+#else
+                lds_span<RY, EY, TAB>(ty, yo, alo, ahi, dy2);
+                lds_span<CH, EZ, TAB>(tz, zo, olo, ohi, dz2);
+#endif
+                u32x2 cand;
+                if (!FINAL) cand.x = prank + ro[rr] + (c == 0 ? xmo : c == 1 ? xo : xpo);
+#pragma unroll
+                for (int a = alo; a <= ahi; ++a) {
+                    const float pre = dx2 + dy2[a];
+                    const bool ownRow = (rr == a + 1) && (c == 1);
+#pragma unroll
+                    for (int o = olo; o <= ohi; ++o) {
+                        const float d = pre + dz2[o];
+                        if constexpr (FINAL) {
+                            best[a][o] = min_f32(best[a][o], d);
+                        } else {
+                            u32x2 cd = cand;
+                            if (ownRow && o == P) cd.x = 0u;           // the voxel's own state wins every tie (sequential.cpp:84,106)
+                            cd.y = __float_as_uint(d);
+#if defined(VP_ABL_NOMIN)
+                            { u32x2 t = __builtin_bit_cast(u32x2, best[a][o]); t.y = __float_as_uint(min_f32(__uint_as_float(t.y), d)); best[a][o] = __builtin_bit_cast(double, t); }
+#else
+                            best[a][o] = min_f64(best[a][o], __builtin_bit_cast(double, cd));
+#endif
+                        }
+                    }
+                }
+                if (c == 2) {
+#pragma unroll
+                    for (int a = alo; a <= ahi; ++a)
+#pragma unroll
+                        for (int o = olo; o <= ohi; ++o) pin(best[a][o]);
+                }
+            }
+        };
+
+        T wa[NI], wb[NI];
+        T pend[RY];                                                // gathered winners of the previous output plane, stored a plane later
+        load_plane(zbase - K, wa, true);
+#pragma clang loop unroll(full)
+        for (int P = -1; P <= CH; ++P) {
+            T (&cur)[NI] = ((P + 1) & 1) ? wb : wa;
+            T (&nxt)[NI] = ((P + 1) & 1) ? wa : wb;
+            if (P + 1 <= CH) load_plane(zbase + (P + 1) * K, nxt, P + 1 <= nout);
+            if (P + 1 < CH) {
+#pragma unroll
+                for (int a = 0; a < RY; ++a) {
+                    if constexpr (FINAL) best[a][P + 1] = INFINITY;
+                    else best[a][P + 1] = __builtin_bit_cast(double, (u32x2){0xFFFFFFFFu, 0x7F800000u});   // (+inf, last rank)
+                }
+            }
+            scatter(P, cur);
+            if constexpr (FINAL) {
+                if (P >= 1 && P - 1 < nout) {
+#pragma unroll
+                    for (int a = 0; a < RY; ++a) {
+                        if (a >= yout) continue;
+                        const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (P - 1) * K) * N + (ybase + a * K);
+                        const bool set = (WM[(a * CH + (P - 1)) * (TAB / 32) + (x >> 5)] >> (x & 31)) & 1u;
+                        row_store(set ? best[a][P - 1] : copysignf(best[a][P - 1], fill), row_resource(sdf + rowIdx * N, rowBytes), xo);
+                    }
+                }
+            } else {
+                if (P >= 2 && P - 2 < nout) {                      // ids gathered during the previous plane
+#pragma unroll
+                    for (int a = 0; a < RY; ++a) {
+                        if (a >= yout) continue;
+                        const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (P - 2) * K) * N + (ybase + a * K);
+                        row_store(pend[a], row_resource(out + rowIdx * N, rowBytes), xo);
+                    }
+                }
+                if (P >= 1 && P - 1 < nout) {                      // output plane P - 1 is complete: fetch the ids of its winners
+                    const uint32_t orank = (uint32_t)((zbase + (P - 1) * K - zlo) * (ptrdiff_t)planeBytes);
+#pragma unroll
+                    for (int a = 0; a < RY; ++a) {
+                        if (a >= yout) continue;
+                        const uint32_t lo = __builtin_bit_cast(u32x2, best[a][P - 1]).x;
+                        const uint32_t ownOff = orank + ro[a + 1] + xo;
+                        const uint32_t off = lo ? lo - 1u : ownOff;
+#if defined(VP_ABL_NOGATHER)
+                        pend[a] = off;
+#else
+                        pend[a] = *reinterpret_cast<const T*>(gbase + off);
+#endif
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < RY; ++a)
+#pragma unroll
+                for (int o = P; o <= P + 1; ++o)
+                    if (o >= 0 && o < CH) pin(best[a][o]);
+        }
+        if constexpr (!FINAL) {
+            if (CH - 1 < nout) {
+#pragma unroll
+                for (int a = 0; a < RY; ++a) {
+                    if (a >= yout) continue;
+                    const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (CH - 1) * K) * N + (ybase + a * K);
+                    row_store(pend[a], row_resource(out + rowIdx * N, rowBytes), xo);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ final
 // One lane = 4 voxels.  sequential.cpp:55-60,106-109 + apps/cli/main.cpp:200 give the sign rule.
 __device__ __forceinline__ void load4(const uint32_t* base, size_t quad, uint32_t (&o)[4])
@@ -790,6 +1119,11 @@ jfa_final(Frame f, const uint32_t* __restrict__ words, const typename ID::T* __r
     sdf[i4] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+#ifdef VP_ISA_PROBE    // dev: compile ONE kernel instance to look at its ISA (hipcc -DVP_ISA_PROBE='...' -S --cuda-device-only)
+template __global__ void VP_ISA_PROBE;
+}  // namespace
+}  // namespace vp
+#else
 inline bool wide(const Frame& f) { return f.n > 1024; }           // 64-bit ids
 
 }  // namespace
@@ -882,6 +1216,75 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     return 0;
 }
 
+#ifndef VP_DENSE_EY
+#define VP_DENSE_EY 1
+#endif
+#ifndef VP_DENSE_EZ
+#define VP_DENSE_EZ 1
+#endif
+// Dense tile kernel (jfa_pass_dense): 32-bit ids, dense passes and the fused last pass, id buffers contiguous.
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static bool dense_applies(const Frame& f, uint32_t k, const void* d_in, const void* d_minus, const void* d_plus, bool fin)
+{
+    // The fused last pass stays on jfa_pass_zstream: its distance-only update (v_min_f32) gains nothing from the pair
+    // minimum, and interleaved A/B runs have the round-1 kernel 0 - 5 % ahead on it (tools/ab_pass.py).
+    static const int finalToo = env_int("VP_JFA_DENSE_FINAL", 0);
+    if (fin && !finalToo) return false;
+    #ifndef VP_JFA_DENSE_DEFAULT
+#define VP_JFA_DENSE_DEFAULT 1
+#endif
+    static const int enabled = env_int("VP_JFA_DENSE", VP_JFA_DENSE_DEFAULT);         // dev switch: 0 = round-1 kernel for every pass
+    if (!enabled || wide(f) || k * 4 >= f.n) return false;
+    const size_t plane = (size_t)f.n * f.n * 4;
+    const char* in = (const char*)d_in;
+    if (f.z0 > 0 && (const char*)d_minus + (size_t)k * plane != in) return false;
+    const uint32_t pbase = std::max(f.z1, f.z0 + k);
+    if (f.z1 < f.n && (const char*)d_plus != in + (size_t)(pbase - f.z0) * plane) return false;
+    return true;
+}
+
+static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
+{
+    const uint32_t nz = f.z1 - f.z0;
+    if (!ctx->none_row.ptr) {
+        VP_TRY(reserve(ctx, ctx->none_row, 2048 * 8));
+        VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, 2048 * 8, ctx->stream));
+    }
+    const uint32_t* none_row = (const uint32_t*)ctx->none_row.ptr;
+    const bool fin = d_sdf != nullptr;
+    const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k;
+    const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
+    static const int forceCH = env_int("VP_JFA_DENSE_CH", 0), forceNT = env_int("VP_JFA_DENSE_NT", 0);
+#define VP_LAUNCH_DENSE(TAB, RY, CH, NT, C, F)                                                                                     \
+    hipLaunchKernelGGL((jfa_pass_dense<TAB, RY, CH, VP_DENSE_EY, VP_DENSE_EZ, NT, C, F>),                                                                    \
+                       dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(NT), 0, ctx->stream, f, k,        \
+                       (const uint32_t*)d_in, (uint32_t*)d_out, none_row, d_words, fill, d_sdf)
+#define VP_DENSE_F(TAB, CH, NT, C) do { if (fin) VP_LAUNCH_DENSE(TAB, 4, CH, NT, C, true); else VP_LAUNCH_DENSE(TAB, 4, CH, NT, C, false); } while (0)
+    bool deep = zlen % 8 == 0;
+    if (forceCH) deep = forceCH == 8;
+    if (f.n <= 512) {
+        if (deep) VP_DENSE_F(512, 8, 256, false); else VP_DENSE_F(512, 4, 256, false);
+    } else {
+        // 4-KB x table + 16-byte / 32-byte entries: 4x8 tiles take 52 KB of LDS, shared by the 8 waves of a 512-thread workgroup
+        const bool chk = f.n >= 1024;
+#ifndef VP_DENSE_1024_BIG
+#define VP_DENSE_1024_BIG 1
+#endif
+        bool big = deep && VP_DENSE_1024_BIG;
+        if (forceNT) big = forceNT == 512;
+        if (big) { if (chk) VP_DENSE_F(1024, 8, 512, true); else VP_DENSE_F(1024, 8, 512, false); }
+        else     { if (chk) VP_DENSE_F(1024, 4, 256, true); else VP_DENSE_F(1024, 4, 256, false); }
+    }
+#undef VP_DENSE_F
+#undef VP_LAUNCH_DENSE
+    return 0;
+}
+
 // d_sdf != nullptr: this is the last pass and it writes the sdf directly (only where
 // jfa_pass_can_fuse_final() says so); otherwise ids go to d_out.
 int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, const void* d_minus,
@@ -897,6 +1300,8 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
         else
             hipLaunchKernelGGL(jfa_pass_direct<Id32>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
                                (const uint32_t*)d_minus, (const uint32_t*)d_plus, (uint32_t*)d_out);
+    } else if (f.n >= 256 && dense_applies(f, k, d_in, d_minus, d_plus, d_sdf != nullptr)) {
+        VP_TRY(launch_dense(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
     } else if (f.n >= 256) {
         if (wide(f)) VP_TRY(launch_chain<Id64>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
         else         VP_TRY(launch_chain<Id32>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
@@ -923,3 +1328,4 @@ int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const
 }
 
 }  // namespace vp
+#endif  // VP_ISA_PROBE
