@@ -51,8 +51,10 @@ struct Id32 {                     // n <= 1024: bits [2..11] x, [12..21] scr(z),
     using T = uint32_t;
     static constexpr int kTab = 1024;             // table entries: any 10-bit field (also those of none) stays in bounds
     static constexpr uint32_t kMask = 0xFFCu;
-    __device__ static __forceinline__ T none() { return 0xFFFFFFFFu; }
-    __device__ static __forceinline__ bool is_none(T a) { return a == 0xFFFFFFFFu; }
+    // "none": y and z fields all ones, x field = 512 -- for n <= 512 the first x slot no real id uses, so the x table of
+    // the tile kernels needs 513 entries (slot 512 = +inf) instead of 1024, which is what lets six workgroups share a CU's LDS.
+    __device__ static __forceinline__ T none() { return kNone; }
+    __device__ static __forceinline__ bool is_none(T a) { return a == kNone; }
     __device__ static __forceinline__ T pack(uint32_t x, uint32_t y, uint32_t z) { return (x << 2) | (scr(z) << 12) | (scr(y) << 22); }
     __device__ static __forceinline__ T add_x(T a, uint32_t dx) { return a + (dx << 2); }
     __device__ static __forceinline__ uint32_t xoff(T a) { return a & kMask; }
@@ -580,7 +582,8 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                 WM[o * (TAB / 32) + i % f.w] = (oy < N && oz < (int)f.z1) ? words[((size_t)(oz - (int)f.z0) * N + oy) * f.w + i % f.w] : 0u;
             }
         }
-        if (PXT > TAB && tid == 0) PX[PXT - 1] = INFINITY;       // n == TAB: "none" gets dx = inf through its x field
+        if (PXT > TAB)                                           // n == TAB: "none" (x field 512 = TAB) gets dx = inf through its x field
+            for (uint32_t i = (uint32_t)N + tid; i < (uint32_t)PXT; i += 256) PX[i] = INFINITY;
         if (!CHECK_NONE && PXT == TAB && tid == 0) {
             PX[kTab - 1] = 0.0f;
 #pragma unroll
@@ -838,17 +841,20 @@ __device__ __forceinline__ void lds_span(const char* base, uint32_t off, int lo,
 }
 
 #ifndef VP_DENSE_WAVES
-#define VP_DENSE_WAVES 1
+#define VP_DENSE_WAVES 6
 #endif
-template <int TAB, int RY, int CH, int EY, int EZ, int NT, bool CHECK_NONE, bool FINAL>
+template <int TAB, int RY, int CH, int EY, int EZ, int NT, bool CHECK_NONE, bool FINAL, bool ROLL>
 __global__ void __launch_bounds__(NT, VP_DENSE_WAVES)
 jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
 {
     using ID = Id32;
     using T = uint32_t;
-    constexpr int PXT = 1024;                                      // x table: every 10-bit field; slots >= n hold +inf (the x field of "none")
-    constexpr uint32_t kFieldX = (uint32_t)(PXT - 1) * 4u;
+    // x table: n <= 512: 513 entries, slot 512 (the x field of "none") = +inf; else every 10-bit field, and "none" gets its
+    // infinite distance from the z tables (slot 1023 is no real scrambled coordinate for n < 1024) or from a test (n = 1024)
+    constexpr int PXT = TAB == 512 ? 513 : 1024;
+    constexpr uint32_t kFieldX = 0xFFCu;
+    static_assert(((kNone >> 2) & 1023u) == 512u, "x field of none = 512");
     constexpr int YB = EY * 4, ZB = EZ * 4;                        // bytes per TY / TZ entry (EY / EZ floats: 1, 2 or 4)
     static_assert(RY % EY == 0 && CH % EZ == 0, "sub-tables");
     constexpr int YSH = 22 - (EY == 1 ? 2 : EY == 2 ? 3 : 4), ZSH = 12 - (EZ == 1 ? 2 : EZ == 2 ? 3 : 4);   // field position -> entry byte offset
@@ -888,11 +894,11 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
             for (int j = 0; j < RY; ++j) { const float d = sy - py[j]; TY[j / EY][si][j % EY] = d * d; }
 #pragma unroll
             for (int j = 0; j < CH; ++j) { const float d = sz - pz[j]; TZ[j / EZ][si][j % EZ] = d * d; }
-        } else {                                                   // slots no real id refers to ("none" does): finite, so inf + it = inf
+        } else {                                                   // slots no real id refers to ("none" does: TAB - 1)
 #pragma unroll
             for (int j = 0; j < RY; ++j) TY[j / EY][i][j % EY] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < CH; ++j) TZ[j / EZ][i][j % EZ] = 0.0f;
+            for (int j = 0; j < CH; ++j) TZ[j / EZ][i][j % EZ] = INFINITY;
         }
     }
     if (FINAL) {
@@ -939,22 +945,20 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
         const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
         const uint32_t xo = x * 4u, xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;   // a column outside the grid reads the centre column
 
-        auto load_plane = [&](int zg, T (&w)[NI], bool needed) {
+        // ids of row rr of source plane zg -> w[rr*3 ..]: columns {x-k, x, x+k}; "none" where outside the grid or not needed
+        auto load_row = [&](int zg, int rr, T (&w)[NI], bool needed) {
             const bool zin = needed && zg >= 0 && zg < N;
             const char* pl = opaque_uniform(reinterpret_cast<const char*>(in) + ((ptrdiff_t)(zin ? zg : (int)f.z0) - (ptrdiff_t)f.z0) * (ptrdiff_t)planeBytes);
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr) {
-                const __amdgpu_buffer_rsrc_t b =
-                    row_resource((zin && yv[rr]) ? pl + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
-                row_load(w[rr * 3 + 0], b, xmo);
-                row_load(w[rr * 3 + 1], b, xo);
-                row_load(w[rr * 3 + 2], b, xpo);
-            }
+            const __amdgpu_buffer_rsrc_t b =
+                row_resource((zin && yv[rr]) ? pl + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
+            row_load(w[rr * 3 + 0], b, xmo);
+            row_load(w[rr * 3 + 1], b, xo);
+            row_load(w[rr * 3 + 2], b, xpo);
         };
 
         B best[RY][CH];
 
-        auto scatter = [&](int P, const T (&w)[NI]) {
+        auto scatter = [&](int P, T (&w)[NI]) {
             // rank of the ids of this plane: byte offset of the row inside the gather window + 1 (wave-uniform) + the column offset
             const uint32_t prank = (uint32_t)((zbase + P * K - zlo) * (ptrdiff_t)planeBytes) + 1u;
 #pragma unroll
@@ -1002,18 +1006,29 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
                     for (int a = alo; a <= ahi; ++a)
 #pragma unroll
                         for (int o = olo; o <= ohi; ++o) pin(best[a][o]);
+                    // Rolling prefetch: the three ids of this row are spent, so the same row of the NEXT source plane is
+                    // requested into their registers right away -- a whole plane of evaluation ahead of its use, without a
+                    // second id buffer (18 VGPRs).  A plane that is not needed reads "none" (never memory past the slab's halo).
+                    if (ROLL && P + 1 <= CH) load_row(zbase + (P + 1) * K, rr, w, P + 1 <= nout);
                 }
             }
         };
 
-        T wa[NI], wb[NI];
+        // ROLL: one id buffer, refilled row by row (see scatter).  Otherwise two buffers: plane P + 1 is requested as a whole
+        // before plane P is evaluated (18 more VGPRs).  Measured (tools/ab_pass.py, interleaved): at n = 512 the two
+        // buffers are 3 % ahead, at n = 1024 the rolling refill is 5 % ahead.
+        T w[NI], w2[ROLL ? 1 : NI];
         T pend[RY];                                                // gathered winners of the previous output plane, stored a plane later
-        load_plane(zbase - K, wa, true);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) load_row(zbase - K, rr, w, true);
 #pragma clang loop unroll(full)
         for (int P = -1; P <= CH; ++P) {
-            T (&cur)[NI] = ((P + 1) & 1) ? wb : wa;
-            T (&nxt)[NI] = ((P + 1) & 1) ? wa : wb;
-            if (P + 1 <= CH) load_plane(zbase + (P + 1) * K, nxt, P + 1 <= nout);
+            T (&cur)[NI] = (ROLL || !((P + 1) & 1)) ? w : reinterpret_cast<T (&)[NI]>(w2);
+            if (!ROLL && P + 1 <= CH) {
+                T (&nxt)[NI] = ((P + 1) & 1) ? w : reinterpret_cast<T (&)[NI]>(w2);
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) load_row(zbase + (P + 1) * K, rr, nxt, P + 1 <= nout);
+            }
             if (P + 1 < CH) {
 #pragma unroll
                 for (int a = 0; a < RY; ++a) {
@@ -1174,17 +1189,24 @@ bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo)
     return algo == VP_ALGO_TILED && f.n >= 256;
 }
 
+// One row of "none" per id format for out-of-grid reads: 2048 x 8 bytes of the 64-bit "none", then 1024 x 4 of the 32-bit one.
+static int ensure_none_rows(vp_ctx* ctx)
+{
+    if (ctx->none_row.ptr) return 0;
+    VP_TRY(reserve(ctx, ctx->none_row, 2048 * 8 + 1024 * 4));
+    VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, 2048 * 8, ctx->stream));
+    VP_HIP(hipMemsetD32Async((hipDeviceptr_t)((char*)ctx->none_row.ptr + 2048 * 8), (int)kNone, 1024, ctx->stream));
+    return 0;
+}
+
 template <class ID>
 static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, const void* d_minus, const void* d_plus,
                         void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
 {
     using T = typename ID::T;
     const uint32_t nz = f.z1 - f.z0;
-    if (!ctx->none_row.ptr) {                                      // a row of "none" for out-of-grid reads (sized for 64-bit ids)
-        VP_TRY(reserve(ctx, ctx->none_row, 2048 * 8));
-        VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, 2048 * 8, ctx->stream));
-    }
-    const T* none_row = (const T*)ctx->none_row.ptr;
+    VP_TRY(ensure_none_rows(ctx));
+    const T* none_row = (const T*)((const char*)ctx->none_row.ptr + (sizeof(T) == 8 ? 0 : 2048 * 8));
     const bool skip = k * 4 >= f.n, fin = d_sdf != nullptr;
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k; // residue classes of the local plane index, planes per class
     const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
@@ -1251,20 +1273,23 @@ static bool dense_applies(const Frame& f, uint32_t k, const void* d_in, const vo
 static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
 {
     const uint32_t nz = f.z1 - f.z0;
-    if (!ctx->none_row.ptr) {
-        VP_TRY(reserve(ctx, ctx->none_row, 2048 * 8));
-        VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, 2048 * 8, ctx->stream));
-    }
-    const uint32_t* none_row = (const uint32_t*)ctx->none_row.ptr;
+    VP_TRY(ensure_none_rows(ctx));
+    const uint32_t* none_row = (const uint32_t*)((const char*)ctx->none_row.ptr + 2048 * 8);
     const bool fin = d_sdf != nullptr;
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k;
     const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
     static const int forceCH = env_int("VP_JFA_DENSE_CH", 0), forceNT = env_int("VP_JFA_DENSE_NT", 0);
 #define VP_LAUNCH_DENSE(TAB, RY, CH, NT, C, F)                                                                                     \
-    hipLaunchKernelGGL((jfa_pass_dense<TAB, RY, CH, VP_DENSE_EY, VP_DENSE_EZ, NT, C, F>),                                                                    \
+    hipLaunchKernelGGL((jfa_pass_dense<TAB, RY, CH, VP_DENSE_EY, VP_DENSE_EZ, NT, C, F, (TAB > 512 || VP_DENSE_ROLL512)>),                                                                    \
                        dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(NT), 0, ctx->stream, f, k,        \
                        (const uint32_t*)d_in, (uint32_t*)d_out, none_row, d_words, fill, d_sdf)
-#define VP_DENSE_F(TAB, CH, NT, C) do { if (fin) VP_LAUNCH_DENSE(TAB, 4, CH, NT, C, true); else VP_LAUNCH_DENSE(TAB, 4, CH, NT, C, false); } while (0)
+#ifndef VP_DENSE_ROLL512
+#define VP_DENSE_ROLL512 1
+#endif
+#ifndef VP_DENSE_RY
+#define VP_DENSE_RY 4
+#endif
+#define VP_DENSE_F(TAB, CH, NT, C) do { if (fin) VP_LAUNCH_DENSE(TAB, 4, CH, NT, C, true); else VP_LAUNCH_DENSE(TAB, VP_DENSE_RY, CH, NT, C, false); } while (0)
     bool deep = zlen % 8 == 0;
     if (forceCH) deep = forceCH == 8;
     if (f.n <= 512) {

@@ -10,7 +10,7 @@
 
 namespace vp {
 
-constexpr uint32_t kNone = 0xFFFFFFFFu;   // JFA state: no seed yet
+constexpr uint32_t kNone = 0xFFFFF803u;   // JFA state (32-bit ids): no seed yet -- y, z fields all ones, x field 512 (jfa.hip, Id32)
 constexpr int kTile = 8;                  // voxelizer tile: 8x8 (y,z) columns = one wave64
 constexpr int kRecDwords = 20;            // per-triangle record, see vox.hip
 

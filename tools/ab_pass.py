@@ -75,7 +75,8 @@ cases = [("k=%d" % k, k) for k in [int(x) for x in a.k.split(",")]] + ([("final"
 res = {(l.name, c): [] for l in libs for c, _ in cases}
 ref = {}
 for r in range(a.rounds + 1):
-    for l in libs:
+    order = libs if r == 0 else libs[r % len(libs):] + libs[:r % len(libs)]      # rotate: whoever runs first after the idle gap is favoured
+    for l in order:
         for cname, k in cases:
             if k:
                 st = states[k]

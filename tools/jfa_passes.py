@@ -29,7 +29,7 @@ for algo in [int(x) for x in a.algos.split(",")]:
     out = torch.empty_like(cur)
     tot = 0.0
     for k, st in states:
-        seeds = int((st != -1).sum().item())
+        seeds = int(((st & 3) == 0).sum().item())                # real ids have bits 0,1 clear
         ctx.prof_reset(); ctx.prof_enable(True)
         for _ in range(a.reps):
             ctx.jfa_pass(fr, k, st.data_ptr(), None, None, out.data_ptr(), algo)
