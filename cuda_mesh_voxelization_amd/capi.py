@@ -13,13 +13,15 @@ ALGO_NAIVE, ALGO_TILED = 1, 2
 OP_VOID, OP_UNION, OP_INTERSECTION, OP_DIFFERENCE = 0, 1, 2, 3
 
 KERNELS = ["vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
-           "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface"]
+           "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last"]
+JFA_PASS_KEYS = ("jfa_pass", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last")
 
 # every symbol include/vphip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_stream", "vp_ctx_sync", "vp_last_error", "vp_abi_version",
-    "vp_malloc", "vp_free", "vp_memset", "vp_upload", "vp_download", "vp_grid_words", "vp_grid_voxels",
-    "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa", "vp_jfa_init", "vp_jfa_pass",
+    "vp_malloc", "vp_free", "vp_memset", "vp_memcpy_d2d", "vp_ctx_workspace", "vp_ctx_release", "vp_upload", "vp_download",
+    "vp_grid_words", "vp_grid_voxels",
+    "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa", "vp_jfa_start", "vp_jfa_run", "vp_jfa_init", "vp_jfa_pass",
     "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass",
     "vp_surface", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
@@ -88,6 +90,9 @@ def lib():
         "vp_malloc": (ctypes.c_int, [_vp, _sz, ctypes.POINTER(_vp)]),
         "vp_free": (ctypes.c_int, [_vp, _vp]),
         "vp_memset": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _sz]),
+        "vp_memcpy_d2d": (ctypes.c_int, [_vp, _vp, _vp, _sz]),
+        "vp_ctx_workspace": (ctypes.c_int, [_vp, ctypes.c_int, _sz, ctypes.POINTER(_vp)]),
+        "vp_ctx_release": (ctypes.c_int, [_vp]),
         "vp_upload": (ctypes.c_int, [_vp, _vp, _vp, _sz]),
         "vp_download": (ctypes.c_int, [_vp, _vp, _vp, _sz]),
         "vp_grid_words": (_sz, [fp]),
@@ -97,6 +102,8 @@ def lib():
         "vp_jfa_workspace_bytes": (_sz, [fp]),
         "vp_jfa_id_bytes": (_sz, [fp]),
         "vp_jfa": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_float, _vp, _vp, _sz, ctypes.c_int]),
+        "vp_jfa_start": (ctypes.c_int, [_vp, fp, _vp, _vp, _sz, ctypes.c_int]),
+        "vp_jfa_run": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_float, _vp, _vp, _sz, ctypes.c_int]),
         "vp_jfa_init": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
         "vp_jfa_pass": (ctypes.c_int, [_vp, fp, ctypes.c_uint32, _vp, _vp, _vp, _vp, ctypes.c_int]),
         "vp_jfa_finalize": (ctypes.c_int, [_vp, fp, _vp, _vp, ctypes.c_float, _vp]),
@@ -185,9 +192,27 @@ class Context:
         """Bytes of JFA state per voxel: 4 for n <= 1024, 8 for n <= 2048."""
         return int(lib().vp_jfa_id_bytes(ctypes.byref(frame)))
 
-    def jfa(self, frame: Frame, d_words: int, fill: float, d_sdf: int, d_work: int, work_bytes: int,
+    def jfa(self, frame: Frame, d_words: int, fill: float, d_sdf: int, d_work=None, work_bytes: int = 0,
             algo: int = ALGO_TILED):
-        check(lib().vp_jfa(self._h, ctypes.byref(frame), _vp(d_words), fill, _vp(d_sdf), _vp(d_work), work_bytes, algo))
+        """d_work = None: the context's own grow-only workspace."""
+        check(lib().vp_jfa(self._h, ctypes.byref(frame), _vp(d_words), fill, _vp(d_sdf), _vp(d_work or None), work_bytes, algo))
+
+    def jfa_start(self, frame: Frame, d_words: int, d_work=None, work_bytes: int = 0, algo: int = ALGO_TILED):
+        check(lib().vp_jfa_start(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_work or None), work_bytes, algo))
+
+    def jfa_run(self, frame: Frame, d_words: int, fill: float, d_sdf: int, d_work=None, work_bytes: int = 0, algo: int = ALGO_TILED):
+        check(lib().vp_jfa_run(self._h, ctypes.byref(frame), _vp(d_words), fill, _vp(d_sdf), _vp(d_work or None), work_bytes, algo))
+
+    def memcpy_d2d(self, dst: int, src: int, nbytes: int):
+        check(lib().vp_memcpy_d2d(self._h, _vp(dst), _vp(src), nbytes))
+
+    def workspace(self, slot: int, nbytes: int) -> int:
+        p = _vp()
+        check(lib().vp_ctx_workspace(self._h, slot, nbytes, ctypes.byref(p)))
+        return p.value
+
+    def release(self):
+        check(lib().vp_ctx_release(self._h))
 
     def jfa_init(self, frame: Frame, d_words: int, d_below, d_above, d_ids: int):
         check(lib().vp_jfa_init(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_below or None),

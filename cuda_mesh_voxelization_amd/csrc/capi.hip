@@ -28,6 +28,12 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line)
     return (int)e;
 }
 
+void release(Buffer& b)
+{
+    if (b.ptr) (void)hipFree(b.ptr);
+    b.ptr = nullptr; b.bytes = 0;
+}
+
 int reserve(vp_ctx* ctx, Buffer& b, size_t bytes)
 {
     if (bytes <= b.bytes) return 0;
@@ -101,7 +107,7 @@ static int bind_device(vp_ctx* ctx)
 
 static const char* kNames[VP_K_COUNT] = {
     "vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
-    "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface"
+    "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last"
 };
 
 }  // namespace vp
@@ -138,10 +144,13 @@ int vp_ctx_destroy(vp_ctx* ctx)
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buffer* bufs[] = { &ctx->rec, &ctx->tile_cnt, &ctx->tile_off, &ctx->tile_cur, &ctx->pairs, &ctx->scratch, &ctx->none_row };
-    for (Buffer* b : bufs) if (b->ptr) (void)hipFree(b->ptr);
+    Buffer* bufs[] = { &ctx->rec, &ctx->tile_cnt, &ctx->tile_off, &ctx->tile_cur, &ctx->pairs, &ctx->scratch, &ctx->none_row, &ctx->jfa_work };
+    for (Buffer* b : bufs) release(*b);
+    for (int i = 0; i < VP_WORKSPACE_SLOTS; ++i) release(ctx->slots[i]);
     for (auto& s : ctx->prof_pending) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
+    if (ctx->vox_total_event) (void)hipEventDestroy(ctx->vox_total_event);
+    if (ctx->vox_total_host) (void)hipHostFree(ctx->vox_total_host);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return 0;
@@ -177,6 +186,33 @@ int vp_free(vp_ctx* ctx, void* d_ptr)
     if (!ctx) return set_error(VP_ERR_INVALID, "vp_free: null ctx");
     VP_TRY(bind_device(ctx));
     if (d_ptr) { VP_HIP(hipStreamSynchronize(ctx->stream)); VP_HIP(hipFree(d_ptr)); }
+    return 0;
+}
+
+int vp_memcpy_d2d(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes)
+{
+    if (!ctx || ((!d_dst || !d_src) && bytes)) return set_error(VP_ERR_INVALID, "vp_memcpy_d2d: null argument");
+    VP_TRY(bind_device(ctx));
+    if (bytes) VP_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int vp_ctx_workspace(vp_ctx* ctx, int slot, size_t bytes, void** d_out)
+{
+    if (!ctx || !d_out || slot < 0 || slot >= VP_WORKSPACE_SLOTS) return set_error(VP_ERR_INVALID, "vp_ctx_workspace: bad argument");
+    VP_TRY(bind_device(ctx));
+    VP_TRY(reserve(ctx, ctx->slots[slot], bytes ? bytes : 1));
+    *d_out = ctx->slots[slot].ptr;
+    return 0;
+}
+
+int vp_ctx_release(vp_ctx* ctx)
+{
+    if (!ctx) return set_error(VP_ERR_INVALID, "vp_ctx_release: null ctx");
+    VP_TRY(bind_device(ctx));
+    VP_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < VP_WORKSPACE_SLOTS; ++i) release(ctx->slots[i]);
+    release(ctx->jfa_work);
     return 0;
 }
 
@@ -289,28 +325,48 @@ int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, con
     return launch_jfa_final(ctx, make_frame(f), d_words, d_ids, fill_unset, d_sdf);
 }
 
-int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset, float* d_sdf,
-           void* d_work, size_t work_bytes, int algo)
+// The two halves of vp_jfa (the reference times them separately: "::Initialization" / "::Processing",
+// jfa/tiled.cu:265-334).  start: border mask (fast sequence) or init ids; run: every pass + the id -> sdf conversion.
+static int jfa_check(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void*& d_work, size_t work_bytes, int algo, const char* who)
 {
-    if (!ctx || !d_words || !d_sdf || !d_work) return set_error(VP_ERR_INVALID, "vp_jfa: null argument");
+    if (!ctx || !d_words) return set_error(VP_ERR_INVALID, "%s: null argument", who);
     VP_TRY(bind_device(ctx));
-    VP_TRY(check_frame(f, "vp_jfa", true));
-    VP_TRY(check_fill(fill_unset, "vp_jfa"));
-    if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_jfa: algo %d", algo);
-    if (work_bytes < vp_jfa_workspace_bytes(f)) return set_error(VP_ERR_INVALID, "vp_jfa: workspace too small");
+    VP_TRY(check_frame(f, who, true));
+    if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "%s: algo %d", who, algo);
+    if (!d_work) {                                                 // context-owned workspace (grow-only, reused by later calls)
+        VP_TRY(reserve(ctx, ctx->jfa_work, vp_jfa_workspace_bytes(f)));
+        d_work = ctx->jfa_work.ptr;
+    } else if (work_bytes < vp_jfa_workspace_bytes(f)) {
+        return set_error(VP_ERR_INVALID, "%s: workspace too small", who);
+    }
+    return 0;
+}
+
+int vp_jfa_start(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void* d_work, size_t work_bytes, int algo)
+{
+    VP_TRY(jfa_check(ctx, f, d_words, d_work, work_bytes, algo, "vp_jfa_start"));
+    const Frame fr = make_frame(f);
+    const size_t volBytes = vp_grid_voxels(f) * vp_jfa_id_bytes(f);
+    char* a = (char*)d_work;
+    if (jfa_can_start_from_mask(fr, algo) && f->n / 2 > 1)
+        return launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, nullptr, (uint32_t*)(a + 2 * volBytes));   // border mask only
+    return launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, a, nullptr);
+}
+
+int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset, float* d_sdf,
+               void* d_work, size_t work_bytes, int algo)
+{
+    if (!d_sdf) return set_error(VP_ERR_INVALID, "vp_jfa_run: null argument");
+    VP_TRY(jfa_check(ctx, f, d_words, d_work, work_bytes, algo, "vp_jfa_run"));
+    VP_TRY(check_fill(fill_unset, "vp_jfa_run"));
     const Frame fr = make_frame(f);
     const size_t volBytes = vp_grid_voxels(f) * vp_jfa_id_bytes(f);
     char* a = (char*)d_work;
     char* b = a + volBytes;
     uint32_t k = f->n / 2;                                         // jfa/sequential.cpp:72
     if (jfa_can_start_from_mask(fr, algo) && k > 1) {
-        // border mask -> first pass directly (no init id volume)
-        uint32_t* border = (uint32_t*)(b + volBytes);
-        VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, nullptr, border));
-        VP_TRY(launch_jfa_first_pass(ctx, fr, border, a));
+        VP_TRY(launch_jfa_first_pass(ctx, fr, (const uint32_t*)(b + volBytes), a));   // straight from the border mask
         k /= 2;
-    } else {
-        VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, a, nullptr));
     }
     for (; k >= 1; k /= 2) {
         if (k == 1 && jfa_pass_can_fuse_final(fr, k, algo))        // last pass writes the sdf itself
@@ -319,6 +375,15 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
         char* t = a; a = b; b = t;
     }
     return launch_jfa_final(ctx, fr, d_words, a, fill_unset, d_sdf);
+}
+
+int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset, float* d_sdf,
+           void* d_work, size_t work_bytes, int algo)
+{
+    if (!d_sdf) return set_error(VP_ERR_INVALID, "vp_jfa: null argument");
+    VP_TRY(check_fill(fill_unset, "vp_jfa"));
+    VP_TRY(vp_jfa_start(ctx, f, d_words, d_work, work_bytes, algo));
+    return vp_jfa_run(ctx, f, d_words, fill_unset, d_sdf, d_work, work_bytes, algo);
 }
 
 int vp_jfa_can_start_from_mask(const vp_frame* f, int algo)
@@ -356,6 +421,10 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
 }
 
 // ---- host-in / host-out ----------------------------------------------------------------------
+// Device buffers come from the context's workspace slots (grow-only): steady-state calls allocate nothing, where the
+// reference's Compute() does ~15 cudaMalloc/cudaFree per call.
+enum { SLOT_GRID_A = 0, SLOT_GRID_B = 1, SLOT_XYZ = 2, SLOT_TRI = 3, SLOT_SDF = 4 };
+
 int vp_voxelize_host(vp_ctx* ctx, const vp_frame* f, uint32_t* h_words, const float* h_xyz, size_t nverts,
                      const uint32_t* h_tri, size_t ntris, int algo)
 {
@@ -363,54 +432,38 @@ int vp_voxelize_host(vp_ctx* ctx, const vp_frame* f, uint32_t* h_words, const fl
     VP_TRY(check_frame(f, "vp_voxelize_host", true));
     void *dw = nullptr, *dx = nullptr, *dt = nullptr;
     const size_t wb = vp_grid_words(f) * 4;
-    int rc = vp_malloc(ctx, wb, &dw);
-    if (!rc) rc = vp_malloc(ctx, nverts * 12, &dx);
-    if (!rc) rc = vp_malloc(ctx, ntris * 12, &dt);
-    if (!rc) rc = vp_upload(ctx, dx, h_xyz, nverts * 12);
-    if (!rc) rc = vp_upload(ctx, dt, h_tri, ntris * 12);
-    if (!rc) rc = vp_voxelize(ctx, f, (uint32_t*)dw, (const float*)dx, nverts, (const uint32_t*)dt, ntris, algo, 0);
-    if (!rc) rc = vp_download(ctx, h_words, dw, wb);
-    char keep[sizeof(g_err)];
-    memcpy(keep, g_err, sizeof(keep));
-    (void)vp_free(ctx, dw); (void)vp_free(ctx, dx); (void)vp_free(ctx, dt);
-    if (rc) memcpy(g_err, keep, sizeof(keep));
-    return rc;
+    VP_TRY(vp_ctx_workspace(ctx, SLOT_GRID_A, wb, &dw));
+    VP_TRY(vp_ctx_workspace(ctx, SLOT_XYZ, nverts * 12, &dx));
+    VP_TRY(vp_ctx_workspace(ctx, SLOT_TRI, ntris * 12, &dt));
+    VP_TRY(vp_upload(ctx, dx, h_xyz, nverts * 12));
+    VP_TRY(vp_upload(ctx, dt, h_tri, ntris * 12));
+    VP_TRY(vp_voxelize(ctx, f, (uint32_t*)dw, (const float*)dx, nverts, (const uint32_t*)dt, ntris, algo, 0));
+    return vp_download(ctx, h_words, dw, wb);
 }
 
 int vp_csg_host(vp_ctx* ctx, uint32_t* h_a, const uint32_t* h_b, size_t nwords, int op)
 {
     if (!ctx || ((!h_a || !h_b) && nwords)) return set_error(VP_ERR_INVALID, "vp_csg_host: null argument");
     void *da = nullptr, *db = nullptr;
-    int rc = vp_malloc(ctx, nwords * 4, &da);
-    if (!rc) rc = vp_malloc(ctx, nwords * 4, &db);
-    if (!rc) rc = vp_upload(ctx, da, h_a, nwords * 4);
-    if (!rc) rc = vp_upload(ctx, db, h_b, nwords * 4);
-    if (!rc) rc = vp_csg(ctx, (uint32_t*)da, (const uint32_t*)db, nwords, op);
-    if (!rc) rc = vp_download(ctx, h_a, da, nwords * 4);
-    char keep[sizeof(g_err)];
-    memcpy(keep, g_err, sizeof(keep));
-    (void)vp_free(ctx, da); (void)vp_free(ctx, db);
-    if (rc) memcpy(g_err, keep, sizeof(keep));
-    return rc;
+    VP_TRY(vp_ctx_workspace(ctx, SLOT_GRID_A, nwords * 4, &da));
+    VP_TRY(vp_ctx_workspace(ctx, SLOT_GRID_B, nwords * 4, &db));
+    VP_TRY(vp_upload(ctx, da, h_a, nwords * 4));
+    VP_TRY(vp_upload(ctx, db, h_b, nwords * 4));
+    VP_TRY(vp_csg(ctx, (uint32_t*)da, (const uint32_t*)db, nwords, op));
+    return vp_download(ctx, h_a, da, nwords * 4);
 }
 
 int vp_jfa_host(vp_ctx* ctx, const vp_frame* f, const uint32_t* h_words, float fill_unset, float* h_sdf, int algo)
 {
     if (!ctx || !h_words || !h_sdf) return set_error(VP_ERR_INVALID, "vp_jfa_host: null argument");
     VP_TRY(check_frame(f, "vp_jfa_host", true));
-    void *dw = nullptr, *ds = nullptr, *wk = nullptr;
-    const size_t wb = vp_grid_words(f) * 4, sb = vp_grid_voxels(f) * 4, kb = vp_jfa_workspace_bytes(f);
-    int rc = vp_malloc(ctx, wb, &dw);
-    if (!rc) rc = vp_malloc(ctx, sb, &ds);
-    if (!rc) rc = vp_malloc(ctx, kb, &wk);
-    if (!rc) rc = vp_upload(ctx, dw, h_words, wb);
-    if (!rc) rc = vp_jfa(ctx, f, (const uint32_t*)dw, fill_unset, (float*)ds, wk, kb, algo);
-    if (!rc) rc = vp_download(ctx, h_sdf, ds, sb);
-    char keep[sizeof(g_err)];
-    memcpy(keep, g_err, sizeof(keep));
-    (void)vp_free(ctx, dw); (void)vp_free(ctx, ds); (void)vp_free(ctx, wk);
-    if (rc) memcpy(g_err, keep, sizeof(keep));
-    return rc;
+    void *dw = nullptr, *ds = nullptr;
+    const size_t wb = vp_grid_words(f) * 4, sb = vp_grid_voxels(f) * 4;
+    VP_TRY(vp_ctx_workspace(ctx, SLOT_GRID_A, wb, &dw));
+    VP_TRY(vp_ctx_workspace(ctx, SLOT_SDF, sb, &ds));
+    VP_TRY(vp_upload(ctx, dw, h_words, wb));
+    VP_TRY(vp_jfa(ctx, f, (const uint32_t*)dw, fill_unset, (float*)ds, nullptr, 0, algo));
+    return vp_download(ctx, h_sdf, ds, sb);
 }
 
 // ---- profiling -------------------------------------------------------------------------------

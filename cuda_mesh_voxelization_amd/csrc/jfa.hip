@@ -1175,7 +1175,7 @@ bool jfa_can_start_from_mask(const Frame& f, int algo) { return algo == VP_ALGO_
 // First pass from the whole-grid border mask (see jfa_first_pass).
 int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out)
 {
-    ProfScope p(ctx, VP_K_JFA_PASS);
+    ProfScope p(ctx, VP_K_JFA_FIRST);
     const dim3 grid((f.n + 255) / 256, f.n / kFirstRows, f.z1 - f.z0);
     if (wide(f)) hipLaunchKernelGGL(jfa_first_pass<Id64>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint2*)d_out);
     else         hipLaunchKernelGGL(jfa_first_pass<Id32>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint32_t*)d_out);
@@ -1316,7 +1316,9 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
                        const void* d_plus, void* d_out, int algo, const uint32_t* d_words, float fill, float* d_sdf)
 {
     const uint32_t nz = f.z1 - f.z0;
-    ProfScope p(ctx, VP_K_JFA_PASS);
+    // timing key: the tile kernels are reported per variant (their algorithmic bytes differ)
+    const bool tile = algo != VP_ALGO_NAIVE && f.n >= 256;
+    ProfScope p(ctx, !tile ? VP_K_JFA_PASS : d_sdf ? VP_K_JFA_LAST : k * 4 >= f.n ? VP_K_JFA_SPARSE : VP_K_JFA_DENSE);
     if (algo == VP_ALGO_NAIVE) {
         const dim3 blocks(f.n * f.n / 256, nz);
         if (wide(f))

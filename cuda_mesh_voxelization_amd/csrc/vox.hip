@@ -18,16 +18,19 @@
 //   vox_tile     one 256-thread workgroup per tile.  A tile OWNS its 64 x-rows: they are brought
 //                into an LDS bit-row buffer (coalesced), the tile's large triangles toggle bits
 //                there with ds_xor (no global atomics; records staged through LDS in batches; lane =
-//                (y,z) column, wave = triangle slice), the prefix-XOR runs in LDS and the finished
-//                rows leave as coalesced 16-byte stores (8 consecutive y-rows of one z are contiguous).
-//                When a mesh has no large triangle the tile stage is replaced by the streaming
-//                vox_fill kernel.
+//                (y,z) column, wave = triangle slice), and the rows go back to the toggle grid.  Launched for every
+//                tile; tiles without large triangles (all of them for a fine mesh) leave at once, so the host never
+//                reads a count back and vp_voxelize is fully asynchronous.
+//   vox_fill     streaming prefix-XOR of the whole toggle grid into the output.
 // NAIVE (reference: vox/naive.cu:12-122): one thread per triangle toggling single bits with
 //   global atomicXor, then vox_fill streams the grid once doing the prefix-XOR per row.
 //
 // All float math below must not be contracted into FMAs: the file is built with
 // -ffp-contract=off and carries the pragma as well.
 #include "vp_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -207,47 +210,58 @@ vox_scan(const uint32_t* __restrict__ cnt, uint32_t m, uint32_t* __restrict__ of
     if (tid == 1023) off[m] = part[1023];
 }
 
+// One thread per record of the compact large-triangle list.  The list length is only known on the device (*nbig):
+// the grid is fixed and strides over it, whole waves at a time (for_each_tile must be reached by all lanes).
 __global__ void __launch_bounds__(256)
-vox_scatter(Frame f, const uint4* __restrict__ rec, size_t nrec, uint32_t* __restrict__ cur,
+vox_scatter(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ nbig, uint32_t* __restrict__ cur,
             uint32_t* __restrict__ pairs, uint32_t cap)
 {
-    const size_t ntris = nrec;                                     // one thread per record of the compact large-triangle list
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nrec = *nbig;
     const int tilesY = f.n / kTile;
     const int tzBase = f.z0 / kTile;
-    int sy = 0, ey = 0, sz = 0, ez = 0;
-    if (t < ntris) {
-        const uint4 q = rec[t * 5 + 4];
-        sy = q.x & 0xFFFF; ey = q.x >> 16; sz = q.y & 0xFFFF; ez = q.y >> 16;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); t0 < nrec; t0 += stride) {
+        const size_t t = t0 + (threadIdx.x & 63u);
+        int sy = 0, ey = 0, sz = 0, ez = 0;
+        if (t < nrec) {
+            const uint4 q = rec[t * 5 + 4];
+            sy = q.x & 0xFFFF; ey = q.x >> 16; sz = q.y & 0xFFFF; ez = q.y >> 16;
+        }
+        const bool valid = sy < ey && sz < ez;
+        const int ty0 = sy / kTile, ty1 = valid ? (ey - 1) / kTile : 0;
+        const int tz0 = sz / kTile, tz1 = valid ? (ez - 1) / kTile : 0;
+        for_each_tile(valid, (uint32_t)t, ty0, ty1, tz0, tz1, [&](uint32_t tt, int ty, int tz) {
+            const uint32_t slot = atomicAdd(&cur[(tz - tzBase) * tilesY + ty], 1u);
+            if (slot < cap) pairs[slot] = tt;                      // a tile whose list does not fit scans the record list instead
+        });
     }
-    const bool valid = sy < ey && sz < ez;
-    const int ty0 = sy / kTile, ty1 = valid ? (ey - 1) / kTile : 0;
-    const int tz0 = sz / kTile, tz1 = valid ? (ez - 1) / kTile : 0;
-    for_each_tile(valid, (uint32_t)t, ty0, ty1, tz0, tz1, [&](uint32_t tt, int ty, int tz) {
-        const uint32_t slot = atomicAdd(&cur[(tz - tzBase) * tilesY + ty], 1u);
-        if (slot < cap) pairs[slot] = tt;
-    });
 }
 
 constexpr int kBatch = 64;        // triangle records staged in LDS per round
 constexpr int kMaxW = 64;         // words per x-row at n = 2048
 
-// tog: toggle grid written by vox_setup (small triangles); dst: output grid.  !ACC: dst = fill(tog ^
-// tile toggles), tog may alias dst.  ACC: dst ^= fill(...), tog is a separate scratch grid.
-template <bool ACC>
+// Applies the toggles of the LARGE triangles of one tile to the toggle grid (the small ones were toggled by vox_setup).
+// Launched for every tile; a tile without large triangles (every tile of a fine mesh) leaves at once, so the host
+// never has to know the list sizes: no read-back, no stream synchronisation inside vp_voxelize.
+// `cap` = capacity of `pairs`.  A tile whose slice of the work queue does not fit completely scans the whole record list
+// itself (correct for any input; the host grows the queue for the next call from the total it reads back lazily).
 __global__ void __launch_bounds__(256)
-vox_tile(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ off,
-         const uint32_t* __restrict__ pairs, const uint32_t* tog, uint32_t* words)
+vox_tile(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ nbig, const uint32_t* __restrict__ off,
+         const uint32_t* __restrict__ pairs, uint32_t cap, uint32_t* tog)
 {
+    const int tilesY = f.n / kTile;
+    const int tile = blockIdx.x;
+    uint32_t begin = off[tile], end = off[tile + 1];
+    if (begin == end) return;
+
     __shared__ uint32_t acc[64 * (kMaxW + 1)];
     __shared__ uint4 srec[kBatch * 5];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = f.w, stride = W + 1;
-    const int tilesY = f.n / kTile;
-    const int tile = blockIdx.x;
     const int ty = tile % tilesY, tzl = tile / tilesY;           // tzl: tile row inside the slab
-    const uint32_t begin = off[tile], end = off[tile + 1];
+    const bool listed = end <= cap;                               // the tile's slice of the work queue is complete
+    if (!listed) { begin = 0; end = *nbig; }
 
     const int rowWords = 64 * W;
     // global word index of LDS row r (= lz*8+ly), word w:  base + (r>>3)*n*W + (r&7)*W + w
@@ -268,16 +282,16 @@ vox_tile(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ of
 
     for (uint32_t b0 = begin; b0 < end; b0 += kBatch) {
         const int nb = min((uint32_t)kBatch, end - b0);
-        __syncthreads();                                          // previous batch consumed / acc zeroed
+        __syncthreads();                                          // previous batch consumed
         for (int i = tid; i < nb * 5; i += 256) {
             const int j = i / 5, p = i - j * 5;
-            srec[i] = rec[(size_t)pairs[b0 + j] * 5 + p];
+            srec[i] = rec[(size_t)(listed ? pairs[b0 + j] : b0 + j) * 5 + p];
         }
         __syncthreads();
         for (int j = wave; j < nb; j += 4) {
             const uint4 q = srec[j * 5 + 4];
             const int sy = q.x & 0xFFFF, ey = q.x >> 16, sz = q.y & 0xFFFF, ez = q.y >> 16;
-            if (y >= sy && y < ey && z >= sz && z < ez) {
+            if (y >= sy && y < ey && z >= sz && z < ez) {       // also rejects the records of other tiles in a full scan
                 float r[16];
                 const float4* fr = reinterpret_cast<const float4*>(&srec[j * 5]);
                 const float4 r0 = fr[0], r1 = fr[1], r2 = fr[2], r3 = fr[3];
@@ -293,43 +307,10 @@ vox_tile(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ of
     }
     __syncthreads();
 
-    // prefix-XOR along x inside LDS: 4 adjacent lanes per row, each a chunk of the row's words
-    {
-        const int row = tid >> 2, q = tid & 3;
-        const int c0 = (q * W) / 4, c1 = ((q + 1) * W) / 4;
-        uint32_t* rw = acc + row * stride;
-        uint32_t par = 0;
-        for (int w = c0; w < c1; ++w) par ^= __popc(rw[w]);
-        par &= 1u;
-        const int l0 = lane & ~3;
-        const uint32_t p0 = __shfl(par, l0), p1 = __shfl(par, l0 + 1), p2 = __shfl(par, l0 + 2);
-        uint32_t carry = (q > 0 ? p0 : 0u) ^ (q > 1 ? p1 : 0u) ^ (q > 2 ? p2 : 0u);
-        for (int w = c0; w < c1; ++w) {
-            const uint32_t v = rw[w];
-            rw[w] = word_prefix_xor(v) ^ (0u - carry);
-            carry ^= __popc(v) & 1u;
-        }
-    }
-    __syncthreads();
-
-    // coalesced write-out: for each lz the 8 rows are 8*W contiguous words of the grid
-    if ((W & 3) == 0) {
-        for (int i = tid * 4; i < rowWords; i += 256 * 4) {
-            const int r = i / W, w = i - r * W;
-            const uint32_t* src = acc + r * stride + w;
-            uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
-            uint4* dst = reinterpret_cast<uint4*>(words + base + (size_t)(r >> 3) * planeStride + (size_t)(r & 7) * W + w);
-            if (ACC) { const uint4 o = *dst; v.x ^= o.x; v.y ^= o.y; v.z ^= o.z; v.w ^= o.w; }
-            *dst = v;
-        }
-    } else {
-        for (int i = tid; i < rowWords; i += 256) {
-            const int r = i / W, w = i - r * W;
-            uint32_t* dst = words + base + (size_t)(r >> 3) * planeStride + (size_t)(r & 7) * W + w;
-            uint32_t v = acc[r * stride + w];
-            if (ACC) v ^= *dst;
-            *dst = v;
-        }
+    // coalesced write-back of the toggled rows (the streaming vox_fill does the prefix-XOR for the whole grid afterwards)
+    for (int i = tid; i < rowWords; i += 256) {
+        const int r = i / W, w = i - r * W;
+        tog[base + (size_t)(r >> 3) * planeStride + (size_t)(r & 7) * W + w] = acc[r * stride + w];
     }
 }
 
@@ -466,62 +447,62 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
     }
 
     // ---- TILED (hybrid) ----
+    // Every stage is enqueued unconditionally and sized on the host from upper bounds: the record list can hold every
+    // triangle, the work queue keeps the capacity the previous calls needed (a tile whose slice does not fit scans the
+    // record list instead), scatter and tile kernels read the list sizes on the device and leave at once when there is
+    // nothing to do.  No read-back, no stream synchronisation: the call is asynchronous and graph-capturable.
     const uint32_t tilesY = f.n / kTile;
     const uint32_t numTiles = tilesY * (uint32_t)(nz / kTile);
     VP_TRY(reserve(ctx, ctx->tile_cnt, ((size_t)numTiles + 1) * 4));
     VP_TRY(reserve(ctx, ctx->tile_off, ((size_t)numTiles + 1) * 4));
     VP_TRY(reserve(ctx, ctx->tile_cur, (size_t)numTiles * 4));
-    uint4* rec = nullptr;
     uint32_t* cnt = (uint32_t*)ctx->tile_cnt.ptr;
     uint32_t* off = (uint32_t*)ctx->tile_off.ptr;
     uint32_t* cur = (uint32_t*)ctx->tile_cur.ptr;
-
-    // The record list holds only large triangles.  Its capacity is a guess (what the previous call needed, at least
-    // 64 Ki); if a mesh has more, the setup is repeated once with the exact size.
-    uint32_t total = 0, nbig = 0;
     uint32_t* d_nbig = cnt + numTiles;                             // one extra counter after the tile histogram
     if (ntris) {
-        size_t cap = std::min<size_t>(ntris, std::max<size_t>(ctx->rec.bytes / (kRecDwords * 4), 65536));
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            VP_TRY(reserve(ctx, ctx->rec, cap * kRecDwords * 4));
-            rec = (uint4*)ctx->rec.ptr;
-            if (attempt) VP_HIP(hipMemsetAsync(tog, 0, nwords * 4, st));   // setup toggles small triangles: start over
-            VP_HIP(hipMemsetAsync(cnt, 0, ((size_t)numTiles + 1) * 4, st));
-            {
-                ProfScope p(ctx, VP_K_VOX_SETUP);
-                hipLaunchKernelGGL(vox_setup, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, rec, (uint32_t)cap,
-                                   d_nbig, cnt, tog);
-            }
-            {
-                ProfScope p(ctx, VP_K_VOX_SCAN);
-                hipLaunchKernelGGL(vox_scan, dim3(1), dim3(1024), 0, st, cnt, numTiles, off, cur);
-            }
-            // sizes of the large-triangle list and of its work queue: two 4-byte read-backs (both 0 for fine meshes)
-            VP_HIP(hipMemcpyAsync(&total, off + numTiles, 4, hipMemcpyDeviceToHost, st));
-            VP_HIP(hipMemcpyAsync(&nbig, d_nbig, 4, hipMemcpyDeviceToHost, st));
-            VP_HIP(hipStreamSynchronize(st));
-            if (nbig <= cap) break;
-            cap = nbig;
+        // work-queue size of the previous call, if its copy has landed (never waited for)
+        if (ctx->vox_total_event && ctx->vox_total_pending && hipEventQuery(ctx->vox_total_event) == hipSuccess) {
+            ctx->vox_total_pending = false;
+            ctx->vox_total_seen = std::max<uint64_t>(ctx->vox_total_seen, *ctx->vox_total_host);
+        }
+        const size_t want = std::max<size_t>((size_t)1 << 20, (size_t)ctx->vox_total_seen + ctx->vox_total_seen / 4);
+        VP_TRY(reserve(ctx, ctx->pairs, want * 4));
+        VP_TRY(reserve(ctx, ctx->rec, ntris * (size_t)kRecDwords * 4));   // only the records of large triangles are ever touched
+        uint4* rec = (uint4*)ctx->rec.ptr;
+        uint32_t* pairs = (uint32_t*)ctx->pairs.ptr;
+        uint32_t pcap = (uint32_t)std::min<size_t>(ctx->pairs.bytes / 4, 0xFFFFFFFFu);
+        if (const char* e = getenv("VP_VOX_QUEUE_CAP")) pcap = std::min<uint32_t>(pcap, (uint32_t)strtoul(e, nullptr, 10));   // tests: force the overflow path
+        VP_HIP(hipMemsetAsync(cnt, 0, ((size_t)numTiles + 1) * 4, st));
+        {
+            ProfScope p(ctx, VP_K_VOX_SETUP);
+            hipLaunchKernelGGL(vox_setup, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, rec, (uint32_t)ntris,
+                               d_nbig, cnt, tog);
+        }
+        {
+            ProfScope p(ctx, VP_K_VOX_SCAN);
+            hipLaunchKernelGGL(vox_scan, dim3(1), dim3(1024), 0, st, cnt, numTiles, off, cur);
+        }
+        if (!ctx->vox_total_host) {
+            VP_HIP(hipHostMalloc((void**)&ctx->vox_total_host, sizeof(uint32_t), hipHostMallocDefault));
+            *ctx->vox_total_host = 0;
+            VP_HIP(hipEventCreateWithFlags(&ctx->vox_total_event, hipEventDisableTiming));
+        }
+        if (!ctx->vox_total_pending) {                             // lazily: the next call may grow the queue from it
+            VP_HIP(hipMemcpyAsync(ctx->vox_total_host, off + numTiles, 4, hipMemcpyDeviceToHost, st));
+            VP_HIP(hipEventRecord(ctx->vox_total_event, st));
+            ctx->vox_total_pending = true;
+        }
+        {
+            ProfScope p(ctx, VP_K_VOX_SCATTER);
+            hipLaunchKernelGGL(vox_scatter, dim3(std::min<unsigned>(tblocks, 1024u)), dim3(256), 0, st, f, rec, d_nbig, cur, pairs, pcap);
+        }
+        {
+            ProfScope p(ctx, VP_K_VOX_TILE);
+            hipLaunchKernelGGL(vox_tile, dim3(numTiles), dim3(256), 0, st, f, rec, d_nbig, off, pairs, pcap, tog);
         }
     }
-    if (total == 0) {                                              // nothing binned: plain streaming fill
-        VP_TRY(launch_fill(ctx, f, tog, d_words, accumulate));
-        VP_HIP(hipGetLastError());
-        return 0;
-    }
-    VP_TRY(reserve(ctx, ctx->pairs, (size_t)total * 4));
-    uint32_t* pairs = (uint32_t*)ctx->pairs.ptr;
-    {
-        ProfScope p(ctx, VP_K_VOX_SCATTER);
-        hipLaunchKernelGGL(vox_scatter, dim3((nbig + 255) / 256), dim3(256), 0, st, f, rec, (size_t)nbig, cur, pairs, total);
-    }
-    {
-        ProfScope p(ctx, VP_K_VOX_TILE);
-        if (accumulate)
-            hipLaunchKernelGGL(vox_tile<true>, dim3(numTiles), dim3(256), 0, st, f, rec, off, pairs, tog, d_words);
-        else
-            hipLaunchKernelGGL(vox_tile<false>, dim3(numTiles), dim3(256), 0, st, f, rec, off, pairs, tog, d_words);
-    }
+    VP_TRY(launch_fill(ctx, f, tog, d_words, accumulate));
     VP_HIP(hipGetLastError());
     return 0;
 }

@@ -45,6 +45,13 @@ struct vp_ctx {
     hipStream_t stream = nullptr;
     // grow-only workspaces
     vp::Buffer rec, tile_cnt, tile_off, tile_cur, pairs, scratch, none_row;
+    vp::Buffer jfa_work;                       // vp_jfa* with d_work = NULL: two id volumes + border mask
+    vp::Buffer slots[VP_WORKSPACE_SLOTS];      // vp_ctx_workspace
+    // voxelizer: work-queue size of an earlier call, copied back lazily (never waited for) to size the next call's queue
+    uint32_t* vox_total_host = nullptr;
+    hipEvent_t vox_total_event = nullptr;
+    bool vox_total_pending = false;
+    uint64_t vox_total_seen = 0;
     // profiling
     bool prof_on = false;
     std::vector<vp::ProfSpan> prof_pending;
@@ -71,6 +78,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     } while (0)
 
 int reserve(vp_ctx* ctx, Buffer& b, size_t bytes);
+void release(Buffer& b);
 
 // RAII-less profiling bracket: begin() before the launch, end() after.
 struct ProfScope {

@@ -4,6 +4,8 @@
 #ifndef VPLIB_RUNTIME_H
 #define VPLIB_RUNTIME_H
 
+#include <string>
+
 #include "vphip.h"
 
 namespace vplib {
@@ -16,6 +18,14 @@ vp_ctx* Context();
 
 // Destroys the context (optional; also done at process exit).
 void Shutdown();
+
+// Workspace slots of the shared context (vp_ctx_workspace) the Compute() wrappers keep their device buffers in.
+enum { kSlotGridA = 0, kSlotGridB = 1, kSlotXyz = 2, kSlotTri = 3, kSlotSdf = 4 };
+
+// PROFILING builds: prints the device time (hipEvents, vp_prof_*) of every kernel that ran since the last vp_prof_reset as
+// "# device-time <label> <kernel> <ms> ms <n> launches" lines.  Deliberately NOT the "[label]: x ms" grammar of
+// PROFILING_SCOPE (profiling.h): parsers of the reference's benchmark contract must not see extra columns.
+void PrintDeviceTimes(const std::string& label);
 
 }  // namespace vplib
 

@@ -38,8 +38,8 @@ void Device(uint32_t* a, const uint32_t* b, size_t n, int op)
     void *da = nullptr, *db = nullptr;
     {
         PROFILING_SCOPE("NaiveCSG::Memory");
-        gpuAssert(vp_malloc(ctx, n * 4, &da));
-        gpuAssert(vp_malloc(ctx, n * 4, &db));
+        gpuAssert(vp_ctx_workspace(ctx, vplib::kSlotGridA, n * 4, &da));     // cached by the context
+        gpuAssert(vp_ctx_workspace(ctx, vplib::kSlotGridB, n * 4, &db));
         gpuAssert(vp_upload(ctx, da, a, n * 4));
         gpuAssert(vp_upload(ctx, db, b, n * 4));
     }
@@ -51,8 +51,6 @@ void Device(uint32_t* a, const uint32_t* b, size_t n, int op)
     {
         PROFILING_SCOPE("NaiveCSG::Memory");
         gpuAssert(vp_download(ctx, a, da, n * 4));
-        gpuAssert(vp_free(ctx, da));
-        gpuAssert(vp_free(ctx, db));
     }
 }
 

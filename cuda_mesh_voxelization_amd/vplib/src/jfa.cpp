@@ -113,6 +113,9 @@ void Host(bool parallel, const uint32_t* words, size_t n, float vs, const float 
 
 void Device(int algo, const char* label, const uint32_t* words, size_t n, float vs, const float origin[3], float* sdf)
 {
+    // Same launch sequence as vp_jfa (what the benchmark times): border mask, first pass straight from it, sparse / dense
+    // tile passes, last pass fused with the id -> sdf conversion -- split at the point where the reference splits its
+    // timers (jfa/tiled.cu:265-334).  Device buffers are the context's cached workspace: no allocation in steady state.
     const std::string L(label);
     PROFILING_SCOPE(L);
     vp_ctx* ctx = vplib::Context();
@@ -125,36 +128,34 @@ void Device(int algo, const char* label, const uint32_t* words, size_t n, float 
     float fill = -INFINITY;
     for (size_t i = 0; i < voxels; ++i)
         if (!((words[i >> 5] >> (i & 31)) & 1u)) { fill = sdf[i]; break; }
-    void *dWords = nullptr, *dSdf = nullptr, *dWork = nullptr;
+    void *dWords = nullptr, *dSdf = nullptr;
     {
         PROFILING_SCOPE(L + "::Memory");
-        gpuAssert(vp_malloc(ctx, gridBytes, &dWords));
-        gpuAssert(vp_malloc(ctx, voxels * sizeof(float), &dSdf));
-        gpuAssert(vp_malloc(ctx, vp_jfa_workspace_bytes(&f), &dWork));
+        gpuAssert(vp_ctx_workspace(ctx, vplib::kSlotGridA, gridBytes, &dWords));
+        gpuAssert(vp_ctx_workspace(ctx, vplib::kSlotSdf, voxels * sizeof(float), &dSdf));
         gpuAssert(vp_upload(ctx, dWords, words, gridBytes));
     }
-    char* a = static_cast<char*>(dWork);                           // two opaque id volumes
-    char* b = a + voxels * vp_jfa_id_bytes(&f);
+#if PROFILING
+    gpuAssert(vp_prof_reset(ctx));
+    gpuAssert(vp_prof_enable(ctx, 1));
+#endif
     {
         PROFILING_SCOPE(L + "::Initialization");
-        gpuAssert(vp_jfa_init(ctx, &f, static_cast<const uint32_t*>(dWords), nullptr, nullptr, a));
+        gpuAssert(vp_jfa_start(ctx, &f, static_cast<const uint32_t*>(dWords), nullptr, 0, algo));
         gpuAssert(vp_ctx_sync(ctx));
     }
     {
         PROFILING_SCOPE(L + "::Processing");
-        for (uint32_t k = f.n / 2; k >= 1; k /= 2) {
-            gpuAssert(vp_jfa_pass(ctx, &f, k, a, nullptr, nullptr, b, algo));
-            std::swap(a, b);
-        }
-        gpuAssert(vp_jfa_finalize(ctx, &f, static_cast<const uint32_t*>(dWords), a, fill, static_cast<float*>(dSdf)));
+        gpuAssert(vp_jfa_run(ctx, &f, static_cast<const uint32_t*>(dWords), fill, static_cast<float*>(dSdf), nullptr, 0, algo));
         gpuAssert(vp_ctx_sync(ctx));
     }
+#if PROFILING
+    gpuAssert(vp_prof_enable(ctx, 0));
+    vplib::PrintDeviceTimes(L);
+#endif
     {
         PROFILING_SCOPE(L + "::Memory");
         gpuAssert(vp_download(ctx, sdf, dSdf, voxels * sizeof(float)));
-        gpuAssert(vp_free(ctx, dWords));
-        gpuAssert(vp_free(ctx, dSdf));
-        gpuAssert(vp_free(ctx, dWork));
     }
 }
 

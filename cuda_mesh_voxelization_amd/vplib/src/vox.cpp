@@ -91,9 +91,9 @@ void Device(int algo, const char* label, uint32_t* words, size_t n, float vs, co
     void *dWords = nullptr, *dXyz = nullptr, *dTri = nullptr;
     {
         PROFILING_SCOPE(L + "::Memory");
-        gpuAssert(vp_malloc(ctx, gridBytes, &dWords));
-        gpuAssert(vp_malloc(ctx, nverts * sizeof(Position), &dXyz));
-        gpuAssert(vp_malloc(ctx, ntris * 3 * sizeof(uint32_t), &dTri));
+        gpuAssert(vp_ctx_workspace(ctx, vplib::kSlotGridA, gridBytes, &dWords));     // cached by the context: no allocation in steady state
+        gpuAssert(vp_ctx_workspace(ctx, vplib::kSlotXyz, nverts * sizeof(Position), &dXyz));
+        gpuAssert(vp_ctx_workspace(ctx, vplib::kSlotTri, ntris * 3 * sizeof(uint32_t), &dTri));
         gpuAssert(vp_upload(ctx, dXyz, mesh.Coords.data(), nverts * sizeof(Position)));
         gpuAssert(vp_upload(ctx, dTri, mesh.FacesCoords.data(), ntris * 3 * sizeof(uint32_t)));
     }
@@ -124,9 +124,6 @@ void Device(int algo, const char* label, uint32_t* words, size_t n, float vs, co
     {
         PROFILING_SCOPE(L + "::Memory");
         gpuAssert(vp_download(ctx, words, dWords, gridBytes));
-        gpuAssert(vp_free(ctx, dWords));
-        gpuAssert(vp_free(ctx, dXyz));
-        gpuAssert(vp_free(ctx, dTri));
     }
 }
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 1
+#define VP_ABI_VERSION 2
 
 enum {
     VP_OK = 0,
@@ -74,6 +74,15 @@ int vp_abi_version(void);
 int vp_malloc(vp_ctx* ctx, size_t bytes, void** d_out);
 int vp_free(vp_ctx* ctx, void* d_ptr);
 int vp_memset(vp_ctx* ctx, void* d_ptr, int byte_value, size_t bytes);           /* async */
+/* CudaPtr's copy constructor / assignment: device-to-device deep copy (cuda_ptr.h:42-53).  async */
+int vp_memcpy_d2d(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* Context-owned scratch: slot in [0, VP_WORKSPACE_SLOTS), grow-only, valid until the next call for the same slot
+ * with a larger size, vp_ctx_release or vp_ctx_destroy.  What the Compute() wrappers use instead of the reference's
+ * per-call cudaMalloc/cudaFree (vox/tiled.cu:496-575 allocates ~15 buffers per call). */
+#define VP_WORKSPACE_SLOTS 8
+int vp_ctx_workspace(vp_ctx* ctx, int slot, size_t bytes, void** d_out);
+/* Frees every workspace slot and the JFA workspace (synchronises). */
+int vp_ctx_release(vp_ctx* ctx);
 int vp_upload(vp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);        /* blocking */
 int vp_download(vp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);      /* blocking */
 
@@ -90,7 +99,7 @@ size_t vp_grid_voxels(const vp_frame* f);
  *   d_tri   ntris x 3 uint32  (Mesh::FacesCoords; ntris = indices/3 as in sequential.cpp:16)
  *   accumulate = 0: d_words is overwritten (GPU variants of the reference replace the grid,
  *                   vox/tiled.cu:572-575); 1: XOR into the existing words (sequential semantics).
- * Synchronises the stream once internally (work-queue size read-back) when algo = TILED. */
+ * Fully asynchronous: list sizes stay on the device (no read-back, no stream synchronisation). */
 int vp_voxelize(vp_ctx* ctx, const vp_frame* f, uint32_t* d_words,
                 const float* d_xyz, size_t nverts, const uint32_t* d_tri, size_t ntris,
                 int algo, int accumulate);
@@ -106,19 +115,26 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
  * the sequential path (jfa/sequential.cpp:7-127): signed SQUARED distance, +inside, -outside.
  *
  * State between passes is one packed id per voxel: the coordinates of the nearest seed found so far
- * (vp_jfa_id_bytes(f) = 4 bytes for n <= 1024, 8 bytes for n <= 2048; all ones = none) instead of the
+ * (vp_jfa_id_bytes(f) = 4 bytes for n <= 1024, 8 bytes for n <= 2048) instead of the
  * reference's float sdf + float3 position; distances are recomputed from it with the reference's
  * expressions.  Id buffers are opaque (void*): vp_grid_voxels(f) * vp_jfa_id_bytes(f) bytes per volume.
  *
  * vp_jfa runs init + all passes + finalize on one device for a whole-grid frame.
  *   fill_unset  value the caller pre-filled the sdf with (apps/cli/main.cpp:200 uses -INFINITY);
  *               must be +-infinity (a finite fill is undefined behaviour in the reference).
- *   d_work      scratch of vp_jfa_workspace_bytes(f) bytes (two id volumes + border mask).
+ *   d_work      scratch of vp_jfa_workspace_bytes(f) bytes (two id volumes + border mask), or NULL: the
+ *               context then keeps a grow-only workspace of its own (work_bytes ignored).
  *   algo        VP_ALGO_NAIVE: direct kernel; VP_ALGO_TILED: LDS-table kernel.  Same results. */
 size_t vp_jfa_workspace_bytes(const vp_frame* f);
 size_t vp_jfa_id_bytes(const vp_frame* f);
 int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
            float* d_sdf, void* d_work, size_t work_bytes, int algo);
+/* vp_jfa in the two parts the reference times separately ("::Initialization" = seeding, jfa/tiled.cu:265-290;
+ * "::Processing" = the passes, jfa/tiled.cu:292-334): vp_jfa == vp_jfa_start + vp_jfa_run on the same workspace.
+ * This is the sequence JFA::Compute<NAIVE|TILED> and the CLI run -- the same kernels the benchmark times. */
+int vp_jfa_start(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void* d_work, size_t work_bytes, int algo);
+int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
+               float* d_sdf, void* d_work, size_t work_bytes, int algo);
 
 /* The three stages separately, for Z-slab sharding (halo exchange happens between calls).
  * Halo pointers may be NULL where the slab touches the global boundary.
@@ -166,7 +182,14 @@ int vp_jfa_host(vp_ctx* ctx, const vp_frame* f, const uint32_t* h_words, float f
  * When enabled, every kernel launch is bracketed by hipEvents on the context's stream. */
 enum {
     VP_K_VOX_SETUP = 0, VP_K_VOX_SCAN, VP_K_VOX_SCATTER, VP_K_VOX_TILE, VP_K_VOX_NAIVE,
-    VP_K_VOX_FILL, VP_K_CSG, VP_K_JFA_INIT, VP_K_JFA_PASS, VP_K_JFA_FINAL, VP_K_SURFACE,
+    VP_K_VOX_FILL, VP_K_CSG, VP_K_JFA_INIT,
+    VP_K_JFA_PASS,      /* direct kernel (VP_ALGO_NAIVE) and the small-grid table kernel (n < 256) */
+    VP_K_JFA_FINAL, VP_K_SURFACE,
+    /* the tile kernels of VP_ALGO_TILED (n >= 256), one key per variant -- their algorithmic bytes differ: */
+    VP_K_JFA_FIRST,     /* k = n/2 straight from the border mask: 4 n^3 + n^3/8 bytes (S = 4) */
+    VP_K_JFA_SPARSE,    /* k >= n/4: 2 S n^3 */
+    VP_K_JFA_DENSE,     /* k <  n/4: 2 S n^3 */
+    VP_K_JFA_LAST,      /* k = 1 fused with the id -> sdf conversion: S n^3 + 4 n^3 + n^3/8 */
     VP_K_COUNT
 };
 int vp_prof_enable(vp_ctx* ctx, int on);

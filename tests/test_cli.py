@@ -139,3 +139,54 @@ def test_cli_export_meshes(cli, tmp_path):
     cubes_xyz, cubes_tri = M.import_mesh(str(out / "sdf_sequential_res.obj"))
     finite_set = int((occ.reshape(-1) & np.isfinite(sdf)).sum())
     assert cubes_xyz.shape[0] == 8 * finite_set and cubes_tri.shape[0] == 12 * finite_set
+
+
+@pytest.mark.gpu
+def test_cli_runs_the_benchmarked_kernel_sequence(cli, engine, tmp_path):
+    """JFA::Compute<TILED> (what `vpcli -t 2 -s` calls) runs the SAME launch sequence as vp_jfa, which bench.py times:
+    border mask, first pass from the mask, sparse / dense tile passes, fused last pass -- same kernels, same launch
+    counts, device time within 5 % (read from vp_prof in both processes)."""
+    import math
+    import torch
+    from cuda_mesh_voxelization_amd.capi import ALGO_TILED, Frame
+    n = 512
+    p, _ = _run(cli, [M.asset("bunny.obj"), "-n", str(n), "-t", "2", "-s", "-m", "4"], tmp_path, dump=False)
+    assert p.returncode == 0, p.stdout + p.stderr
+    runs = []                                             # one dict per JFA::Compute call: kernel -> (ms, launches)
+    cur = {}
+    for line in p.stdout.splitlines():
+        if line.startswith("# device-time TiledJFA "):
+            _, _, _, kern, ms, _, cnt, _ = line.split()
+            cur[kern] = (float(ms), int(cnt))
+        elif line.startswith("[TiledJFA]:"):
+            runs.append(cur); cur = {}
+    assert len(runs) == 4
+    want = {"surface": 1, "jfa_first": 1, "jfa_sparse": 1, "jfa_dense": 6, "jfa_last": 1}
+    for r in runs:
+        assert {k: c for k, (_, c) in r.items()} == want, r
+    cli_ms = min(sum(ms for ms, _ in r.values()) for r in runs[1:])
+
+    xyz, tri = M.import_mesh(M.asset("bunny.obj"))
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    g = engine.voxelize(fr, dx, dt, algo=ALGO_TILED)
+    sdf = torch.empty(fr.voxels, dtype=torch.float32, device=engine.device)
+    best = math.inf
+    words = engine.words_to_numpy(g)
+    for i in range(4):
+        # same conditions as one JFA::Compute call of the CLI: grid upload before, stream sync after the seeding stage,
+        # sdf download after (the idle gaps matter: the chip drops its clock between bursts of work)
+        g.copy_(torch.from_numpy(words.view(np.int32)))
+        engine.ctx.prof_reset(); engine.ctx.prof_enable(True)
+        engine.ctx.jfa_start(fr, g.data_ptr(), None, 0, ALGO_TILED)
+        engine.sync()
+        engine.ctx.jfa_run(fr, g.data_ptr(), -math.inf, sdf.data_ptr(), None, 0, ALGO_TILED)
+        engine.sync()
+        engine.ctx.prof_enable(False)
+        sdf.cpu()
+        pr = engine.ctx.prof()
+        assert {k: v["launches"] for k, v in pr.items()} == want
+        if i:
+            best = min(best, sum(v["ms"] for v in pr.values()))
+    assert abs(cli_ms - best) <= 0.05 * best, (cli_ms, best)

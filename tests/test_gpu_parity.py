@@ -100,6 +100,48 @@ def test_voxelize_empty_and_degenerate(engine):
         assert np.array_equal(got, exp)
 
 
+def test_voxelize_work_queue_overflow_path(engine, monkeypatch):
+    """The tile stage sizes nothing on the host: a tile whose slice of the work queue does not fit scans the record list
+    itself.  Force that path (VP_VOX_QUEUE_CAP) on meshes made of large triangles and on a mixed one."""
+    for name, n in (("d20.obj", 128), ("torus.obj", 256), ("sphere.obj", 160)):
+        xyz, tri = M.import_mesh(M.asset(name))
+        origin, vs = M.frame([xyz], n)
+        fr = Frame.make(n, vs, origin)
+        exp = O.voxelize(xyz, tri, n, vs, origin)
+        dx, dt = engine.mesh_to_device(xyz, tri)
+        for cap in ("0", "7", "100"):
+            monkeypatch.setenv("VP_VOX_QUEUE_CAP", cap)
+            got = engine.words_to_numpy(engine.voxelize(fr, dx, dt, algo=ALGO_TILED))
+            assert np.array_equal(got, exp), (name, n, cap)
+        monkeypatch.delenv("VP_VOX_QUEUE_CAP")
+        got = engine.words_to_numpy(engine.voxelize(fr, dx, dt, algo=ALGO_TILED))
+        assert np.array_equal(got, exp), (name, n)
+
+
+def test_jfa_start_run_equals_jfa(engine):
+    """vp_jfa == vp_jfa_start + vp_jfa_run (the split the C++ JFA::Compute uses for its Initialization / Processing timers),
+    with the caller's workspace and with the context's own."""
+    import torch
+    for name, n in (("bunny.obj", 64), ("bunny.obj", 256)):
+        xyz, tri = M.import_mesh(M.asset(name))
+        origin, vs = M.frame([xyz], n)
+        fr = Frame.make(n, vs, origin)
+        dx, dt = engine.mesh_to_device(xyz, tri)
+        g = engine.voxelize(fr, dx, dt)
+        for algo in (ALGO_TILED, ALGO_NAIVE):
+            ref = engine.jfa(fr, g, algo=algo).clone()
+            out = torch.full_like(ref, 7.0)
+            engine.ctx.jfa_start(fr, g.data_ptr(), None, 0, algo)
+            engine.ctx.jfa_run(fr, g.data_ptr(), -math.inf, out.data_ptr(), None, 0, algo)
+            assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+            nb = engine.ctx.jfa_workspace_bytes(fr)
+            work = torch.empty(nb, dtype=torch.uint8, device=engine.device)
+            out.fill_(7.0)
+            engine.ctx.jfa_start(fr, g.data_ptr(), work.data_ptr(), nb, algo)
+            engine.ctx.jfa_run(fr, g.data_ptr(), -math.inf, out.data_ptr(), work.data_ptr(), nb, algo)
+            assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+
+
 @pytest.mark.parametrize("op", [1, 2, 3, 0])
 def test_csg_matches_oracle(engine, op):
     rng = np.random.default_rng(op)
