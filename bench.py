@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mvoxels/s of (voxelize + JFA) at n = 512 on the 1,348,128-face bunny.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n {512,1024,2048}]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = tiled voxelization of the resident mesh into a bit-packed 512^3 grid followed by the
-full JFA (init + 9 passes + finalize) into a float sdf -- both through the C ABI of libvphip.so,
-inputs already in HBM.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+One "step" = tiled voxelization of the resident mesh into a bit-packed n^3 grid followed by the full JFA
+(border mask, first pass from the mask, sparse / dense tile passes, last pass fused with the id -> sdf
+conversion) into a float sdf -- both through the C ABI of libvphip.so, inputs already in HBM.
+Rank 0 prints ONE JSON line (DESIGN.md "Measurement"):
 
-N > 1: strong scaling of the same 512^3 job over N Z-slabs, one process per GPU.  Default: ghost planes are
-recomputed instead of exchanged (a plane costs ~1.6 us to recompute and ~20 us to move over xGMI);
---multi halo selects the RCCL point-to-point halo exchange.
+  value / ms_per_step   whole job, wall clock between barriers, max over ranks
+  roofline              the DOMINANT kernel only: the dense tile pass (jfa_dense), its own algorithmic bytes
+                        (2 * S * n^3) / its own mean launch time from hipEvents on the kernel's stream
+  kernels               every kernel of the step: launches per step, mean ms, algorithmic bytes, GB/s, fraction of peak
+  n1024                 (N = 1, default size only) the same JFA at n = 1024, where the north star puts its roofline target
+  cpu_baseline          the oracle (C restatement of the reference's sequential path) on the box's host cores:
+                        1-thread voxelize + OpenMP JFA with ALL passes -- measured, not extrapolated
+
+N > 1: strong scaling of the same n^3 job over N Z-slabs, one process per GPU (cuda_mesh_voxelization_amd/slab.py).
 """
 from __future__ import annotations
 
@@ -31,32 +38,83 @@ import torch  # noqa: E402
 N_GRID = 512
 REFINE = 24                      # 56,172 * 24 = 1,348,128 faces (benchmarks_v2/bunny_1348128)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-STATE_BYTES = 4                  # JFA state per voxel as implemented (packed seed id)
+HBM_ACHIEVABLE_GBS = 6290.0      # same guide: float4 copy, 79 % of spec
 BASELINE_MVOX = 480.0            # reference tiled vox+JFA, n=512, kernels only (derived from its CSVs)
 
 
-def cpu_baseline(xyz, tri, origin, vs):
-    """Oracle (C restatement of the reference's sequential path, OpenMP over the host cores) on a
-    bounded sample of the same workload: the full voxelization, the JFA initialisation and the first
-    two of the nine JFA passes at n = 512; pass time is extrapolated to nine passes."""
+def kernel_bytes(n, planes, S, ntris, nverts):
+    """Algorithmic bytes per launch (every array once per kernel that must touch it; S = id bytes)."""
+    vox = n * n * planes
+    return {
+        "vox_setup": 12 * ntris + 12 * nverts, "vox_scan": 0, "vox_scatter": 0, "vox_tile": 0, "vox_naive": 12 * ntris + 12 * nverts,
+        "vox_fill": 2 * vox // 8, "csg_words": 3 * vox // 8,
+        "surface": 2 * vox // 8, "jfa_init": vox // 8 + S * vox,
+        "jfa_first": S * vox + vox // 8,                 # pure store stream + the border mask
+        "jfa_sparse": 2 * S * vox, "jfa_dense": 2 * S * vox, "jfa_pass": 2 * S * vox,
+        "jfa_last": S * vox + 4 * vox + vox // 8,        # ids in, floats out, bitmask in
+        "jfa_final": S * vox + 4 * vox + vox // 8,
+    }
+
+
+def kernel_table(prof, steps, bytes_per):
+    out = {}
+    for k, v in prof.items():
+        ms = v["ms"] / max(v["launches"], 1)
+        b = bytes_per.get(k, 0)
+        gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[k] = {"launches_per_step": round(v["launches"] / steps, 2), "avg_ms": round(ms, 4), "ms_per_step": round(v["ms"] / steps, 4),
+                  "bytes": int(b), "GB/s": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def cpu_baseline(xyz, tri, origin, vs, n):
+    """Oracle on the host cores, the whole job: sequential voxelize (1 thread = the reference's -t 0 semantics) and the
+    JFA with every pass under OpenMP (the reference's -t 3).  ~10-30 s on the GPU box's host."""
     from oracle import oracle as O
-    n = N_GRID
     t0 = time.perf_counter()
     words = O.voxelize(xyz, tri, n, vs, origin)
     t_vox = time.perf_counter() - t0
     t0 = time.perf_counter()
-    O.jfa(words, n, vs, origin, max_passes=0)
-    t_init = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.jfa(words, n, vs, origin, max_passes=2)
-    t_two = time.perf_counter() - t0 - t_init
-    passes = int(math.log2(n))
-    est = t_vox + t_init + max(t_two, 0.0) * passes / 2.0
+    O.jfa(words, n, vs, origin)
+    t_jfa = time.perf_counter() - t0
     return {
-        "value": round(n ** 3 / est / 1e6, 3), "unit": "Mvoxels/s", "cores": O.threads(), "kind": "port",
-        "sample": "n=512 bunny 1,348,128 faces: full sequential voxelize (%.2fs, 1 thread) + JFA init (%.2fs) + first 2 of %d "
-                  "passes (%.2fs) with OpenMP; pass time extrapolated x%d/2" % (t_vox, t_init, passes, t_two, passes),
+        "value": round(n ** 3 / (t_vox + t_jfa) / 1e6, 3), "unit": "Mvoxels/s", "cores": O.threads(), "kind": "port",
+        "voxelize_s_1thread": round(t_vox, 3), "jfa_s_openmp": round(t_jfa, 3),
+        "sample": "n=%d bunny %d faces, the whole step: sequential voxelize on 1 thread (%.2f s) + JFA init and all %d passes with "
+                  "OpenMP on %d threads (%.2f s); nothing extrapolated" % (n, tri.shape[0], t_vox, int(math.log2(n)), O.threads(), t_jfa),
     }
+
+
+def profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
+
+
+def run_single(eng, frame, d_xyz, d_tri, steps, warmup, algo):
+    grid = eng.new_grid(frame)
+    sdf = torch.empty(frame.voxels, dtype=torch.float32, device=eng.device)
+
+    def step():
+        eng.voxelize(frame, d_xyz, d_tri, out=grid, algo=algo)
+        eng.jfa(frame, grid, out=sdf, algo=algo)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.ctx.prof_reset()
+    eng.ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.ctx.prof_enable(False)
+    return elapsed, eng.ctx.prof()
 
 
 def main():
@@ -64,19 +122,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_GRID, choices=[256, 512, 1024, 2048],
+                    help="grid side; 512 = the headline configuration, 1024 / 2048 = the sizes the north star shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-n1024", action="store_true", help="skip the extra n = 1024 JFA block of the default run")
     ap.add_argument("--multi", choices=["ghost", "halo"], default="ghost",
-                    help="N > 1: 'ghost' = communication-free Z-slabs with recomputed ghost planes (default); "
-                         "'halo' = Z-slabs with RCCL point-to-point halo exchange between JFA passes")
-    ap.add_argument("--n", type=int, default=N_GRID, help=argparse.SUPPRESS)
+                    help="N > 1: 'ghost' = Z-slabs with recomputed ghost planes, no data-path exchange (default: a plane costs ~1 us "
+                         "to recompute and ~20 us to move over xGMI); 'halo' = Z-slabs with RCCL point-to-point halo planes before every pass")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
 
     from cuda_mesh_voxelization_amd import mesh as M
@@ -91,29 +150,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n = args.n
-    xyz, tri = M.bunny(REFINE)
+    refine = REFINE if n <= 1024 else 192                  # n = 2048: the 10,785,024-face mesh of BASELINE config 5
+    xyz, tri = M.bunny(refine)
     origin, vs = M.frame([xyz], n)
     frame = Frame.make(n, vs, origin)
     eng = Engine(local_rank)
     d_xyz, d_tri = eng.mesh_to_device(xyz, tri)
-
-    if world == 1:
-        grid = eng.new_grid(frame)
-        sdf = torch.empty(frame.voxels, dtype=torch.float32, device=eng.device)
-
-        def step():
-            eng.voxelize(frame, d_xyz, d_tri, out=grid, algo=ALGO_TILED)
-            eng.jfa(frame, grid, out=sdf, algo=ALGO_TILED)
-    else:
-        from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline, HipSlabBackend, SlabPipeline
-        if args.multi == "ghost":
-            pipe = GhostSlabPipeline(HipSlabBackend(eng), frame, rank, world)
-        else:
-            pipe = SlabPipeline(HipSlabBackend(eng), frame, rank, world, dist)
-
-        def step():
-            pipe.voxelize(d_xyz, d_tri, algo=ALGO_TILED)
-            pipe.jfa(algo=ALGO_TILED)
+    S = eng.ctx.jfa_id_bytes(frame)
+    passes = int(math.log2(n))
 
     def barrier():
         torch.cuda.synchronize()
@@ -121,60 +165,90 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    eng.ctx.prof_reset()
-    eng.ctx.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    eng.ctx.prof_enable(False)
-    prof = eng.ctx.prof()
+    pipe = None
+    if world == 1:
+        barrier()
+        elapsed, prof = run_single(eng, frame, d_xyz, d_tri, args.steps, args.warmup, ALGO_TILED)
+        planes = n
+    else:
+        from cuda_mesh_voxelization_amd.slab import make_pipeline
+        pipe = make_pipeline(args.multi, eng, frame, rank, world, dist)
 
-    if dist is not None:
+        def step():
+            pipe.voxelize(d_xyz, d_tri, algo=ALGO_TILED)
+            pipe.jfa(algo=ALGO_TILED)
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        eng.ctx.prof_reset()
+        eng.ctx.prof_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        eng.ctx.prof_enable(False)
+        prof = eng.ctx.prof()
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        planes = n // world
+        regs = getattr(pipe, "regions", None)
+        if regs:                                           # ghost planes: a dense pass covers the slab widened by the later steps
+            dense = [b1 - b0 for k, b0, b1 in regs if k * 4 < n and k > 1]
+            if dense:
+                planes = sum(dense) / len(dense)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n ** 3 / (elapsed / args.steps) / 1e6
-        passes = int(math.log2(n))
-        kp = prof.get("jfa_pass", {"ms": 0.0, "launches": 0})
-        # mean planes per jfa_pass launch on this rank (ghost mode widens the slab by the reach of later passes)
-        planes = pipe.planes_computed / passes if (world > 1 and args.multi == "ghost") else n // world
-        alg_bytes = int(2 * STATE_BYTES * n * n * planes)              # one id read + one id write per voxel
-        avg_ms = kp["ms"] / max(kp["launches"], 1)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "jfa_pass_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        bytes_per = kernel_bytes(n, planes, S, int(tri.shape[0]), int(xyz.shape[0]))
+        kernels = kernel_table(prof, args.steps, bytes_per)
+        dom = "jfa_dense" if "jfa_dense" in kernels else max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        kd = kernels[dom]
+        tj = profile_json("jfa_dense_traffic.json") or {}
+        traffic = tj.get("hbm_bytes_per_launch") if (n == N_GRID and world == 1) else None
         out = {
-            "metric": "Mvoxels/s (voxelize+JFA) at N=512, bunny 1.35M tris",
+            "metric": "Mvoxels/s (voxelize+JFA) at N=%d, bunny %.2fM tris" % (n, tri.shape[0] / 1e6),
             "value": round(value, 2), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong",        # the same 512^3 job for every N (N > 1 splits it into Z-slabs)
-            "vs_baseline": round(value / BASELINE_MVOX, 2), "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "bunny.obj refined x24 (1,348,128 faces, 680k verts) -> tiled solid voxelize into bit-packed "
-                                   "%d^3 grid + JFA sdf (init + %d passes + finalize), device-resident" % (n, passes),
-                       "n": n, "triangles": int(tri.shape[0]), "jfa_state_bytes": STATE_BYTES,
-                       "parallelism": "1 gpu" if world == 1 else ("z-slab x%d, ghost planes recomputed, no exchange" % world if args.multi == "ghost"
-                                                                   else "z-slab x%d, RCCL p2p halo exchange" % world),
+            "scaling": "strong",        # the same n^3 job for every N (N > 1 splits it into Z-slabs)
+            "vs_baseline": round(value / BASELINE_MVOX, 2) if n == N_GRID else None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "bunny.obj refined x%d (%d faces, %d verts) -> tiled solid voxelize into bit-packed %d^3 grid + JFA sdf "
+                                   "(border mask + %d passes, last one fused with id -> sdf), device-resident"
+                                   % (refine, tri.shape[0], xyz.shape[0], n, passes),
+                       "n": n, "triangles": int(tri.shape[0]), "jfa_state_bytes": S,
+                       "parallelism": "1 gpu" if world == 1 else pipe.describe(),
+                       "world_size_seen": world,
                        "baseline": "480 Mvoxels/s = reference tiled vox+JFA kernels-only at n=512 (BASELINE.md, unstated NVIDIA GPU)"},
-            "roofline": {"kernel": "jfa_pass", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4), "launches": kp["launches"]},
-            "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in prof.items()},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": kd["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kd["frac_of_peak"], "frac_of_achievable": round(kd["GB/s"] / HBM_ACHIEVABLE_GBS, 4),
+                         "achievable": HBM_ACHIEVABLE_GBS, "traffic": traffic,
+                         "bytes_per_launch": kd["bytes"], "avg_launch_ms": kd["avg_ms"], "launches": int(round(kd["launches_per_step"] * args.steps)),
+                         "valu_issue_frac": tj.get("valu_issue_frac") if traffic else None,
+                         "note": "the dense pass is VALU-issue bound, not HBM bound (DESIGN.md section 4): 27 exact candidate "
+                                 "evaluations per voxel; bytes = 2*S*n^2*planes"},
+            "kernels": kernels,
+            "kernels_ms_per_step": {k: v["ms_per_step"] for k, v in kernels.items()},
         }
+        if pipe is not None:
+            out["multi"] = pipe.report()
+        if world == 1 and n == N_GRID and not args.no_n1024:
+            # the north star's roofline target lives at n = 1024: same mesh, JFA only is what differs in cost per voxel
+            n2 = 1024
+            o2, v2 = M.frame([xyz], n2)
+            f2 = Frame.make(n2, v2, o2)
+            e2, p2 = run_single(eng, f2, d_xyz, d_tri, 3, 1, ALGO_TILED)
+            k2 = kernel_table(p2, 3, kernel_bytes(n2, n2, eng.ctx.jfa_id_bytes(f2), int(tri.shape[0]), int(xyz.shape[0])))
+            jfa_ms = sum(v["ms_per_step"] for k, v in k2.items() if k.startswith("jfa_") or k == "surface")
+            jfa_bytes = sum(v["bytes"] * v["launches_per_step"] for k, v in k2.items() if k.startswith("jfa_") or k == "surface")
+            out["n1024"] = {"ms_per_step": round(e2 / 3 * 1e3, 3), "Mvoxels/s": round(n2 ** 3 / (e2 / 3) / 1e6, 1), "jfa_ms": round(jfa_ms, 3),
+                            "jfa_GB/s": round(jfa_bytes / (jfa_ms * 1e-3) / 1e9, 1), "jfa_frac_of_peak": round(jfa_bytes / (jfa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "dense_pass_ms": k2.get("jfa_dense", {}).get("avg_ms"), "dense_frac_of_peak": k2.get("jfa_dense", {}).get("frac_of_peak"),
+                            "kernels": k2}
         if world == 1 and not args.no_cpu_baseline and n == N_GRID:
-            out["cpu_baseline"] = cpu_baseline(xyz, tri, origin, vs)
+            out["cpu_baseline"] = cpu_baseline(xyz, tri, origin, vs, n)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

@@ -145,6 +145,12 @@ class SlabPipeline:
         self.above = self.be.empty_u32(self.plane_words) if rank < world - 1 else None
         self.bytes_received = 0
 
+    def describe(self):
+        return "z-slab x%d, RCCL p2p halo exchange before every pass" % self.world
+
+    def report(self):
+        return {"pipeline": "halo", "slab_planes": self.nz, "bytes_received_total": int(self.bytes_received)}
+
     # -- stages ---------------------------------------------------------------------------
     def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
         out = self.words if out is None else out
@@ -259,6 +265,15 @@ class GhostSlabPipeline:
         self.planes_computed = sum(b1 - b0 for _, b0, b1 in self.regions)
         self.border = None
 
+    def describe(self):
+        return "z-slab x%d, ghost planes recomputed, no data-path exchange" % self.world
+
+    def report(self):
+        n, passes = self.global_frame.n, len(self.regions)
+        return {"pipeline": "ghost", "slab_planes": self.z1 - self.z0, "regions": [[k, b0, b1] for k, b0, b1 in self.regions],
+                "plane_passes_this_rank": int(self.planes_computed), "plane_passes_one_gpu": n * passes,
+                "work_ceiling_speedup": round(n * passes / self.planes_computed, 3), "bytes_exchanged": 0}
+
     def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
         out = self.words if out is None else out
         self.be.voxelize(self.global_frame, out, d_xyz, d_tri, algo)
@@ -293,3 +308,14 @@ class GhostSlabPipeline:
             self.be.jfa_pass_global(region, k, a, b, algo)
             a, b = b, a
         return out
+
+
+# =============================================================================================
+def make_pipeline(kind: str, engine, frame: Frame, rank: int, world: int, dist):
+    """bench.py / callers: 'ghost' (no exchange) or 'halo' (RCCL point-to-point halos) on the HIP backend."""
+    be = HipSlabBackend(engine)
+    if kind == "ghost":
+        return GhostSlabPipeline(be, frame, rank, world)
+    if kind == "halo":
+        return SlabPipeline(be, frame, rank, world, dist)
+    raise ValueError("unknown multi-GPU pipeline %r" % kind)
