@@ -160,6 +160,40 @@ def bunny(factor: int = 1):
     return xyz, tri
 
 
+def decimate_cluster(xyz, tri, cells: int = 24, seed: int = 80):
+    """Seeded vertex-cluster decimation (the reference's 3,510-face bunny is not in its repo; this is the
+    stand-in for BASELINE config 1).  Vertices are binned into a cells^3 lattice over the bounding cube, shifted by a
+    seeded fraction of a cell; every cluster collapses to its float64 mean rounded to float32; faces that lose a corner
+    and duplicate faces are dropped.  assets/bunny.obj, cells = 24, seed = 80 -> 1,747 vertices, 3,511 faces (the seed whose face count is closest to 3,510)."""
+    xyz = np.asarray(xyz, np.float32)
+    t = np.asarray(tri).astype(np.int64)
+    off = np.random.default_rng(seed).random(3).astype(np.float32)
+    mn = xyz.min(axis=0)
+    side = np.float32((xyz.max(axis=0) - mn).max())
+    q = np.floor((xyz - mn) / (side / np.float32(cells)) + off).astype(np.int64)
+    key = (q[:, 2] * (cells + 2) + q[:, 1]) * (cells + 2) + q[:, 0]
+    uniq, inv = np.unique(key, return_inverse=True)
+    acc = np.zeros((uniq.size, 3), np.float64)
+    np.add.at(acc, inv, xyz.astype(np.float64))
+    cnt = np.bincount(inv, minlength=uniq.size)[:, None]
+    nxyz = (acc / cnt).astype(np.float32)
+    t = inv[t]
+    t = t[(t[:, 0] != t[:, 1]) & (t[:, 1] != t[:, 2]) & (t[:, 0] != t[:, 2])]
+    srt = np.sort(t, axis=1)
+    _, first = np.unique(srt[:, 0] * (1 << 40) + srt[:, 1] * (1 << 20) + srt[:, 2], return_index=True)
+    t = t[np.sort(first)]
+    return np.ascontiguousarray(nxyz, np.float32), np.ascontiguousarray(t, np.uint32)
+
+
+@functools.lru_cache(maxsize=1)
+def bunny_decimated():
+    """BASELINE config 1 stand-in: assets/bunny.obj decimated to ~3.5 k faces (see decimate_cluster)."""
+    xyz, tri = decimate_cluster(*import_mesh(asset("bunny.obj")))
+    xyz.setflags(write=False)
+    tri.setflags(write=False)
+    return xyz, tri
+
+
 def export_obj(path: str, xyz, tri):
     """Write `v`/`f a//a` lines with 9 significant digits (round-trips float32 through strtof)."""
     with open(path, "w") as f:

@@ -48,6 +48,17 @@ def test_cli_cpu_variants_match_golden(cli, golden_rows, tmp_path, t):
         _check_row(prefix, _row(golden_rows, meshes, n, op))
 
 
+def test_cli_config1_decimated_bunny_sequential(cli, tmp_path):
+    """BASELINE config 1 through the CLI: `vpcli <3,511-face bunny>.obj -n 64 -t 0` == the committed oracle grid."""
+    obj = str(tmp_path / "bunny_decimated.obj")
+    xyz, tri = M.bunny_decimated()
+    M.export_obj(obj, xyz, tri)
+    p, prefix = _run(cli, [obj, "-n", "64", "-t", "0"], tmp_path)
+    assert p.returncode == 0, p.stdout + p.stderr
+    exp = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bunny_decimated_n64.grid.u32"), np.uint32)
+    assert np.array_equal(np.fromfile(prefix + ".grid.u32", np.uint32), exp)
+
+
 def test_cli_timer_grammar_sequential(cli, tmp_path):
     p, _ = _run(cli, [M.asset("bimba.obj"), M.asset("bunny.obj"), "--num-voxels=32", "--type", "0", "-p1", "--sdf"], tmp_path, dump=False)
     assert p.returncode == 0

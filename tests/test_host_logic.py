@@ -90,4 +90,5 @@ def test_product_never_imports_oracle():
         for f in fs:
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
-                assert "oracle" not in txt.lower() or f == "__init__.py" and False, os.path.join(dp, f)
+                # the product path must never reach the CPU oracle: no import, include, dlopen or mention of it at all
+                assert "oracle" not in txt.lower(), os.path.join(dp, f)

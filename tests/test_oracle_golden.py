@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/vp_oracle.c) to the outputs of the reference's own sequential
 path recorded in tests/golden/survey_table.json."""
+import os
+
 import numpy as np
 import pytest
 
@@ -86,3 +88,17 @@ def test_empty_grid_sdf_keeps_fill():
     words = np.zeros(O.nwords(n), np.uint32)
     s = O.jfa(words, n, 1.0, np.zeros(3, np.float32))
     assert np.all(np.isneginf(s))
+
+
+def test_config1_decimated_bunny_fixture():
+    """BASELINE config 1: the oracle reproduces the committed n = 64 grid of the seeded 3,511-face decimation, and the mesh
+    generator is deterministic (tests/golden/make_bunny_decimated.py)."""
+    import json
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(gdir, "bunny_decimated_n64.json")))
+    exp = np.fromfile(os.path.join(gdir, "bunny_decimated_n64.grid.u32"), np.uint32)
+    xyz, tri = M.bunny_decimated()
+    assert [O.fnv(xyz), O.fnv(tri)] == meta["mesh_fnv"]
+    origin, vs = O.frame([xyz], 64)
+    got = O.voxelize(xyz, tri, 64, vs, origin)
+    assert np.array_equal(got, exp) and (O.popcount(got), O.fnv(got)) == tuple(meta["grid"])
