@@ -1,5 +1,8 @@
-// grid.h -- dense x-fastest 3-D array view + owning host wrapper
+// grid.h -- dense x-fastest 3-D array view + owning host and device wrappers
 // (/root/reference/vplib/src/grid/grid.h:22-230).  Index is 64-bit here (reference: 32-bit, :89-92).
+// DeviceGrid<T> owns its storage through DevicePtr<T> (device_ptr.h): copying is a device-to-device deep copy, Host <->
+// Device construction uploads / downloads, exactly the reference's conversions (:129-135, :184-201).  A Grid<T> obtained from
+// DeviceGrid::View() carries a DEVICE pointer: its shape accessors and Data() are usable on the host, element access is not.
 #ifndef VPLIB_GRID_H
 #define VPLIB_GRID_H
 
@@ -10,10 +13,13 @@
 #include <memory>
 #include <span>
 
+#include "device_ptr.h"
 #include "mesh/mesh.h"
 
 template <typename T>
 class HostGrid;
+template <typename T>
+class DeviceGrid;
 
 template <typename T>
 class Grid {
@@ -39,6 +45,7 @@ public:
     const T* Data() const { return mGrid.data(); }
 
     friend class HostGrid<T>;
+    friend class DeviceGrid<T>;
 };
 
 template <typename T>
@@ -60,6 +67,7 @@ public:
     {
         std::copy_n(o.mData.get(), o.mView.Size(), mData.get());
     }
+    HostGrid(const DeviceGrid<T>& device);                          // download (grid.h:129-135)
     HostGrid(HostGrid&& o) noexcept { swap(o); }
     HostGrid& operator=(HostGrid o) noexcept { swap(o); return *this; }
 
@@ -68,6 +76,47 @@ public:
 
     Grid<T>& View() { return mView; }
     const Grid<T>& View() const { return mView; }
+
+    friend class DeviceGrid<T>;
 };
+
+template <typename T>
+class DeviceGrid {
+    DevicePtr<T> mData;
+    Grid<T> mView;
+
+public:
+    DeviceGrid() = default;
+    DeviceGrid(size_t size) : DeviceGrid(size, size, size) {}
+    DeviceGrid(size_t sx, size_t sy, size_t sz) : mData(sx * sy * sz), mView(mData.get(), sx, sy, sz) {}
+    DeviceGrid(const HostGrid<T>& host)                              // upload (grid.h:184-191)
+        : mData(host.View().Data(), host.View().Size()), mView(mData.get(), host.View().SizeX(), host.View().SizeY(), host.View().SizeZ()) {}
+    DeviceGrid(const DeviceGrid& o) : mData(o.mData), mView(mData.get(), o.mView.SizeX(), o.mView.SizeY(), o.mView.SizeZ()) {}
+    DeviceGrid(DeviceGrid&& o) noexcept { swap(o); }
+    DeviceGrid& operator=(const DeviceGrid& o)
+    {
+        if (this == &o) return *this;
+        mData = o.mData;                                            // device-to-device
+        mView = Grid<T>(mData.get(), o.mView.SizeX(), o.mView.SizeY(), o.mView.SizeZ());
+        return *this;
+    }
+    DeviceGrid& operator=(DeviceGrid&& o) noexcept { swap(o); return *this; }
+
+    void swap(DeviceGrid& o) noexcept { mData.swap(o.mData); std::swap(mView, o.mView); }
+    friend void swap(DeviceGrid& a, DeviceGrid& b) noexcept { a.swap(b); }
+
+    Grid<T>& View() { return mView; }
+    const Grid<T>& View() const { return mView; }
+
+    friend class HostGrid<T>;
+};
+
+template <typename T>
+HostGrid<T>::HostGrid(const DeviceGrid<T>& device)
+    : mData(std::make_unique<T[]>(device.View().Size())),
+      mView(mData.get(), device.View().SizeX(), device.View().SizeY(), device.View().SizeZ())
+{
+    device.mData.CopyToHost(mData.get(), mView.Size());
+}
 
 #endif

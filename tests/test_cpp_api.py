@@ -12,17 +12,26 @@ from oracle import oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def api_check(tmp_path_factory):
+def _compile(tmp_path_factory, name):
     build.build_lib()
-    exe = str(tmp_path_factory.mktemp("cpp") / "api_check")
+    exe = str(tmp_path_factory.mktemp("cpp") / name)
     pkg = os.path.join(ROOT, "cuda_mesh_voxelization_amd")
     srcs = [os.path.join(pkg, "vplib", "src", f) for f in sorted(os.listdir(os.path.join(pkg, "vplib", "src"))) if f.endswith(".cpp")]
     subprocess.check_call(["g++", "-std=c++23", "-O2", "-ffp-contract=off", "-fopenmp",
                            "-I", os.path.join(pkg, "vplib", "include"), "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "api_check.cpp")] + srcs +
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp")] + srcs +
                           ["-o", exe, "-L", pkg, "-lvphip", "-Wl,-rpath," + pkg])
     return exe
+
+
+@pytest.fixture(scope="module")
+def api_check(tmp_path_factory):
+    return _compile(tmp_path_factory, "api_check")
+
+
+@pytest.fixture(scope="module")
+def device_types_check(tmp_path_factory):
+    return _compile(tmp_path_factory, "device_types_check")
 
 
 def _expected(name, n):
@@ -62,3 +71,17 @@ def test_cpp_api_gpu_variants(api_check):
     p = subprocess.run([api_check, M.asset("bunny.obj"), "64", "1"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     _check(p.stdout, ["seq32", "seq64", "omp32", "naive32", "naive64", "tiled32", "tiled64"], exp)
+
+
+def test_device_types_compile(device_types_check):
+    """User-style code naming VoxelsGrid<T, device>, DeviceVoxelsGrid, DeviceGrid, CudaPtr and
+    CalculateBoundingBox<device>(std::span<Position>, ...) compiles against the mirror (CPU: compile only)."""
+    assert os.path.exists(device_types_check)
+
+
+@pytest.mark.gpu
+def test_device_types_run(device_types_check):
+    """... and runs: deep device-to-device copies, Host <-> Device conversions with the frame, zero fill, move / swap."""
+    p = subprocess.run([device_types_check, M.asset("bunny.obj"), "64"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "FAIL" not in p.stdout and p.stdout.strip().endswith("done"), p.stdout + p.stderr
+    assert p.stdout.count("ok ") >= 20
