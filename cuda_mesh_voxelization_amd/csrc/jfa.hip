@@ -840,11 +840,10 @@ __device__ __forceinline__ void lds_span(const char* base, uint32_t off, int lo,
     }
 }
 
-#ifndef VP_DENSE_WAVES
-#define VP_DENSE_WAVES 6
-#endif
-template <int TAB, int RY, int CH, int EY, int EZ, int NT, bool CHECK_NONE, bool FINAL, bool ROLL>
-__global__ void __launch_bounds__(NT, VP_DENSE_WAVES)
+// occupancy the register allocation aims at: six waves per SIMD where the LDS footprint allows six workgroups (2-KB tables)
+// or three 512-thread ones (4-KB tables); the 256-thread variant with 4-KB tables is LDS-limited to four
+template <int TAB, int RY, int CH, int EY, int EZ, int NT, bool CHECK_NONE, bool FINAL, bool ROLL, bool SKIP>
+__global__ void __launch_bounds__(NT, (TAB == 512 || NT == 512) ? 6 : 4)
 jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
 {
@@ -945,15 +944,22 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
         const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
         const uint32_t xo = x * 4u, xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;   // a column outside the grid reads the centre column
 
+        // SKIP (wide passes, k >= n/4: half of the neighbour rows / planes / columns lie outside the grid): a source row that
+        // does not exist is neither loaded nor evaluated (wave-uniform branch), and neither is a column x-k / x+k that no lane
+        // of the wave has (it would re-evaluate the centre column, which cannot change the result).  Dense passes keep the
+        // branch-free form: out-of-grid rows read a row of "none".
+        const bool anyM = !SKIP || __any(hasM), anyP = !SKIP || __any(hasP);
+        auto row_exists = [&](int zg, int rr, bool needed) { return needed && zg >= 0 && zg < N && yv[rr]; };
         // ids of row rr of source plane zg -> w[rr*3 ..]: columns {x-k, x, x+k}; "none" where outside the grid or not needed
         auto load_row = [&](int zg, int rr, T (&w)[NI], bool needed) {
-            const bool zin = needed && zg >= 0 && zg < N;
-            const char* pl = opaque_uniform(reinterpret_cast<const char*>(in) + ((ptrdiff_t)(zin ? zg : (int)f.z0) - (ptrdiff_t)f.z0) * (ptrdiff_t)planeBytes);
+            const bool ok = row_exists(zg, rr, needed);
+            if (SKIP && !ok) return;
+            const char* pl = opaque_uniform(reinterpret_cast<const char*>(in) + ((ptrdiff_t)(ok ? zg : (int)f.z0) - (ptrdiff_t)f.z0) * (ptrdiff_t)planeBytes);
             const __amdgpu_buffer_rsrc_t b =
-                row_resource((zin && yv[rr]) ? pl + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
-            row_load(w[rr * 3 + 0], b, xmo);
+                row_resource(ok ? pl + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
+            if (anyM) row_load(w[rr * 3 + 0], b, xmo);
             row_load(w[rr * 3 + 1], b, xo);
-            row_load(w[rr * 3 + 2], b, xpo);
+            if (anyP) row_load(w[rr * 3 + 2], b, xpo);
         };
 
         B best[RY][CH];
@@ -961,56 +967,60 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
         auto scatter = [&](int P, T (&w)[NI]) {
             // rank of the ids of this plane: byte offset of the row inside the gather window + 1 (wave-uniform) + the column offset
             const uint32_t prank = (uint32_t)((zbase + P * K - zlo) * (ptrdiff_t)planeBytes) + 1u;
+            const int olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
 #pragma unroll
-            for (int q = 0; q < NI; ++q) {
-                const int rr = q / 3, c = q % 3;
-                const T id = w[q];
-                const float sx = lds_f32(tx + (id & kFieldX));
-                const float dxv = sx - px;
-                const float dx2 = (CHECK_NONE && ID::is_none(id)) ? INFINITY : dxv * dxv;   // n == 1024: no spare x slot for "none"
-                const uint32_t yo = (id >> YSH) & kFieldY, zo = (id >> ZSH) & kFieldZ;
-                const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
-                float dy2[RY], dz2[CH];
+            for (int rr = 0; rr < NR; ++rr) {
+                const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1);
+                if (!SKIP || row_exists(zbase + P * K, rr, P <= nout)) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (SKIP && ((c == 0 && !anyM) || (c == 2 && !anyP))) continue;
+                        const T id = w[rr * 3 + c];
+                        const float sx = lds_f32(tx + (id & kFieldX));
+                        const float dxv = sx - px;
+                        const float dx2 = (CHECK_NONE && ID::is_none(id)) ? INFINITY : dxv * dxv;   // n == 1024: no spare x slot for "none"
+                        const uint32_t yo = (id >> YSH) & kFieldY, zo = (id >> ZSH) & kFieldZ;
+                        float dy2[RY], dz2[CH];
 #if defined(VP_ABL_NOLDS)
-                for (int a = 0; a < RY; ++a) dy2[a] = __uint_as_float(yo + a);
-                for (int o = 0; o < CH; ++o) dz2[o] = __uint_as_float(zo + o);
+                        for (int a = 0; a < RY; ++a) dy2[a] = __uint_as_float(yo + a);
+                        for (int o = 0; o < CH; ++o) dz2[o] = __uint_as_float(zo + o);
 #else
-                lds_span<RY, EY, TAB>(ty, yo, alo, ahi, dy2);
-                lds_span<CH, EZ, TAB>(tz, zo, olo, ohi, dz2);
+                        lds_span<RY, EY, TAB>(ty, yo, alo, ahi, dy2);
+                        lds_span<CH, EZ, TAB>(tz, zo, olo, ohi, dz2);
 #endif
-                u32x2 cand;
-                if (!FINAL) cand.x = prank + ro[rr] + (c == 0 ? xmo : c == 1 ? xo : xpo);
+                        u32x2 cand;
+                        if (!FINAL) cand.x = prank + ro[rr] + (c == 0 ? xmo : c == 1 ? xo : xpo);
 #pragma unroll
-                for (int a = alo; a <= ahi; ++a) {
-                    const float pre = dx2 + dy2[a];
-                    const bool ownRow = (rr == a + 1) && (c == 1);
+                        for (int a = alo; a <= ahi; ++a) {
+                            const float pre = dx2 + dy2[a];
+                            const bool ownRow = (rr == a + 1) && (c == 1);
 #pragma unroll
-                    for (int o = olo; o <= ohi; ++o) {
-                        const float d = pre + dz2[o];
-                        if constexpr (FINAL) {
-                            best[a][o] = min_f32(best[a][o], d);
-                        } else {
-                            u32x2 cd = cand;
-                            if (ownRow && o == P) cd.x = 0u;           // the voxel's own state wins every tie (sequential.cpp:84,106)
-                            cd.y = __float_as_uint(d);
+                            for (int o = olo; o <= ohi; ++o) {
+                                const float d = pre + dz2[o];
+                                if constexpr (FINAL) {
+                                    best[a][o] = min_f32(best[a][o], d);
+                                } else {
+                                    u32x2 cd = cand;
+                                    if (ownRow && o == P) cd.x = 0u;           // the voxel's own state wins every tie (sequential.cpp:84,106)
+                                    cd.y = __float_as_uint(d);
 #if defined(VP_ABL_NOMIN)
-                            { u32x2 t = __builtin_bit_cast(u32x2, best[a][o]); t.y = __float_as_uint(min_f32(__uint_as_float(t.y), d)); best[a][o] = __builtin_bit_cast(double, t); }
+                                    { u32x2 t = __builtin_bit_cast(u32x2, best[a][o]); t.y = __float_as_uint(min_f32(__uint_as_float(t.y), d)); best[a][o] = __builtin_bit_cast(double, t); }
 #else
-                            best[a][o] = min_f64(best[a][o], __builtin_bit_cast(double, cd));
+                                    best[a][o] = min_f64(best[a][o], __builtin_bit_cast(double, cd));
 #endif
+                                }
+                            }
                         }
                     }
-                }
-                if (c == 2) {
 #pragma unroll
                     for (int a = alo; a <= ahi; ++a)
 #pragma unroll
                         for (int o = olo; o <= ohi; ++o) pin(best[a][o]);
-                    // Rolling prefetch: the three ids of this row are spent, so the same row of the NEXT source plane is
-                    // requested into their registers right away -- a whole plane of evaluation ahead of its use, without a
-                    // second id buffer (18 VGPRs).  A plane that is not needed reads "none" (never memory past the slab's halo).
-                    if (ROLL && P + 1 <= CH) load_row(zbase + (P + 1) * K, rr, w, P + 1 <= nout);
                 }
+                // Rolling prefetch: the three ids of this row are spent, so the same row of the NEXT source plane is
+                // requested into their registers right away -- a whole plane of evaluation ahead of its use, without a
+                // second id buffer (18 VGPRs).  A plane that is not needed reads "none" (never memory past the slab's halo).
+                if (ROLL && P + 1 <= CH) load_row(zbase + (P + 1) * K, rr, w, P + 1 <= nout);
             }
         };
 
@@ -1254,14 +1264,22 @@ static int env_int(const char* name, int dflt)
 static bool dense_applies(const Frame& f, uint32_t k, const void* d_in, const void* d_minus, const void* d_plus, bool fin)
 {
     // The fused last pass stays on jfa_pass_zstream: its distance-only update (v_min_f32) gains nothing from the pair
-    // minimum, and interleaved A/B runs have the round-1 kernel 0 - 5 % ahead on it (tools/ab_pass.py).
-    static const int finalToo = env_int("VP_JFA_DENSE_FINAL", 0);
-    if (fin && !finalToo) return false;
+    // minimum, and interleaved A/B runs have the round-1 kernel 0 - 5 % ahead on it (tools/ab_pass.py); build with
+    // -DVP_JFA_DENSE_FINAL=1 to route it here.
+#ifndef VP_JFA_DENSE_FINAL
+#define VP_JFA_DENSE_FINAL 0
+#endif
+    if (fin && !VP_JFA_DENSE_FINAL) return false;
     #ifndef VP_JFA_DENSE_DEFAULT
 #define VP_JFA_DENSE_DEFAULT 1
 #endif
     static const int enabled = env_int("VP_JFA_DENSE", VP_JFA_DENSE_DEFAULT);         // dev switch: 0 = round-1 kernel for every pass
-    if (!enabled || wide(f) || k * 4 >= f.n) return false;
+    // Wide passes (k >= n/4) stay on jfa_pass_zstream<SKIP>: the SKIP form of this kernel was measured 5 - 9 % slower there
+    // (those passes wait on scattered row segments, not on VALU issue); build with -DVP_JFA_DENSE_WIDEK=1 to try it.
+#ifndef VP_JFA_DENSE_WIDEK
+#define VP_JFA_DENSE_WIDEK 0
+#endif
+    if (!enabled || wide(f) || (k * 4 >= f.n && !VP_JFA_DENSE_WIDEK)) return false;
     const size_t plane = (size_t)f.n * f.n * 4;
     const char* in = (const char*)d_in;
     if (f.z0 > 0 && (const char*)d_minus + (size_t)k * plane != in) return false;
@@ -1276,11 +1294,12 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     VP_TRY(ensure_none_rows(ctx));
     const uint32_t* none_row = (const uint32_t*)((const char*)ctx->none_row.ptr + 2048 * 8);
     const bool fin = d_sdf != nullptr;
+    const bool wideK = k * 4 >= f.n;                               // half of the neighbour rows / planes are outside the grid: SKIP variant
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k;
     const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
     static const int forceCH = env_int("VP_JFA_DENSE_CH", 0), forceNT = env_int("VP_JFA_DENSE_NT", 0);
-#define VP_LAUNCH_DENSE(TAB, RY, CH, NT, C, F)                                                                                     \
-    hipLaunchKernelGGL((jfa_pass_dense<TAB, RY, CH, VP_DENSE_EY, VP_DENSE_EZ, NT, C, F, (TAB > 512 || VP_DENSE_ROLL512)>),                                                                    \
+#define VP_LAUNCH_DENSE(TAB, RY, CH, NT, C, F, S)                                                                                   \
+    hipLaunchKernelGGL((jfa_pass_dense<TAB, RY, CH, VP_DENSE_EY, VP_DENSE_EZ, NT, C, F, (TAB > 512 || VP_DENSE_ROLL512), S>),                                                                    \
                        dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(NT), 0, ctx->stream, f, k,        \
                        (const uint32_t*)d_in, (uint32_t*)d_out, none_row, d_words, fill, d_sdf)
 #ifndef VP_DENSE_ROLL512
@@ -1289,11 +1308,19 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 #ifndef VP_DENSE_RY
 #define VP_DENSE_RY 4
 #endif
-#define VP_DENSE_F(TAB, CH, NT, C) do { if (fin) VP_LAUNCH_DENSE(TAB, 4, CH, NT, C, true); else VP_LAUNCH_DENSE(TAB, VP_DENSE_RY, CH, NT, C, false); } while (0)
+#define VP_DENSE_F(TAB, CH, NT, C) do { if (fin) VP_LAUNCH_DENSE(TAB, 4, CH, NT, C, (VP_JFA_DENSE_FINAL != 0), false); else if (wideK) VP_LAUNCH_DENSE(TAB, 4, CH, NT, C, false, (VP_JFA_DENSE_WIDEK != 0)); \
+                                          else VP_LAUNCH_DENSE(TAB, VP_DENSE_RY, CH, NT, C, false, false); } while (0)
     bool deep = zlen % 8 == 0;
     if (forceCH) deep = forceCH == 8;
+#ifndef VP_DENSE_NT512
+#define VP_DENSE_NT512 256
+#endif
+#ifndef VP_DENSE_NT512_WIDE
+#define VP_DENSE_NT512_WIDE 256
+#endif
     if (f.n <= 512) {
-        if (deep) VP_DENSE_F(512, 8, 256, false); else VP_DENSE_F(512, 4, 256, false);
+        if (wideK) { if (deep) VP_DENSE_F(512, 8, VP_DENSE_NT512_WIDE, false); else VP_DENSE_F(512, 4, VP_DENSE_NT512_WIDE, false); }
+        else       { if (deep) VP_DENSE_F(512, 8, VP_DENSE_NT512, false); else VP_DENSE_F(512, 4, VP_DENSE_NT512, false); }
     } else {
         // 4-KB x table + 16-byte / 32-byte entries: 4x8 tiles take 52 KB of LDS, shared by the 8 waves of a 512-thread workgroup
         const bool chk = f.n >= 1024;

@@ -136,9 +136,14 @@ class SlabPipeline:
         self.plane_words = n * n // 32            # bitmask words per plane
         self.nz = self.z1 - self.z0
         self.words = self.be.empty_u32(self.frame.words)
-        self.ids = [self.be.empty_u32(self.frame.voxels * idw), self.be.empty_u32(self.frame.voxels * idw)]
+        # Id volumes with room for the halo planes of the narrow passes (k <= nz/2) directly below and above the slab:
+        # [H | nz | H] planes, H = nz/2.  For those passes the received planes land next to the slab, the three buffers
+        # vp_jfa_pass takes are ONE contiguous volume, and the dense tile kernel (jfa.hip: jfa_pass_dense) applies.
+        # Wide passes (k >= nz) receive whole slabs of distant ranks into the separate minus / plus buffers.
+        self.H = (self.nz // 2) if world > 1 else 0
+        self._bufs = [self.be.empty_u32((self.nz + 2 * self.H) * self.plane_ids) for _ in range(2)]
+        self.ids = [b[self.H * self.plane_ids:(self.H + self.nz) * self.plane_ids] for b in self._bufs]
         self.sdf = self.be.empty_f32(self.frame.voxels)
-        # halo buffers, sized for the largest request (a whole slab)
         self.minus = self.be.empty_u32(self.frame.voxels * idw) if world > 1 else None
         self.plus = self.be.empty_u32(self.frame.voxels * idw) if world > 1 else None
         self.below = self.be.empty_u32(self.plane_words) if rank > 0 else None
@@ -178,11 +183,23 @@ class SlabPipeline:
             ops.append(P(d.irecv, self.above, self.rank + 1))
         self._exchange(ops)
 
+    def _halo_buffers(self, k: int, src):
+        """(minus, plus) for step k around the id volume `src` (one of self.ids): views into src's own allocation when
+        the halo fits next to the slab (k <= H), else the separate whole-slab buffers."""
+        if self.world == 1:
+            return None, None
+        if k <= self.H:
+            buf = self._bufs[0] if src.data_ptr() == self.ids[0].data_ptr() else self._bufs[1]
+            pi = self.plane_ids
+            return buf[(self.H - k) * pi:self.H * pi], buf[(self.H + self.nz) * pi:(self.H + self.nz + k) * pi]
+        return self.minus, self.plus
+
     def _exchange_ids(self, k: int, src):
         d, P = self.dist, self.dist.P2POp
         pi = self.plane_ids
         minus_base = self.z0 - k                                  # global plane of minus[0] (vphip.h, vp_jfa_pass)
         plus_base = max(self.z1, self.z0 + k)
+        minus, plus = self._halo_buffers(k, src)
         ops = []
         for s, t, side, g0, g1 in halo_plan(self.global_frame.n, self.world, k):
             if s == t:
@@ -190,7 +207,7 @@ class SlabPipeline:
             if s == self.rank:
                 ops.append(P(d.isend, src[(g0 - self.z0) * pi:(g1 - self.z0) * pi], t))
             elif t == self.rank:
-                buf, base = (self.minus, minus_base) if side == "minus" else (self.plus, plus_base)
+                buf, base = (minus, minus_base) if side == "minus" else (plus, plus_base)
                 ops.append(P(d.irecv, buf[(g0 - base) * pi:(g1 - base) * pi], s))
                 self.bytes_received += (g1 - g0) * pi * 4
         self._exchange(ops)
@@ -205,10 +222,11 @@ class SlabPipeline:
         while k >= 1:                                             # jfa/sequential.cpp:72
             if self.world > 1:
                 self._exchange_ids(k, a)
+            minus, plus = self._halo_buffers(k, a)
             if k == 1 and hasattr(self.be, "jfa_last_pass"):       # last pass + finalize fused
-                self.be.jfa_last_pass(self.frame, a, self.minus, self.plus, b, self.words, fill, out, algo)
+                self.be.jfa_last_pass(self.frame, a, minus, plus, b, self.words, fill, out, algo)
                 return out
-            self.be.jfa_pass(self.frame, k, a, self.minus, self.plus, b, algo)
+            self.be.jfa_pass(self.frame, k, a, minus, plus, b, algo)
             a, b = b, a
             k //= 2
         self.be.jfa_finalize(self.frame, self.words, a, fill, out)

@@ -111,3 +111,65 @@ def test_ghost_slabs_equal_whole_grid(engine, world, n, name):
         del pipe
     sdf = np.concatenate(parts)
     assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
+
+
+def test_config4_n1024_four_slabs(engine):
+    """BASELINE config 4 at its stated shape: 1,348,128 faces, n = 1024, four Z-slabs -- both multi-GPU pipelines (RCCL-style
+    halo exchange through the loopback; ghost planes without exchange), four emulated ranks on one GPU with the real
+    kernels, bit-identical to the single-GPU result."""
+    import gc
+    from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
+    xyz, tri = M.bunny(24)
+    n, world = 1024, 4
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    ref_w = engine.voxelize(fr, dx, dt)
+    ref_s = engine.jfa(fr, ref_w).clone()
+    engine._work = None
+    gc.collect(); torch.cuda.empty_cache()
+    nzv = fr.voxels // world
+    for r in range(world):                                     # ghost planes: one rank at a time
+        pipe = GhostSlabPipeline(HipSlabBackend(engine), fr, r, world)
+        pipe.voxelize(dx, dt)
+        s = pipe.jfa()
+        assert torch.equal(s.view(torch.int32), ref_s[r * nzv:(r + 1) * nzv].view(torch.int32)), ("ghost", r)
+        del pipe, s
+        gc.collect(); torch.cuda.empty_cache()
+    words, sdf = _run_slabs(world, fr, xyz, tri, ALGO_TILED)   # halo exchange: all ranks at once
+    assert np.array_equal(words, engine.words_to_numpy(ref_w))
+    assert np.array_equal(sdf.view(np.uint32), ref_s.cpu().numpy().view(np.uint32))
+
+
+def test_config5_n2048_eight_ghost_slabs(engine):
+    """BASELINE config 5 at its stated shape: the 10,785,024-face mesh, n = 2048 (64-bit ids), eight Z-slabs, ghost-plane
+    pipeline: every emulated rank's slab bit-identical to the single-GPU result (itself checked against the oracle's
+    recorded run in test_gpu_parity.py)."""
+    import gc
+    from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
+    gc.collect(); torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 230 * 2**30:
+        pytest.skip("needs ~200 GiB of free HBM, %.0f GiB free" % (free / 2**30))
+    xyz, tri = M.bunny(192)
+    n, world = 2048, 8
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    ref_w = engine.voxelize(fr, dx, dt)
+    ref_s = engine.jfa(fr, ref_w).clone()
+    del ref_w
+    engine._work = None
+    gc.collect(); torch.cuda.empty_cache()
+    nzv = fr.voxels // world
+    pipe = None
+    for r in range(world):
+        pipe = None
+        gc.collect(); torch.cuda.empty_cache()
+        pipe = GhostSlabPipeline(HipSlabBackend(engine), fr, r, world)
+        pipe.voxelize(dx, dt)
+        s = pipe.jfa()
+        assert torch.equal(s.view(torch.int32), ref_s[r * nzv:(r + 1) * nzv].view(torch.int32)), r
+        del s
+    del pipe, ref_s
+    gc.collect(); torch.cuda.empty_cache()
