@@ -162,6 +162,7 @@ int main(int argc, char** argv)
     const unsigned N = opt.numVoxels;
     const bool BENCHMARK = opt.iterations > 1;
     const bool EXPORT = !BENCHMARK && opt.doExport;
+    const bool GPU = TYPE == Types::NAIVE || TYPE == Types::TILED;      // exports: the walk over the grid runs on the device too
 
     std::vector<Mesh> meshes(opt.filenames.size());
     std::vector<HostVoxelsGrid<gridType>> grids(opt.filenames.size());
@@ -199,7 +200,7 @@ int main(int argc, char** argv)
             }
             if (EXPORT) {                                                                               // main.cpp:118-124
                 Mesh outMesh;
-                VoxelsGridToMeshCompressed(grid.View(), outMesh);
+                if (GPU) VoxelsGridToMeshCompressedDevice(grid.View(), outMesh); else VoxelsGridToMeshCompressed(grid.View(), outMesh);
                 cpuAssert(ExportMesh("out/" + typeName + "_" + GetFilename(opt.filenames[i]), outMesh),
                           "Error in " + typeName + " " + opt.filenames[i] + " export");
             }
@@ -217,7 +218,7 @@ int main(int argc, char** argv)
 
         if (EXPORT && OPERATION != CSG::Op::VOID) {                                                     // main.cpp:192-197
             Mesh outMesh;
-            VoxelsGridToMeshCompressed(grids[0].View(), outMesh);
+            if (GPU) VoxelsGridToMeshCompressedDevice(grids[0].View(), outMesh); else VoxelsGridToMeshCompressed(grids[0].View(), outMesh);
             cpuAssert(ExportMesh("out/csg_vox_" + typeName + "_" + opt.output, outMesh), "Error in " + opt.output + " export (csg)");
         }
 
@@ -231,9 +232,9 @@ int main(int argc, char** argv)
             }
             if (EXPORT) {                                                                               // main.cpp:220-230
                 Mesh outMesh;
-                VoxelsGridToMesh(grids[0].View(), sdf.View(), outMesh);
+                if (GPU) VoxelsGridToMeshDevice(grids[0].View(), sdf.View(), outMesh); else VoxelsGridToMesh(grids[0].View(), sdf.View(), outMesh);
                 cpuAssert(ExportMesh("out/sdf_" + typeName + "_" + opt.output, outMesh), "Error in " + opt.output + " export (sdf)");
-                VoxelsGridToPointCloud(grids[0].View(), sdf.View(), outMesh);
+                if (GPU) VoxelsGridToPointCloudDevice(grids[0].View(), sdf.View(), outMesh); else VoxelsGridToPointCloud(grids[0].View(), sdf.View(), outMesh);
                 cpuAssert(ExportMesh("out/sdf_point_cloud_" + typeName + "_" + opt.output, outMesh),
                           "Error in " + opt.output + " export (sdf)");
             }

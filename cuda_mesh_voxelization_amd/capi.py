@@ -11,9 +11,10 @@ LIB_PATH = os.environ.get("VPHIP_LIB") or os.path.join(PKG, "libvphip.so")   # V
 
 ALGO_NAIVE, ALGO_TILED = 1, 2
 OP_VOID, OP_UNION, OP_INTERSECTION, OP_DIFFERENCE = 0, 1, 2, 3
+EXTRACT_SET, EXTRACT_EXPOSED = 0, 1
 
 KERNELS = ["vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
-           "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last"]
+           "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract"]
 JFA_PASS_KEYS = ("jfa_pass", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last")
 
 # every symbol include/vphip.h declares (tests check the library exports all of them)
@@ -23,7 +24,7 @@ SYMBOLS = [
     "vp_grid_words", "vp_grid_voxels",
     "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa", "vp_jfa_start", "vp_jfa_run", "vp_jfa_init", "vp_jfa_pass",
     "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass",
-    "vp_surface", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
+    "vp_surface", "vp_extract_count", "vp_extract", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
 ]
 
@@ -111,6 +112,8 @@ def lib():
         "vp_jfa_can_start_from_mask": (ctypes.c_int, [fp, ctypes.c_int]),
         "vp_jfa_first_pass": (ctypes.c_int, [_vp, fp, _vp, _vp]),
         "vp_surface": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
+        "vp_extract_count": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
+        "vp_extract": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_int, _vp, _vp, _vp, _sz]),
         "vp_voxelize_host": (ctypes.c_int, [_vp, fp, _vp, _vp, _sz, _vp, _sz, ctypes.c_int]),
         "vp_csg_host": (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int]),
         "vp_jfa_host": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_float, _vp, ctypes.c_int]),
@@ -239,6 +242,15 @@ class Context:
     def surface(self, frame: Frame, d_words: int, d_below, d_above, d_border: int):
         check(lib().vp_surface(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_below or None),
                                _vp(d_above or None), _vp(d_border)))
+
+    def extract_count(self, frame: Frame, d_words: int, mode: int) -> int:
+        n = ctypes.c_uint64()
+        check(lib().vp_extract_count(self._h, ctypes.byref(frame), _vp(d_words), mode, ctypes.byref(n)))
+        return int(n.value)
+
+    def extract(self, frame: Frame, d_words: int, mode: int, d_sdf, d_records: int, d_values, capacity: int):
+        check(lib().vp_extract(self._h, ctypes.byref(frame), _vp(d_words), mode, _vp(d_sdf or None), _vp(d_records),
+                               _vp(d_values or None), capacity))
 
     # -- host-in / host-out (numpy arrays), the reference's Compute() convention
     def voxelize_host(self, frame: Frame, h_words, h_xyz, h_tri, algo: int = ALGO_TILED):

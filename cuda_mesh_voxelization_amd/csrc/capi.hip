@@ -107,7 +107,7 @@ static int bind_device(vp_ctx* ctx)
 
 static const char* kNames[VP_K_COUNT] = {
     "vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
-    "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last"
+    "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract"
 };
 
 }  // namespace vp
@@ -144,7 +144,8 @@ int vp_ctx_destroy(vp_ctx* ctx)
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buffer* bufs[] = { &ctx->rec, &ctx->tile_cnt, &ctx->tile_off, &ctx->tile_cur, &ctx->pairs, &ctx->scratch, &ctx->none_row, &ctx->jfa_work };
+    Buffer* bufs[] = { &ctx->rec, &ctx->tile_cnt, &ctx->tile_off, &ctx->tile_cur, &ctx->pairs, &ctx->scratch, &ctx->none_row, &ctx->jfa_work,
+                       &ctx->ext_cnt, &ctx->ext_off };
     for (Buffer* b : bufs) release(*b);
     for (int i = 0; i < VP_WORKSPACE_SLOTS; ++i) release(ctx->slots[i]);
     for (auto& s : ctx->prof_pending) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -418,6 +419,27 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
         return launch_jfa_pass_ex(ctx, fr, 1, d_in, d_minus, d_plus, d_scratch, algo, d_words, fill_unset, d_sdf);
     VP_TRY(launch_jfa_pass(ctx, fr, 1, d_in, d_minus, d_plus, d_scratch, algo));
     return launch_jfa_final(ctx, fr, d_words, d_scratch, fill_unset, d_sdf);
+}
+
+// ---- export front end -------------------------------------------------------------------------
+int vp_extract_count(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode, uint64_t* h_count)
+{
+    if (!ctx || !d_words) return set_error(VP_ERR_INVALID, "vp_extract_count: null argument");
+    VP_TRY(bind_device(ctx));
+    VP_TRY(check_frame(f, "vp_extract_count", true));
+    if (mode != VP_EXTRACT_SET && mode != VP_EXTRACT_EXPOSED) return set_error(VP_ERR_INVALID, "vp_extract_count: mode %d", mode);
+    return launch_extract_count(ctx, make_frame(f), d_words, mode, h_count);
+}
+
+int vp_extract(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode, const float* d_sdf,
+               uint64_t* d_records, float* d_values, size_t capacity)
+{
+    if (!ctx || !d_words || (!d_records && capacity)) return set_error(VP_ERR_INVALID, "vp_extract: null argument");
+    if ((d_values != nullptr) != (d_sdf != nullptr)) return set_error(VP_ERR_INVALID, "vp_extract: d_sdf and d_values go together");
+    VP_TRY(bind_device(ctx));
+    VP_TRY(check_frame(f, "vp_extract", true));
+    if (mode != VP_EXTRACT_SET && mode != VP_EXTRACT_EXPOSED) return set_error(VP_ERR_INVALID, "vp_extract: mode %d", mode);
+    return launch_extract_write(ctx, make_frame(f), d_words, mode, d_sdf, d_records, d_values, capacity);
 }
 
 // ---- host-in / host-out ----------------------------------------------------------------------

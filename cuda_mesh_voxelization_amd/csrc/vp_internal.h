@@ -47,6 +47,12 @@ struct vp_ctx {
     vp::Buffer rec, tile_cnt, tile_off, tile_cur, pairs, scratch, none_row;
     vp::Buffer jfa_work;                       // vp_jfa* with d_work = NULL: two id volumes + border mask
     vp::Buffer slots[VP_WORKSPACE_SLOTS];      // vp_ctx_workspace
+    // vp_extract_*: block counts / offsets of the last count call and what it was for
+    vp::Buffer ext_cnt, ext_off;
+    const uint32_t* ext_words = nullptr;
+    int ext_mode = -1;
+    uint32_t ext_n = 0;
+    uint64_t ext_total = 0;
     // voxelizer: work-queue size of an earlier call, copied back lazily (never waited for) to size the next call's queue
     uint32_t* vox_total_host = nullptr;
     hipEvent_t vox_total_event = nullptr;
@@ -103,5 +109,8 @@ bool jfa_can_start_from_mask(const Frame& f, int algo);
 int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out);
 int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const void* d_ids,
                      float fill, float* d_sdf);
+int launch_extract_count(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, int mode, uint64_t* h_count);
+int launch_extract_write(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, int mode, const float* d_sdf,
+                         uint64_t* d_records, float* d_values, size_t capacity);
 
 }  // namespace vp

@@ -5,7 +5,8 @@
 //                               an unset / outside neighbour (the visible surface) -- same picture, no interior quads.
 //   VoxelsGridToMesh            one 8-vertex cube per set voxel with a finite sdf, coloured by SDFToRGB(sqrt(sdf), diag)
 //   VoxelsGridToPointCloud      one vertex at the centre of every set voxel, same colouring
-// CPU-only and never on the timed path (benchmark mode disables -e, main.cpp:57).
+// Never on the timed path (benchmark mode disables -e, main.cpp:57).  The *Device variants (used by the CLI for -t 1 / -t 2)
+// leave the O(n^3) walk over the grid to the GPU (vp_extract, include/vphip.h) and write byte-identical files.
 #ifndef VPLIB_GRID_TO_MESH_H
 #define VPLIB_GRID_TO_MESH_H
 
@@ -28,5 +29,8 @@ inline std::tuple<float, float, float> SDFToRGB(float v, float max)
 template <VGType T> bool VoxelsGridToMeshCompressed(const VoxelsGrid<T>& grid, Mesh& mesh);
 template <VGType T> bool VoxelsGridToMesh(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh);
 template <VGType T> bool VoxelsGridToPointCloud(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh);
+template <VGType T> bool VoxelsGridToMeshCompressedDevice(const VoxelsGrid<T>& grid, Mesh& mesh);
+template <VGType T> bool VoxelsGridToMeshDevice(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh);
+template <VGType T> bool VoxelsGridToPointCloudDevice(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh);
 
 #endif

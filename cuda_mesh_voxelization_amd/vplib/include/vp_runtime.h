@@ -20,7 +20,7 @@ vp_ctx* Context();
 void Shutdown();
 
 // Workspace slots of the shared context (vp_ctx_workspace) the Compute() wrappers keep their device buffers in.
-enum { kSlotGridA = 0, kSlotGridB = 1, kSlotXyz = 2, kSlotTri = 3, kSlotSdf = 4 };
+enum { kSlotGridA = 0, kSlotGridB = 1, kSlotXyz = 2, kSlotTri = 3, kSlotSdf = 4, kSlotRecords = 5 };
 
 // PROFILING builds: prints the device time (hipEvents, vp_prof_*) of every kernel that ran since the last vp_prof_reset as
 // "# device-time <label> <kernel> <ms> ms <n> launches" lines.  Deliberately NOT the "[label]: x ms" grammar of

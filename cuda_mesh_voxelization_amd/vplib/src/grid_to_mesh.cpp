@@ -1,10 +1,19 @@
 // grid_to_mesh.cpp -- see grid_to_mesh.h.  Visual exports only; no parity contract beyond the OBJ conventions
 // of the reference (six axis normals in the order +Z,+Y,+X,-Z,-Y,-X, grid_to_mesh.cpp:25-31; colours per vertex).
+//
+// Every exporter is written against a stream of voxel RECORDS (linear index + exposed-face mask) in z, y, x order.
+// The host variants produce the records by walking the grid (what the reference does, grid_to_mesh.cpp:10-201); the
+// *Device variants get them from the GPU compaction (vp_extract_count / vp_extract, include/vphip.h) and emit the same
+// bytes -- the O(n^3) walk leaves the CPU, which then only touches the voxels it writes.
 #include "mesh/grid_to_mesh.h"
 
 #include <array>
 #include <cstdint>
 #include <unordered_map>
+#include <vector>
+
+#include "debug_utils.h"
+#include "vp_runtime.h"
 
 namespace {
 
@@ -15,10 +24,63 @@ void AxisNormals(Mesh& mesh)
 
 float Diagonal(float side) { return std::sqrt(side * side * 3.0f); }
 
-}  // namespace
+constexpr uint64_t kIndexMask = (1ull << 40) - 1;
 
+// host record generator: set voxels (exposedOnly = false) or set voxels with a face towards unset / outside, + face mask
+// (bit = axis * 2 + side; X, Y, Z; side 0 = minus) -- the same records vp_extract produces
 template <VGType T>
-bool VoxelsGridToMeshCompressed(const VoxelsGrid<T>& grid, Mesh& mesh)
+std::vector<uint64_t> HostRecords(const VoxelsGrid<T>& grid, bool exposedOnly)
+{
+    std::vector<uint64_t> out;
+    const int64_t n = static_cast<int64_t>(grid.VoxelsPerSide());
+    auto set = [&](int64_t x, int64_t y, int64_t z) {
+        return x >= 0 && y >= 0 && z >= 0 && x < n && y < n && z < n && grid.Voxel(x, y, z);
+    };
+    for (int64_t z = 0; z < n; ++z)
+        for (int64_t y = 0; y < n; ++y)
+            for (int64_t x = 0; x < n; ++x) {
+                if (!grid.Voxel(x, y, z)) continue;
+                const uint64_t idx = static_cast<uint64_t>(x + n * (y + n * z));
+                if (!exposedOnly) { out.push_back(idx); continue; }
+                uint64_t mask = 0;
+                for (int axis = 0; axis < 3; ++axis)
+                    for (int side = 0; side < 2; ++side) {
+                        const int d = side ? 1 : -1;
+                        if (!set(x + d * (axis == 0), y + d * (axis == 1), z + d * (axis == 2))) mask |= 1ull << (axis * 2 + side);
+                    }
+                if (mask) out.push_back(idx | (mask << 40));
+            }
+    return out;
+}
+
+// device record generator: upload the grid, count, extract, download
+template <VGType T>
+std::vector<uint64_t> DeviceRecords(const VoxelsGrid<T>& grid, bool exposedOnly)
+{
+    vp_ctx* ctx = vplib::Context();
+    vp_frame f{};
+    f.n = static_cast<uint32_t>(grid.VoxelsPerSide()); f.voxel_size = grid.VoxelSize();
+    f.origin[0] = grid.OriginX(); f.origin[1] = grid.OriginY(); f.origin[2] = grid.OriginZ();
+    f.z0 = 0; f.z1 = f.n;
+    const size_t gridBytes = vp_grid_words(&f) * 4;
+    const int mode = exposedOnly ? VP_EXTRACT_EXPOSED : VP_EXTRACT_SET;
+    void *dWords = nullptr, *dRec = nullptr;
+    gpuAssert(vp_ctx_workspace(ctx, vplib::kSlotGridA, gridBytes, &dWords));
+    gpuAssert(vp_upload(ctx, dWords, grid.Data(), gridBytes));
+    uint64_t count = 0;
+    gpuAssert(vp_extract_count(ctx, &f, static_cast<const uint32_t*>(dWords), mode, &count));
+    std::vector<uint64_t> out(count);
+    if (count) {
+        gpuAssert(vp_ctx_workspace(ctx, vplib::kSlotRecords, count * sizeof(uint64_t), &dRec));
+        gpuAssert(vp_extract(ctx, &f, static_cast<const uint32_t*>(dWords), mode, nullptr, static_cast<uint64_t*>(dRec), nullptr, count));
+        gpuAssert(vp_download(ctx, out.data(), dRec, count * sizeof(uint64_t)));
+    }
+    return out;
+}
+
+// ---- emitters (shared by the host and the device variants) ------------------------------------------------
+template <VGType T>
+void EmitSurface(const VoxelsGrid<T>& grid, const std::vector<uint64_t>& records, Mesh& mesh)
 {
     mesh.Clear();
     AxisNormals(mesh);
@@ -33,38 +95,33 @@ bool VoxelsGridToMeshCompressed(const VoxelsGrid<T>& grid, Mesh& mesh)
                                      grid.OriginZ() + (z * grid.VoxelSize()));
         return it->second;
     };
-    auto set = [&](int64_t x, int64_t y, int64_t z) {
-        return x >= 0 && y >= 0 && z >= 0 && x < n && y < n && z < n && grid.Voxel(x, y, z);
-    };
     // the two in-plane axes of each face direction, ordered so that (u x v) points along +axis
     static const int U[3][3] = {{0, 1, 0}, {0, 0, 1}, {1, 0, 0}};   // axis X: u = Y ; axis Y: u = Z ; axis Z: u = X
     static const int V[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}};   // axis X: v = Z ; axis Y: v = X ; axis Z: v = Y
     static const uint32_t normalIndex[3][2] = {{5, 2}, {4, 1}, {3, 0}};   // [axis][positive side]
-    for (int64_t z = 0; z < n; ++z)
-        for (int64_t y = 0; y < n; ++y)
-            for (int64_t x = 0; x < n; ++x) {
-                if (!grid.Voxel(x, y, z)) continue;
-                for (int axis = 0; axis < 3; ++axis)
-                    for (int side = 0; side < 2; ++side) {
-                        const int d = side ? 1 : -1;
-                        const int64_t ax = axis == 0, ay = axis == 1, az = axis == 2;
-                        if (set(x + d * ax, y + d * ay, z + d * az)) continue;       // interior face: not visible
-                        const int64_t bx = x + side * ax, by = y + side * ay, bz = z + side * az;   // face corner
-                        const uint32_t p00 = vertex(bx, by, bz);
-                        const uint32_t p10 = vertex(bx + U[axis][0], by + U[axis][1], bz + U[axis][2]);
-                        const uint32_t p01 = vertex(bx + V[axis][0], by + V[axis][1], bz + V[axis][2]);
-                        const uint32_t p11 = vertex(bx + U[axis][0] + V[axis][0], by + U[axis][1] + V[axis][1], bz + U[axis][2] + V[axis][2]);
-                        if (side) mesh.FacesCoords.insert(mesh.FacesCoords.end(), {p00, p10, p11, p00, p11, p01});   // outward = +axis
-                        else      mesh.FacesCoords.insert(mesh.FacesCoords.end(), {p00, p11, p10, p00, p01, p11});   // outward = -axis
-                        mesh.FacesNormals.insert(mesh.FacesNormals.end(), 6, normalIndex[axis][side]);
-                    }
+    for (const uint64_t rec : records) {
+        const int64_t idx = static_cast<int64_t>(rec & kIndexMask);
+        const unsigned mask = static_cast<unsigned>(rec >> 40);
+        const int64_t x = idx % n, y = (idx / n) % n, z = idx / (n * n);
+        for (int axis = 0; axis < 3; ++axis)
+            for (int side = 0; side < 2; ++side) {
+                if (!((mask >> (axis * 2 + side)) & 1u)) continue;                   // interior face: not visible
+                const int64_t ax = axis == 0, ay = axis == 1, az = axis == 2;
+                const int64_t bx = x + side * ax, by = y + side * ay, bz = z + side * az;   // face corner
+                const uint32_t p00 = vertex(bx, by, bz);
+                const uint32_t p10 = vertex(bx + U[axis][0], by + U[axis][1], bz + U[axis][2]);
+                const uint32_t p01 = vertex(bx + V[axis][0], by + V[axis][1], bz + V[axis][2]);
+                const uint32_t p11 = vertex(bx + U[axis][0] + V[axis][0], by + U[axis][1] + V[axis][1], bz + U[axis][2] + V[axis][2]);
+                if (side) mesh.FacesCoords.insert(mesh.FacesCoords.end(), {p00, p10, p11, p00, p11, p01});   // outward = +axis
+                else      mesh.FacesCoords.insert(mesh.FacesCoords.end(), {p00, p11, p10, p00, p01, p11});   // outward = -axis
+                mesh.FacesNormals.insert(mesh.FacesNormals.end(), 6, normalIndex[axis][side]);
             }
+    }
     mesh.Colors.assign(mesh.VerticesSize(), Color(1.0f, 1.0f, 1.0f, 1.0f));
-    return true;
 }
 
 template <VGType T>
-bool VoxelsGridToMesh(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh)
+void EmitCubes(const VoxelsGrid<T>& grid, const Grid<float>& sdf, const std::vector<uint64_t>& records, Mesh& mesh)
 {
     mesh.Clear();
     AxisNormals(mesh);
@@ -75,51 +132,61 @@ bool VoxelsGridToMesh(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& m
     static const uint32_t quads[6][4] = {{0, 2, 3, 1}, {4, 5, 7, 6}, {2, 6, 7, 3}, {0, 1, 5, 4}, {1, 3, 7, 5}, {0, 4, 6, 2}};
     static const uint32_t quadNormal[6] = {3, 0, 1, 4, 2, 5};     // -Z, +Z, +Y, -Y, +X, -X
     uint32_t cubes = 0;
-    for (size_t z = 0; z < n; ++z)
-        for (size_t y = 0; y < n; ++y)
-            for (size_t x = 0; x < n; ++x) {
-                if (!grid.Voxel(x, y, z) || std::isinf(sdf(x, y, z))) continue;
-                const auto [r, g, b] = SDFToRGB(std::sqrt(sdf(x, y, z)), max);
-                for (int c = 0; c < 8; ++c) {
-                    mesh.Coords.emplace_back(grid.OriginX() + (x * vs) + (vs * (c & 1)), grid.OriginY() + (y * vs) + (vs * ((c >> 1) & 1)),
-                                             grid.OriginZ() + (z * vs) + (vs * ((c >> 2) & 1)));
-                    mesh.Colors.emplace_back(r, g, b, 1.0f);
-                }
-                const uint32_t base = cubes * 8;
-                for (int q = 0; q < 6; ++q) {
-                    const uint32_t* p = quads[q];
-                    mesh.FacesCoords.insert(mesh.FacesCoords.end(), {base + p[0], base + p[1], base + p[2], base + p[0], base + p[2], base + p[3]});
-                    mesh.FacesNormals.insert(mesh.FacesNormals.end(), 6, quadNormal[q]);
-                }
-                ++cubes;
-            }
+    for (const uint64_t rec : records) {
+        const size_t idx = static_cast<size_t>(rec & kIndexMask);
+        const size_t x = idx % n, y = (idx / n) % n, z = idx / (n * n);
+        if (std::isinf(sdf(x, y, z))) continue;
+        const auto [r, g, b] = SDFToRGB(std::sqrt(sdf(x, y, z)), max);
+        for (int c = 0; c < 8; ++c) {
+            mesh.Coords.emplace_back(grid.OriginX() + (x * vs) + (vs * (c & 1)), grid.OriginY() + (y * vs) + (vs * ((c >> 1) & 1)),
+                                     grid.OriginZ() + (z * vs) + (vs * ((c >> 2) & 1)));
+            mesh.Colors.emplace_back(r, g, b, 1.0f);
+        }
+        const uint32_t base = cubes * 8;
+        for (int q = 0; q < 6; ++q) {
+            const uint32_t* p = quads[q];
+            mesh.FacesCoords.insert(mesh.FacesCoords.end(), {base + p[0], base + p[1], base + p[2], base + p[0], base + p[2], base + p[3]});
+            mesh.FacesNormals.insert(mesh.FacesNormals.end(), 6, quadNormal[q]);
+        }
+        ++cubes;
+    }
     mesh.ShrinkToFit();
-    return true;
 }
 
 template <VGType T>
-bool VoxelsGridToPointCloud(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh)
+void EmitPoints(const VoxelsGrid<T>& grid, const Grid<float>& sdf, const std::vector<uint64_t>& records, Mesh& mesh)
 {
     mesh.Clear();
     const size_t n = grid.VoxelsPerSide();
     const float vs = grid.VoxelSize();
     const float max = Diagonal(n * vs);
-    for (size_t z = 0; z < n; ++z)
-        for (size_t y = 0; y < n; ++y)
-            for (size_t x = 0; x < n; ++x) {
-                if (!grid.Voxel(x, y, z)) continue;
-                mesh.Coords.emplace_back(grid.OriginX() + (x * vs) + (vs / 2), grid.OriginY() + (y * vs) + (vs / 2),
-                                         grid.OriginZ() + (z * vs) + (vs / 2));
-                const auto [r, g, b] = SDFToRGB(std::sqrt(sdf(x, y, z)), max);
-                mesh.Colors.emplace_back(r, g, b, 1.0f);
-            }
+    for (const uint64_t rec : records) {
+        const size_t idx = static_cast<size_t>(rec & kIndexMask);
+        const size_t x = idx % n, y = (idx / n) % n, z = idx / (n * n);
+        mesh.Coords.emplace_back(grid.OriginX() + (x * vs) + (vs / 2), grid.OriginY() + (y * vs) + (vs / 2),
+                                 grid.OriginZ() + (z * vs) + (vs / 2));
+        const auto [r, g, b] = SDFToRGB(std::sqrt(sdf(x, y, z)), max);
+        mesh.Colors.emplace_back(r, g, b, 1.0f);
+    }
     mesh.ShrinkToFit();
-    return true;
 }
 
-template bool VoxelsGridToMeshCompressed<uint32_t>(const VoxelsGrid<uint32_t>&, Mesh&);
-template bool VoxelsGridToMeshCompressed<uint64_t>(const VoxelsGrid<uint64_t>&, Mesh&);
-template bool VoxelsGridToMesh<uint32_t>(const VoxelsGrid<uint32_t>&, const Grid<float>&, Mesh&);
-template bool VoxelsGridToMesh<uint64_t>(const VoxelsGrid<uint64_t>&, const Grid<float>&, Mesh&);
-template bool VoxelsGridToPointCloud<uint32_t>(const VoxelsGrid<uint32_t>&, const Grid<float>&, Mesh&);
-template bool VoxelsGridToPointCloud<uint64_t>(const VoxelsGrid<uint64_t>&, const Grid<float>&, Mesh&);
+}  // namespace
+
+template <VGType T> bool VoxelsGridToMeshCompressed(const VoxelsGrid<T>& grid, Mesh& mesh) { EmitSurface(grid, HostRecords(grid, true), mesh); return true; }
+template <VGType T> bool VoxelsGridToMesh(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitCubes(grid, sdf, HostRecords(grid, false), mesh); return true; }
+template <VGType T> bool VoxelsGridToPointCloud(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitPoints(grid, sdf, HostRecords(grid, false), mesh); return true; }
+template <VGType T> bool VoxelsGridToMeshCompressedDevice(const VoxelsGrid<T>& grid, Mesh& mesh) { EmitSurface(grid, DeviceRecords(grid, true), mesh); return true; }
+template <VGType T> bool VoxelsGridToMeshDevice(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitCubes(grid, sdf, DeviceRecords(grid, false), mesh); return true; }
+template <VGType T> bool VoxelsGridToPointCloudDevice(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitPoints(grid, sdf, DeviceRecords(grid, false), mesh); return true; }
+
+#define VP_INSTANTIATE(T)                                                                         \
+    template bool VoxelsGridToMeshCompressed<T>(const VoxelsGrid<T>&, Mesh&);                     \
+    template bool VoxelsGridToMesh<T>(const VoxelsGrid<T>&, const Grid<float>&, Mesh&);           \
+    template bool VoxelsGridToPointCloud<T>(const VoxelsGrid<T>&, const Grid<float>&, Mesh&);     \
+    template bool VoxelsGridToMeshCompressedDevice<T>(const VoxelsGrid<T>&, Mesh&);               \
+    template bool VoxelsGridToMeshDevice<T>(const VoxelsGrid<T>&, const Grid<float>&, Mesh&);     \
+    template bool VoxelsGridToPointCloudDevice<T>(const VoxelsGrid<T>&, const Grid<float>&, Mesh&);
+VP_INSTANTIATE(uint32_t)
+VP_INSTANTIATE(uint64_t)
+#undef VP_INSTANTIATE

@@ -3,6 +3,7 @@
 // "f a//b c//d e//f" with 1-based indices; "# Vertices: n" / "# Faces: n" comments pre-reserve.
 #include "mesh/mesh_io.h"
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +37,91 @@ float to_float(const char* b, const char* e)
 
 }  // namespace
 
+// ---- binary cache of parsed meshes -------------------------------------------------------------------------
+// Parsing a 10-million-triangle OBJ (about 1 GB of text) takes tens of seconds; the five arrays of the parsed Mesh are
+// ~400 MB and load in a fraction of a second.  Opt-in: VPLIB_MESH_CACHE=1 in the environment (the reference has no such
+// thing; its CLI re-parses on every run).  The cache file "<obj>.vpmesh" is keyed on the source's size and modification
+// time and ignored when either differs or the file is malformed.
+namespace {
+
+struct CacheHeader {
+    char magic[8];               // "VPMESH1\0"
+    uint64_t srcSize;
+    int64_t srcMtime;
+    uint64_t counts[5];          // FacesCoords, FacesNormals, Coords, Normals, Colors (elements)
+};
+
+bool source_stamp(const std::string& filename, uint64_t& size, int64_t& mtime)
+{
+    std::error_code ec;
+    const auto sz = std::filesystem::file_size(filename, ec);
+    if (ec) return false;
+    const auto tm = std::filesystem::last_write_time(filename, ec);
+    if (ec) return false;
+    size = static_cast<uint64_t>(sz);
+    mtime = static_cast<int64_t>(tm.time_since_epoch().count());
+    return true;
+}
+
+template <typename V>
+bool read_vec(std::FILE* f, V& v, uint64_t count)
+{
+    v.resize(count);
+    return count == 0 || std::fread(v.data(), sizeof(typename V::value_type), count, f) == count;
+}
+
+template <typename V>
+bool write_vec(std::FILE* f, const V& v)
+{
+    return v.empty() || std::fwrite(v.data(), sizeof(typename V::value_type), v.size(), f) == v.size();
+}
+
+bool load_cache(const std::string& filename, Mesh& mesh)
+{
+    uint64_t size; int64_t mtime;
+    if (!source_stamp(filename, size, mtime)) return false;
+    std::FILE* f = std::fopen((filename + ".vpmesh").c_str(), "rb");
+    if (!f) return false;
+    CacheHeader h{};
+    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "VPMESH1", 8) == 0 && h.srcSize == size && h.srcMtime == mtime;
+    if (ok) {
+        mesh.Clear();
+        ok = read_vec(f, mesh.FacesCoords, h.counts[0]) && read_vec(f, mesh.FacesNormals, h.counts[1]) && read_vec(f, mesh.Coords, h.counts[2]) &&
+             read_vec(f, mesh.Normals, h.counts[3]) && read_vec(f, mesh.Colors, h.counts[4]) && std::fgetc(f) == EOF;
+    }
+    std::fclose(f);
+    if (!ok) mesh.Clear();
+    return ok;
+}
+
+void store_cache(const std::string& filename, const Mesh& mesh)
+{
+    CacheHeader h{};
+    std::memcpy(h.magic, "VPMESH1", 8);
+    if (!source_stamp(filename, h.srcSize, h.srcMtime)) return;
+    h.counts[0] = mesh.FacesCoords.size(); h.counts[1] = mesh.FacesNormals.size(); h.counts[2] = mesh.Coords.size();
+    h.counts[3] = mesh.Normals.size(); h.counts[4] = mesh.Colors.size();
+    const std::string tmp = filename + ".vpmesh.tmp";
+    std::FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;                                                 // read-only directory: just no cache
+    const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && write_vec(f, mesh.FacesCoords) && write_vec(f, mesh.FacesNormals) &&
+                    write_vec(f, mesh.Coords) && write_vec(f, mesh.Normals) && write_vec(f, mesh.Colors);
+    std::fclose(f);
+    std::error_code ec;
+    if (ok) std::filesystem::rename(tmp, filename + ".vpmesh", ec);
+    if (!ok || ec) std::filesystem::remove(tmp, ec);
+}
+
+bool cache_enabled()
+{
+    const char* e = std::getenv("VPLIB_MESH_CACHE");
+    return e && *e && std::strcmp(e, "0") != 0;
+}
+
+}  // namespace
+
+static bool ParseObj(const std::string& filename, Mesh& mesh);
+
 bool ImportMesh(const std::string filename, Mesh& mesh)
 {
     const std::string ext = std::filesystem::path(filename).extension().string();
@@ -43,6 +129,17 @@ bool ImportMesh(const std::string filename, Mesh& mesh)
         LOG_ERROR("%s is a wrong file extension. It must be .obj or .OBJ", ext.c_str());
         return false;
     }
+    if (cache_enabled() && load_cache(filename, mesh)) {
+        mesh.Name = filename;
+        return true;
+    }
+    if (!ParseObj(filename, mesh)) return false;
+    if (cache_enabled()) store_cache(filename, mesh);
+    return true;
+}
+
+static bool ParseObj(const std::string& filename, Mesh& mesh)
+{
     std::ifstream file(filename, std::ios::binary | std::ios::ate);
     if (!file.is_open()) {
         LOG_ERROR("Error to open file %s", filename.c_str());

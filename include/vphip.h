@@ -169,6 +169,22 @@ int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_g
 int vp_surface(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words,
                const uint32_t* d_plane_below, const uint32_t* d_plane_above, uint32_t* d_border_words);
 
+/* ---- export: ordered compaction of the grid into voxel records --------------------------------
+ * The reference's exporters walk all n^3 voxels on the CPU (vplib/src/mesh/grid_to_mesh.cpp:10-201); this is the
+ * accelerated front end: the walk is a GPU stream and the host only sees the voxels it will emit, in the exporter's own
+ * scan order (z, y, x), so the files it writes are byte-identical.  Whole-grid frames only.
+ *   mode VP_EXTRACT_SET      every set voxel (point cloud, sdf cubes: grid_to_mesh.cpp:133-201)
+ *   mode VP_EXTRACT_EXPOSED  set voxels with a face towards an unset voxel or the outside of the grid, with the mask of
+ *                            those faces (visible-surface mesh)
+ *   record = linear voxel index x + n (y + n z) in bits 0..39 | face mask << 40 (bit = axis * 2 + side; X, Y, Z; 0 = minus)
+ * vp_extract_count runs the counting pass and returns the number of records (blocking); vp_extract then writes up to
+ * `capacity` records (and, when d_sdf and d_values are given, the sdf value of each voxel) -- it must follow a count call for
+ * the same grid and mode. */
+enum { VP_EXTRACT_SET = 0, VP_EXTRACT_EXPOSED = 1 };
+int vp_extract_count(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode, uint64_t* h_count);
+int vp_extract(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode, const float* d_sdf,
+               uint64_t* d_records, float* d_values, size_t capacity);
+
 /* ---- host-in / host-out conveniences (the reference's Compute() calling convention) -------
  * Upload, run, download, synchronise -- what every reference Compute<NAIVE|TILED> does
  * (vox/tiled.cu:504-575, csg/naive.cu:38-63, jfa/tiled.cu:254-336).  Whole-grid frames only. */
@@ -190,6 +206,7 @@ enum {
     VP_K_JFA_SPARSE,    /* k >= n/4: 2 S n^3 */
     VP_K_JFA_DENSE,     /* k <  n/4: 2 S n^3 */
     VP_K_JFA_LAST,      /* k = 1 fused with the id -> sdf conversion: S n^3 + 4 n^3 + n^3/8 */
+    VP_K_EXTRACT,       /* vp_extract_count / vp_extract: 2 n^3/8 + records */
     VP_K_COUNT
 };
 int vp_prof_enable(vp_ctx* ctx, int on);

@@ -460,3 +460,51 @@ def test_config5_10m_triangles_n2048(engine, capsys):
     del s_t, border, g, h
     engine._work = None
     gc.collect(); torch.cuda.empty_cache()
+
+
+def test_extract_records_match_numpy(engine):
+    """vp_extract_count / vp_extract (the GPU front end of the exporters): ordered records of set voxels and of exposed
+    voxels with their 6-bit face masks, against a numpy restatement, on a solid, on a CSG shell, on empty and full grids."""
+    from cuda_mesh_voxelization_amd.capi import EXTRACT_EXPOSED, EXTRACT_SET
+    a = M.import_mesh(M.asset("bunny.obj"))
+    b = M.import_mesh(M.asset("bimba.obj"))
+    cases = []
+    for n, op in ((64, 0), (128, 3), (96, 1)):
+        fr, origin, vs = _frame([a, b], n)
+        g = _gpu_grid(engine, fr, a[0], a[1], ALGO_TILED)
+        if op:
+            engine.csg(g, _gpu_grid(engine, fr, b[0], b[1], ALGO_TILED), op)
+        cases.append((fr, g))
+    fr32 = Frame.make(32, 1.0, (0, 0, 0))
+    cases.append((fr32, torch.zeros(fr32.words, dtype=torch.int32, device=engine.device)))
+    cases.append((fr32, torch.full((fr32.words,), -1, dtype=torch.int32, device=engine.device)))
+    for fr, g in cases:
+        n = fr.n
+        occ = np.unpackbits(engine.words_to_numpy(g).view(np.uint8), bitorder="little").reshape(n, n, n).astype(bool)   # [z, y, x]
+        pad = np.pad(occ, 1)
+        masks = np.zeros((n, n, n), np.uint64)
+        for bit, (ax, d) in enumerate(((2, -1), (2, 1), (1, -1), (1, 1), (0, -1), (0, 1))):     # -X +X -Y +Y -Z +Z ; array axes are z, y, x
+            nb = np.roll(pad, -d, ax)[1:-1, 1:-1, 1:-1]
+            masks |= (occ & ~nb).astype(np.uint64) << np.uint64(bit)
+        lin = np.arange(n ** 3, dtype=np.uint64).reshape(n, n, n)
+        exp_set = lin[occ]
+        sel = occ & (masks != 0)
+        exp_exposed = lin[sel] | (masks[sel] << np.uint64(40))
+        sdf = torch.arange(n ** 3, dtype=torch.float32, device=engine.device)
+        for mode, exp in ((EXTRACT_SET, exp_set), (EXTRACT_EXPOSED, exp_exposed)):
+            cnt = engine.ctx.extract_count(fr, g.data_ptr(), mode)
+            assert cnt == exp.size
+            rec = torch.zeros(max(cnt, 1), dtype=torch.int64, device=engine.device)
+            val = torch.zeros(max(cnt, 1), dtype=torch.float32, device=engine.device)
+            engine.ctx.extract(fr, g.data_ptr(), mode, sdf.data_ptr(), rec.data_ptr(), val.data_ptr(), cnt)
+            engine.sync()
+            got = rec.cpu().numpy().view(np.uint64)[:cnt]
+            assert np.array_equal(got, exp), (n, mode)
+            assert np.array_equal(val.cpu().numpy()[:cnt], (exp & np.uint64((1 << 40) - 1)).astype(np.float32))
+            # a capacity smaller than the count truncates, never writes past it
+            if cnt > 10:
+                rec.fill_(-1)
+                engine.ctx.extract(fr, g.data_ptr(), mode, None, rec.data_ptr(), None, 10)
+                engine.sync()
+                r2 = rec.cpu().numpy()
+                assert np.array_equal(r2[:10].view(np.uint64), exp[:10]) and (r2[10:] == -1).all()

@@ -1,0 +1,63 @@
+"""Dev tool (one GPU): what the Z-slab pipelines cost per rank at the sizes the north star shards.
+
+  python tools/slab_scaling.py 512 | 1024 | 2048
+
+ghost planes (no exchange): every rank of a G-GPU job is run on THIS GPU with the real kernels and timed; ranks share
+  nothing, so the job time on G GPUs is the slowest rank -- a measurement, not a model.  Also printed: plane-passes per
+  rank against the single-GPU count (the work-replication ceiling of the scheme).
+halo exchange: bytes each rank must RECEIVE over xGMI per job (exact, from slab.halo_plan) and the time that takes at two
+  assumed per-GPU ingest rates -- a model (no multi-GPU box is reachable from here); compute per rank is the measured
+  single-GPU time / G at best.
+"""
+import math, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cuda_mesh_voxelization_amd import mesh as M
+from cuda_mesh_voxelization_amd.capi import ALGO_TILED, Frame
+from cuda_mesh_voxelization_amd.pipeline import Engine
+from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline, HipSlabBackend, halo_plan, ghost_regions
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+refine = 24 if n <= 1024 else 192
+xyz, tri = M.bunny(refine); origin, vs = M.frame([xyz], n); fr = Frame.make(n, vs, origin)
+eng = Engine(0); dx, dt = eng.mesh_to_device(xyz, tri)
+S = eng.ctx.jfa_id_bytes(fr); passes = int(math.log2(n))
+reps = 10 if n <= 512 else 3
+
+def timeit(fn, reps):
+    for _ in range(2): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+
+g = eng.new_grid(fr); sdf = torch.empty(fr.voxels, dtype=torch.float32, device=eng.device)
+def single():
+    eng.voxelize(fr, dx, dt, out=g); eng.jfa(fr, g, out=sdf)
+t1 = timeit(single, reps)
+del g, sdf; eng._work = None; torch.cuda.empty_cache()
+print("n = %d, %d faces, id bytes S = %d, %d passes; 1 GPU: %.3f ms per job" % (n, tri.shape[0], S, passes, t1))
+print("\nghost planes (measured per rank on one GPU; job = slowest rank; nothing is exchanged)")
+print("  G   job ms  speedup  efficiency  plane-passes/rank (1 GPU: %d)  ceiling   per-rank ms" % (n * passes))
+for world in (2, 4, 8):
+    ts, pp = [], []
+    for r in range(world):
+        pipe = GhostSlabPipeline(HipSlabBackend(eng), fr, r, world)
+        def step(): pipe.voxelize(dx, dt); pipe.jfa()
+        ts.append(timeit(step, max(2, reps // 2))); pp.append(pipe.planes_computed)
+        del pipe; torch.cuda.empty_cache()
+    print("  %d  %7.3f  %6.2fx  %9.0f%%  %8d                        %5.2fx   %s"
+          % (world, max(ts), t1 / max(ts), 100 * t1 / max(ts) / world, max(pp), n * passes / max(pp), " ".join("%.2f" % t for t in ts)))
+print("\nhalo exchange (bytes received per rank and job: exact; times: MODEL at an assumed per-GPU ingest rate)")
+print("  G   max GiB received/rank   @150 GB/s   @400 GB/s   + compute >= t1/G   vs 1 GPU")
+plane = n * n * S
+for world in (2, 4, 8):
+    rx = [0] * world
+    k = n // 2
+    while k >= 1:
+        for s_, t_, side, g0, g1 in halo_plan(n, world, k):
+            if s_ != t_: rx[t_] += (g1 - g0) * plane
+        k //= 2
+    b = max(rx)
+    t150, t400 = b / 150e9 * 1e3, b / 400e9 * 1e3
+    print("  %d   %8.2f               %8.2f ms %8.2f ms   %8.2f ms         %.2fx .. %.2fx"
+          % (world, b / 2**30, t150, t400, t1 / world, t1 / (t150 + t1 / world), t1 / (t400 + t1 / world)))
