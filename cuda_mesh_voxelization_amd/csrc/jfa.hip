@@ -469,36 +469,35 @@ __device__ __forceinline__ size_t opaque_uniform(size_t v)
     asm volatile("" : "+s"(v));
     return v;
 }
-// Candidate update "if (d < bestd) { bestd = d; best = id; }" as v_cmpx + plain moves under the narrowed EXEC mask,
-// EXEC restored afterwards: about 9 clocks per wave on this part against 16 for v_cmp + two v_cndmask
-// (tools/ubench/valu_rate.hip); the 27 candidate updates are 70 % of the dense kernel's VALU work (dense pass 0.50 ->
-// 0.47 ms).  `ex` is the wave's EXEC mask on entry (wave_exec()); it has to be ONE SGPR pair -- a ballot at each use is
-// rematerialised into fresh SGPRs and spills.  OWN = the voxel's own state: '<=' (it wins ties).
-__device__ __forceinline__ uint64_t wave_exec()
+// Candidate update "if (d < bestd) { bestd = d; best = id; }" as v_cmpx + plain moves under the narrowed EXEC mask:
+// about 9 clocks per wave on this part against 16 for v_cmp + two v_cndmask (tools/ubench/valu_rate.hip).  The live
+// mask is saved and restored INSIDE the asm (an early-clobber SGPR pair), so the statement is correct wherever the compiler
+// places it -- round 1 restored EXEC from a mask captured once per x iteration, which was only right as long as every call
+// stayed in the control-flow region of that capture.  Since round 2 this form only serves the fallback passes (64-bit ids,
+// slabs whose halo buffers are not contiguous); the dense passes use the v_min_f64 pair update of jfa_pass_dense.
+// OWN = the voxel's own state: '<=' (it wins ties).
+__device__ __forceinline__ uint64_t wave_exec() { return 0; }     // kept for the call sites: the mask is no longer passed around
+template <bool OWN>
+__device__ __forceinline__ void take_if_closer(float& bestd, uint32_t& best, float d, uint32_t id, uint64_t)
 {
-    uint64_t ex;
-    asm volatile("s_mov_b64 %0, exec" : "=s"(ex));              // volatile: one copy, never rematerialised per use
-    return ex;
+    uint64_t saved;
+    if (OWN)
+        asm volatile("s_mov_b64 %2, exec\n\tv_cmpx_le_f32 exec, %3, %0\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\ts_mov_b64 exec, %2"
+                     : "+v"(bestd), "+v"(best), "=&s"(saved) : "v"(d), "v"(id));
+    else
+        asm volatile("s_mov_b64 %2, exec\n\tv_cmpx_lt_f32 exec, %3, %0\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\ts_mov_b64 exec, %2"
+                     : "+v"(bestd), "+v"(best), "=&s"(saved) : "v"(d), "v"(id));
 }
 template <bool OWN>
-__device__ __forceinline__ void take_if_closer(float& bestd, uint32_t& best, float d, uint32_t id, uint64_t ex)
+__device__ __forceinline__ void take_if_closer(float& bestd, uint2& best, float d, uint2 id, uint64_t)
 {
+    uint64_t saved;
     if (OWN)
-        asm("v_cmpx_le_f32 exec, %2, %0\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\ts_mov_b64 exec, %4"
-            : "+v"(bestd), "+v"(best) : "v"(d), "v"(id), "s"(ex));
+        asm volatile("s_mov_b64 %3, exec\n\tv_cmpx_le_f32 exec, %4, %0\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\ts_mov_b64 exec, %3"
+                     : "+v"(bestd), "+v"(best.x), "+v"(best.y), "=&s"(saved) : "v"(d), "v"(id.x), "v"(id.y));
     else
-        asm("v_cmpx_lt_f32 exec, %2, %0\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\ts_mov_b64 exec, %4"
-            : "+v"(bestd), "+v"(best) : "v"(d), "v"(id), "s"(ex));
-}
-template <bool OWN>
-__device__ __forceinline__ void take_if_closer(float& bestd, uint2& best, float d, uint2 id, uint64_t ex)
-{
-    if (OWN)
-        asm("v_cmpx_le_f32 exec, %3, %0\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5\n\ts_mov_b64 exec, %6"
-            : "+v"(bestd), "+v"(best.x), "+v"(best.y) : "v"(d), "v"(id.x), "v"(id.y), "s"(ex));
-    else
-        asm("v_cmpx_lt_f32 exec, %3, %0\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5\n\ts_mov_b64 exec, %6"
-            : "+v"(bestd), "+v"(best.x), "+v"(best.y) : "v"(d), "v"(id.x), "v"(id.y), "s"(ex));
+        asm volatile("s_mov_b64 %3, exec\n\tv_cmpx_lt_f32 exec, %4, %0\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\ts_mov_b64 exec, %3"
+                     : "+v"(bestd), "+v"(best.x), "+v"(best.y), "=&s"(saved) : "v"(d), "v"(id.x), "v"(id.y));
 }
 // An empty asm that "modifies" a running value: everything feeding it has to be computed here.  Without it the
 // compiler sinks the compare/select chains of a whole chain towards the stores and keeps every distance live

@@ -13,7 +13,8 @@ n = a.n
 xyz, tri = M.bunny(a.refine); origin, vs = M.frame([xyz], n); fr = Frame.make(n, vs, origin)
 eng = Engine(0); dx, dt = eng.mesh_to_device(xyz, tri)
 g = eng.voxelize(fr, dx, dt)
-ids = [torch.empty(fr.voxels, dtype=torch.int32, device=eng.device) for _ in range(2)]
+idw = eng.ctx.jfa_id_bytes(fr) // 4                      # 32-bit words per id (2 above n = 1024)
+ids = [torch.empty(fr.voxels * idw, dtype=torch.int32, device=eng.device) for _ in range(2)]
 sdf = torch.empty(fr.voxels, dtype=torch.float32, device=eng.device)
 ctx = eng.ctx
 for algo in [int(x) for x in a.algos.split(",")]:
@@ -29,7 +30,7 @@ for algo in [int(x) for x in a.algos.split(",")]:
     out = torch.empty_like(cur)
     tot = 0.0
     for k, st in states:
-        seeds = int(((st & 3) == 0).sum().item())                # real ids have bits 0,1 clear
+        seeds = int(((st[::idw] & 3) == 0).sum().item())         # real ids have bits 0,1 of their first word clear
         ctx.prof_reset(); ctx.prof_enable(True)
         for _ in range(a.reps):
             ctx.jfa_pass(fr, k, st.data_ptr(), None, None, out.data_ptr(), algo)
