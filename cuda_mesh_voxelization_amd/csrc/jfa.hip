@@ -871,8 +871,18 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
     const uint32_t tid = threadIdx.x;
     const int nresY = min(K, N);
     const bool rev = ((31 - __builtin_clz(k)) & 1) != 0;          // alternate the traversal direction between passes
-    const uint32_t bx = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
-    const uint32_t by = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+#ifndef VP_DENSE_XCD
+#define VP_DENSE_XCD 0
+#endif
+    // Workgroups are dealt round-robin to the 8 XCDs (dispatch index mod 8), each with its own L2, so neighbouring tiles --
+    // which share halo rows and planes -- land on different L2s.  Re-mapping the dispatch index so that each XCD walks one
+    // contiguous eighth of the tile sequence (-DVP_DENSE_XCD=1) was measured twice (round 1: +-0; round 2, tools/ab_pass.py:
+    // -1 % .. +1 % at n = 512, 0 .. -4 % at n = 1024): the halos come from the Infinity Cache either way.  Off.
+    uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t total = gridDim.x * gridDim.y;
+    if (VP_DENSE_XCD && total % 8u == 0u) lin = (lin % 8u) * (total / 8u) + lin / 8u;
+    if (rev) lin = total - 1u - lin;
+    const uint32_t bx = lin % gridDim.x, by = lin / gridDim.x;
     const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
     const int nres = min(K, nzl);
     const int lbase = (int)(by % nres) + (int)(by / nres) * CH * K;
@@ -948,14 +958,21 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
         // of the wave has (it would re-evaluate the centre column, which cannot change the result).  Dense passes keep the
         // branch-free form: out-of-grid rows read a row of "none".
         const bool anyM = !SKIP || __any(hasM), anyP = !SKIP || __any(hasP);
-        auto row_exists = [&](int zg, int rr, bool needed) { return needed && zg >= 0 && zg < N && yv[rr]; };
-        // ids of row rr of source plane zg -> w[rr*3 ..]: columns {x-k, x, x+k}; "none" where outside the grid or not needed
-        auto load_row = [&](int zg, int rr, T (&w)[NI], bool needed) {
-            const bool ok = row_exists(zg, rr, needed);
+        // A source plane: its base address (wave-uniform, computed once per plane, right where the plane is first used) and
+        // whether it exists at all (inside the grid, and needed by an output plane of this tile that exists).
+        struct Plane { const char* base; bool ok; };
+        auto plane_of = [&](int zg, bool needed) {
+            Plane pl;
+            pl.ok = needed && zg >= 0 && zg < N;
+            pl.base = opaque_uniform(reinterpret_cast<const char*>(in) + ((ptrdiff_t)(pl.ok ? zg : (int)f.z0) - (ptrdiff_t)f.z0) * (ptrdiff_t)planeBytes);
+            return pl;
+        };
+        // ids of row rr of a source plane -> w[rr*3 ..]: columns {x-k, x, x+k}; "none" where outside the grid or not needed
+        auto load_row = [&](const Plane& pl, int rr, T (&w)[NI]) {
+            const bool ok = pl.ok && yv[rr];
             if (SKIP && !ok) return;
-            const char* pl = opaque_uniform(reinterpret_cast<const char*>(in) + ((ptrdiff_t)(ok ? zg : (int)f.z0) - (ptrdiff_t)f.z0) * (ptrdiff_t)planeBytes);
             const __amdgpu_buffer_rsrc_t b =
-                row_resource(ok ? pl + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
+                row_resource(ok ? pl.base + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
             if (anyM) row_load(w[rr * 3 + 0], b, xmo);
             row_load(w[rr * 3 + 1], b, xo);
             if (anyP) row_load(w[rr * 3 + 2], b, xpo);
@@ -967,10 +984,13 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
             // rank of the ids of this plane: byte offset of the row inside the gather window + 1 (wave-uniform) + the column offset
             const uint32_t prank = (uint32_t)((zbase + P * K - zlo) * (ptrdiff_t)planeBytes) + 1u;
             const int olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
+            const bool curOk = P <= nout && zbase + P * K >= 0 && zbase + P * K < N;      // SKIP: does this source plane exist
+            Plane next{nullptr, false};
+            if (ROLL && P + 1 <= CH) next = plane_of(zbase + (P + 1) * K, P + 1 <= nout);
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
                 const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1);
-                if (!SKIP || row_exists(zbase + P * K, rr, P <= nout)) {
+                if (!SKIP || (curOk && yv[rr])) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         if (SKIP && ((c == 0 && !anyM) || (c == 2 && !anyP))) continue;
@@ -1019,7 +1039,7 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
                 // Rolling prefetch: the three ids of this row are spent, so the same row of the NEXT source plane is
                 // requested into their registers right away -- a whole plane of evaluation ahead of its use, without a
                 // second id buffer (18 VGPRs).  A plane that is not needed reads "none" (never memory past the slab's halo).
-                if (ROLL && P + 1 <= CH) load_row(zbase + (P + 1) * K, rr, w, P + 1 <= nout);
+                if (ROLL && P + 1 <= CH) load_row(next, rr, w);
             }
         };
 
@@ -1028,15 +1048,19 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
         // buffers are 3 % ahead, at n = 1024 the rolling refill is 5 % ahead.
         T w[NI], w2[ROLL ? 1 : NI];
         T pend[RY];                                                // gathered winners of the previous output plane, stored a plane later
+        {
+            const Plane first = plane_of(zbase - K, true);
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr) load_row(zbase - K, rr, w, true);
+            for (int rr = 0; rr < NR; ++rr) load_row(first, rr, w);
+        }
 #pragma clang loop unroll(full)
         for (int P = -1; P <= CH; ++P) {
             T (&cur)[NI] = (ROLL || !((P + 1) & 1)) ? w : reinterpret_cast<T (&)[NI]>(w2);
             if (!ROLL && P + 1 <= CH) {
                 T (&nxt)[NI] = ((P + 1) & 1) ? w : reinterpret_cast<T (&)[NI]>(w2);
+                const Plane np = plane_of(zbase + (P + 1) * K, P + 1 <= nout);
 #pragma unroll
-                for (int rr = 0; rr < NR; ++rr) load_row(zbase + (P + 1) * K, rr, nxt, P + 1 <= nout);
+                for (int rr = 0; rr < NR; ++rr) load_row(np, rr, nxt);
             }
             if (P + 1 < CH) {
 #pragma unroll
@@ -1058,11 +1082,11 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
                 }
             } else {
                 if (P >= 2 && P - 2 < nout) {                      // ids gathered during the previous plane
+                    const char* orow = opaque_uniform(reinterpret_cast<const char*>(out) + ((size_t)(lbase + (P - 2) * K) * N + ybase) * rowBytes);
 #pragma unroll
                     for (int a = 0; a < RY; ++a) {
                         if (a >= yout) continue;
-                        const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (P - 2) * K) * N + (ybase + a * K);
-                        row_store(pend[a], row_resource(out + rowIdx * N, rowBytes), xo);
+                        row_store(pend[a], row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
                     }
                 }
                 if (P >= 1 && P - 1 < nout) {                      // output plane P - 1 is complete: fetch the ids of its winners
@@ -1089,11 +1113,11 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
         }
         if constexpr (!FINAL) {
             if (CH - 1 < nout) {
+                const char* orow = opaque_uniform(reinterpret_cast<const char*>(out) + ((size_t)(lbase + (CH - 1) * K) * N + ybase) * rowBytes);
 #pragma unroll
                 for (int a = 0; a < RY; ++a) {
                     if (a >= yout) continue;
-                    const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (CH - 1) * K) * N + (ybase + a * K);
-                    row_store(pend[a], row_resource(out + rowIdx * N, rowBytes), xo);
+                    row_store(pend[a], row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
                 }
             }
         }
