@@ -61,6 +61,7 @@ struct Id32 {                     // n <= 1024: bits [2..11] x, [12..21] scr(z),
     __device__ static __forceinline__ uint32_t zoff(T a) { return (a >> 10) & kMask; }
     __device__ static __forceinline__ uint32_t yoff(T a) { return (a >> 20) & kMask; }
     __device__ static __forceinline__ T sel(bool c, T a, T b) { return c ? a : b; }
+    __device__ static __forceinline__ T join(T a, T b) { return a | b; }               // ids packed from disjoint coordinates
     __device__ static __forceinline__ T shfl(T a, int src) { return (T)__shfl((int)a, src); }
 };
 
@@ -76,6 +77,7 @@ struct Id64 {                     // n <= 2048: .x = scr(z)<<2 | x<<13, .y = scr
     __device__ static __forceinline__ uint32_t xoff(T a) { return (a.x >> 11) & kMask; }
     __device__ static __forceinline__ uint32_t yoff(T a) { return a.y & kMask; }
     __device__ static __forceinline__ T sel(bool c, T a, T b) { return make_uint2(c ? a.x : b.x, c ? a.y : b.y); }
+    __device__ static __forceinline__ T join(T a, T b) { return make_uint2(a.x | b.x, a.y | b.y); }
     __device__ static __forceinline__ T shfl(T a, int src) { return make_uint2((uint32_t)__shfl((int)a.x, src), (uint32_t)__shfl((int)a.y, src)); }
 };
 
@@ -222,13 +224,18 @@ jfa_pass_direct(Frame f, uint32_t k, const typename ID::T* __restrict__ in, cons
 // volume at all -- a candidate exists iff its border bit is set and its id is its own coordinates.  This
 // drops the id volume jfa_init would write and this pass would read back.
 // One wave = one 64-voxel x-segment.  Requires n % 128 == 0, so k is a multiple of 64 and every candidate
-// segment of a wave is exactly two aligned mask words.  Lane q of the wave fetches the words of candidate
-// segment q -- ONE vector load instruction per wave and row (the vector-memory instruction rate, not bytes,
-// is what limits these kernels; one scalar load per segment was measured 10x slower: the scalar cache
-// thrashes on 16 lines per wave) -- and v_readlane distributes the masks as wave-uniform values, so
-// segments without border bits are skipped with scalar branches.  The pass is a pure store stream.
+// segment of a wave is exactly two aligned mask words.  With k = n/2 exactly one of -k / +k is inside the grid per axis,
+// wave-uniformly: 8 candidate segments (the own one + 7), not 27.  Lane q < 8 fetches the words of segment q -- ONE vector
+// load instruction per wave and row (one scalar load per segment was measured 10x slower: the scalar cache thrashes) --
+// and v_readlane distributes the masks as wave-uniform values, so empty segments are skipped with scalar branches.  The
+// per-axis squared differences and id parts are formed once per wave / row, a candidate costs two adds and the
+// compare + selects.  (Round 1 walked all 27 candidate slots with per-candidate index arithmetic on the scalar unit:
+// 43 SALU + 57 VALU per row and the CU's scalar unit 66 % busy; profiles/r01.)
 // `border` is the border mask of the WHOLE grid (vp_surface); the kernel produces the planes of `f`.
-constexpr int kFirstRows = 8;     // rows per wave: their mask loads are all in flight before the first is used
+#ifndef VP_FIRST_ROWS
+#define VP_FIRST_ROWS 16
+#endif
+constexpr int kFirstRows = VP_FIRST_ROWS;     // rows per wave: their mask loads are all in flight before the first is used
 
 template <class ID>
 __global__ void __launch_bounds__(256)
@@ -236,6 +243,7 @@ jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, typenam
 {
     using T = typename ID::T;
     const int N = (int)f.n;
+    const int K = (int)k;                                           // = n / 2: per axis exactly one of -k / +k is inside the grid
     const int lane = threadIdx.x & 63;
     const int x0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 256u + (threadIdx.x & ~63u)));   // segment start
     if (x0 >= N) return;                                            // whole wave
@@ -243,48 +251,62 @@ jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, typenam
     const int ybase = blockIdx.y * kFirstRows;
     const int zl = blockIdx.z;
     const int zg = zl + (int)f.z0;
+    // The in-grid neighbour along each axis (wave-uniform: k is a multiple of 64, the rows of a wave are 8-aligned): 8
+    // candidate segments in all -- the own one and 7 others -- instead of the 27 of a general pass.
+    const int ax = x0 < K ? K : -K, ay = ybase < K ? K : -K, az = zg < K ? K : -K;
 
-    const int q = lane;
-    const int qz = zg + (q / 9 - 1) * (int)k, qdy = ((q / 3) % 3 - 1) * (int)k, qx0 = x0 + (q % 3 - 1) * (int)k;
-    const bool qin = q < 27 && qz >= 0 && qz < N && qx0 >= 0 && qx0 < N;
+    // Lane L < 8 fetches the two mask words of the L-th candidate segment IN SCAN ORDER (z, y, x; sequential.cpp:86-88):
+    // bit 2 / 1 / 0 of L = second position along z / y / x, where the first position is the neighbour if it lies at -k and
+    // the voxel's own coordinate otherwise.  s = 1 marks the neighbour.
+    const int sx0 = ax < 0, sy0 = ay < 0, sz0 = az < 0;               // is the FIRST position along the axis the neighbour?
+    const int bxL = (lane & 1) ^ sx0, byL = ((lane >> 1) & 1) ^ sy0, bzL = ((lane >> 2) & 1) ^ sz0;
+    const int ownLane = sz0 * 4 + sy0 * 2 + sx0;                       // the voxel's own segment (all three on "own")
     uint2 mine[kFirstRows];
 #pragma unroll
     for (int r = 0; r < kFirstRows; ++r) {
-        const int ny = ybase + r + qdy;
         mine[r] = make_uint2(0u, 0u);
-        if (qin && ny >= 0 && ny < N)
-            mine[r] = *reinterpret_cast<const uint2*>(border + ((((size_t)qz * N + ny) * N + qx0) >> 5));   // 8-byte aligned: qx0 % 64 == 0
+        if (lane < 8)
+            mine[r] = *reinterpret_cast<const uint2*>(border + ((((size_t)(zg + bzL * az) * N + (ybase + r + byL * ay)) * N + (x0 + bxL * ax)) >> 5));
     }
+    // Per axis and position: squared coordinate difference (0 to oneself: fl(p - p) = 0 exactly) and id part -- the
+    // reference's expressions (jfa/jfa.h:19-20, sequential.cpp:79-81), evaluated once per wave / row instead of per candidate.
     const float px = axis_pos(f.ox, x, f.vs), pz = axis_pos(f.oz, zg, f.vs);
+    const float ddxv = axis_pos(f.ox, x + ax, f.vs) - px, ddzv = axis_pos(f.oz, zg + az, f.vs) - pz;
+    const float dxx = ddxv * ddxv, dzz = ddzv * ddzv;
+    const float dxs[2] = {sx0 ? dxx : 0.0f, sx0 ? 0.0f : dxx}, dzs[2] = {sz0 ? dzz : 0.0f, sz0 ? 0.0f : dzz};
+    const T idxOwn = ID::pack((uint32_t)x, 0u, 0u), idxNb = ID::pack((uint32_t)(x + ax), 0u, 0u);
+    const T idzOwn = ID::pack(0u, 0u, (uint32_t)zg), idzNb = ID::pack(0u, 0u, (uint32_t)(zg + az));
+    const T idxs[2] = {ID::sel(sx0, idxNb, idxOwn), ID::sel(sx0, idxOwn, idxNb)};
+    const T idzs[2] = {ID::sel(sz0, idzNb, idzOwn), ID::sel(sz0, idzOwn, idzNb)};
 #pragma unroll
     for (int r = 0; r < kFirstRows; ++r) {
         const int y = ybase + r;
-        const unsigned long long own = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].x, 13) |
-                                       ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].y, 13) << 32);
+        const unsigned long long own = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].x, ownLane) |
+                                       ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].y, ownLane) << 32);
+        const float py = axis_pos(f.oy, y, f.vs);
+        const float ddyv = axis_pos(f.oy, y + ay, f.vs) - py;
+        const float dyy = ddyv * ddyv;
+        const float dys[2] = {sy0 ? dyy : 0.0f, sy0 ? 0.0f : dyy};
+        const T idyOwn = ID::pack(0u, (uint32_t)y, 0u), idyNb = ID::pack(0u, (uint32_t)(y + ay), 0u);
+        const T idys[2] = {ID::sel(sy0, idyNb, idyOwn), ID::sel(sy0, idyOwn, idyNb)};
         T best = ID::none();
         float bestd = INFINITY;
-        if ((own >> lane) & 1ull) { best = ID::pack(x, y, zg); bestd = 0.0f; }           // own seed: distance 0 (:56)
-        // One ballot gives the set of neighbour segments that hold a border voxel at all; only those are visited, in
-        // ascending candidate index = reference scan order z, y, x (sequential.cpp:86-88).
-        unsigned long long todo = __ballot(lane != 13 && lane < 27 && (mine[r].x | mine[r].y) != 0u);
+        if ((own >> lane) & 1ull) { best = ID::join(ID::join(idxOwn, idyOwn), idzOwn); bestd = 0.0f; }   // own seed: distance 0 (:56)
+        // one ballot = the set of neighbour segments that hold a border voxel at all; only those are evaluated, in lane order
+        const uint32_t todo = (uint32_t)__ballot(lane < 8 && lane != ownLane && (mine[r].x | mine[r].y) != 0u);
         if (todo) {
-            const float py = axis_pos(f.oy, y, f.vs);
-            do {
-                const int c = __builtin_ctzll(todo);               // wave-uniform
-                todo &= todo - 1;
-                const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].x, c) |
-                                             ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine[r].y, c) << 32);
-                const int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (!((todo >> c) & 1u)) continue;                  // wave-uniform
+                const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)mine[r].x, c), mhi = (uint32_t)__builtin_amdgcn_readlane((int)mine[r].y, c);
+                const unsigned long long m = (unsigned long long)mlo | ((unsigned long long)mhi << 32);
                 const bool has = (m >> lane) & 1ull;
-                // the candidate's coordinates are known without unpacking an id: y and z parts are wave-uniform
-                const uint32_t sxi = (uint32_t)(x + dx * (int)k), syi = (uint32_t)(y + dy * (int)k), szi = (uint32_t)(zg + dz * (int)k);
-                const float ddx = axis_pos(f.ox, sxi, f.vs) - px, ddy = axis_pos(f.oy, syi, f.vs) - py, ddz = axis_pos(f.oz, szi, f.vs) - pz;
-                const float d = ((ddx * ddx) + (ddy * ddy)) + (ddz * ddz);                   // jfa/jfa.h:19-20
-                const T id = ID::pack(sxi, syi, szi);
+                const float d = (dxs[c & 1] + dys[(c >> 1) & 1]) + dzs[(c >> 2) & 1];                     // jfa/jfa.h:19-20
+                const T id = ID::join(ID::join(idxs[c & 1], idys[(c >> 1) & 1]), idzs[(c >> 2) & 1]);
                 const bool take = has & (d < bestd);
                 bestd = take ? d : bestd;
                 best = ID::sel(take, id, best);
-            } while (todo);
+            }
         }
         out[((size_t)zl * N + y) * N + x] = best;
     }
