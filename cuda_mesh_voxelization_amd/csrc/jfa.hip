@@ -7,7 +7,7 @@
 //
 // State: the reference keeps float sdf + float3 seed position per voxel (16 B, two copies, plus a
 // deep copy per pass, :123-124).  Here the state is ONE packed id per voxel -- the voxel coordinates of
-// the best seed so far (4 bytes for n <= 1024, 8 bytes for n <= 2048; "none" = all ones).  The seed
+// the best seed so far (4 bytes for n <= 1024 -- two layouts, n <= 512 and above --, 8 bytes for n <= 2048).  The seed
 // position and the distance are recomputed from it with the reference's expressions, which gives the
 // same floats because the reference's stored sdf is itself the result of exactly that expression.
 // Ping-pong between two id volumes; the last step converts ids to floats.
@@ -41,29 +41,38 @@ namespace {
 // involution and stays inside [0, n) because n % 32 == 0.
 __device__ __forceinline__ uint32_t scr(uint32_t i) { return i ^ ((i >> 5) & 31u); }
 
-// Id formats.  Every coordinate field is stored pre-multiplied by 4, i.e. it already is a byte offset into
-// a float table after one shift+mask.  In the 32-bit format x sits in the lowest field: its table (seed x
-// positions) has 4-byte entries, so a single AND is its byte offset, while the y / z tables of the dense kernel
-// have 16- / 32-byte entries (one entry = the squared differences to all output rows / planes of the tile, fetched
-// with one wide LDS read) and need a shift + mask anyway.  A real id has bits 0,1 of its first word clear,
-// "none" has them set.
-struct Id32 {                     // n <= 1024: bits [2..11] x, [12..21] scr(z), [22..31] scr(y)
+// Id formats.  An accessor returns a coordinate field as a BYTE offset into a table of floats (index * 4).
+//
+// 32-bit formats IdU<BITS> (BITS = 9: n <= 512, BITS = 10: n <= 1024).  x sits UNSHIFTED in the low BITS + 1 bits -- its
+// top bit is set only in "none", whose x index 2^BITS is therefore the first slot no real id uses: the x table has 2^BITS + 1
+// entries with +inf in the last one, and "none" gets an infinite distance through the ordinary lookup at every n (no test, no
+// spare-slot tricks in the y / z tables).  y and z follow, each preceded by zero guard bits where the 32 bits allow it, so
+// that their byte offsets come out of ONE instruction:
+//   BITS = 9 :  x [0..9] | 00 | scr(y) [12..20] | 00 | scr(z) [23..31]     yoff = bfe(id, 10, 11), zoff = id >> 21, xoff = (id & 0x3FF) << 2
+//   BITS = 10:  x [0..10] | scr(y) [11..20] | 0 | scr(z) [22..31]          yoff, zoff = shift + mask, xoff = (id & 0x7FF) << 2
+// (four / six decode instructions per id; round 1's layout -- three pre-shifted 10-bit fields -- needed five + a none test at n = 1024).
+template <int BITS>
+struct IdU {
     using T = uint32_t;
-    static constexpr int kTab = 1024;             // table entries: any 10-bit field (also those of none) stays in bounds
-    static constexpr uint32_t kMask = 0xFFCu;
-    // "none": y and z fields all ones, x field = 512 -- for n <= 512 the first x slot no real id uses, so the x table of
-    // the tile kernels needs 513 entries (slot 512 = +inf) instead of 1024, which is what lets six workgroups share a CU's LDS.
-    __device__ static __forceinline__ T none() { return kNone; }
-    __device__ static __forceinline__ bool is_none(T a) { return a == kNone; }
-    __device__ static __forceinline__ T pack(uint32_t x, uint32_t y, uint32_t z) { return (x << 2) | (scr(z) << 12) | (scr(y) << 22); }
-    __device__ static __forceinline__ T add_x(T a, uint32_t dx) { return a + (dx << 2); }
-    __device__ static __forceinline__ uint32_t xoff(T a) { return a & kMask; }
-    __device__ static __forceinline__ uint32_t zoff(T a) { return (a >> 10) & kMask; }
-    __device__ static __forceinline__ uint32_t yoff(T a) { return (a >> 20) & kMask; }
+    static constexpr int kTab = 1 << BITS;        // entries of the y / z tables; the x table has kTab + 1
+    static constexpr uint32_t kMask = (uint32_t)(kTab - 1) * 4u;
+    static constexpr int kYS = BITS == 9 ? 12 : 11, kZS = BITS == 9 ? 23 : 22;
+    static constexpr uint32_t kXMask = (2u << BITS) - 1u;
+    static constexpr T kNoneValue = (1u << BITS) | ((uint32_t)(kTab - 1) << kYS) | ((uint32_t)(kTab - 1) << kZS);
+    __device__ static __forceinline__ T none() { return kNoneValue; }
+    __device__ static __forceinline__ bool is_none(T a) { return a == kNoneValue; }
+    __device__ static __forceinline__ T pack(uint32_t x, uint32_t y, uint32_t z) { return x | (scr(y) << kYS) | (scr(z) << kZS); }
+    __device__ static __forceinline__ T add_x(T a, uint32_t dx) { return a + dx; }
+    __device__ static __forceinline__ uint32_t xoff(T a) { return (a & kXMask) << 2; }            // <= 4 * kTab ("none")
+    __device__ static __forceinline__ uint32_t yoff(T a) { return BITS == 9 ? __builtin_amdgcn_ubfe(a, 10u, 11u) : ((a >> (kYS - 2)) & kMask); }
+    __device__ static __forceinline__ uint32_t zoff(T a) { return BITS == 9 ? (a >> 21) : ((a >> (kZS - 2)) & kMask); }
     __device__ static __forceinline__ T sel(bool c, T a, T b) { return c ? a : b; }
     __device__ static __forceinline__ T join(T a, T b) { return a | b; }               // ids packed from disjoint coordinates
     __device__ static __forceinline__ T shfl(T a, int src) { return (T)__shfl((int)a, src); }
 };
+using Id9 = IdU<9>;
+using Id10 = IdU<10>;
+static_assert(Id9::kNoneValue == kNone9 && Id10::kNoneValue == kNone10, "vp_internal.h");
 
 struct Id64 {                     // n <= 2048: .x = scr(z)<<2 | x<<13, .y = scr(y)<<2
     using T = uint2;
@@ -312,6 +321,8 @@ jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, typenam
     }
 }
 
+constexpr int kTableKernelTab = 1024;   // entries per table of jfa_pass_table (every field offset of Id9, "none" included, stays inside)
+
 // Table variant for small grids (n < 256, 32-bit ids).  Workgroup = RY consecutive x-rows of one z.
 // LDS: PX[i] = ox + i*vs; TZ[i] = (PZ[i]-pz)^2 for this z; TY[r][i] = (PY[i]-py_r)^2 for row r.
 // dist = ((PX[ix]-px)^2 + TY[iy]) + TZ[iz]  -- the same float operations as seed_distance().
@@ -319,8 +330,8 @@ __global__ void __launch_bounds__(256)
 jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
                const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, int RY)
 {
-    using ID = Id32;
-    constexpr int kTab = ID::kTab;
+    using ID = Id9;                                                // n < 256
+    constexpr int kTab = kTableKernelTab;
     extern __shared__ float lds[];
     float* PX = lds;
     float* TZ = lds + kTab;
@@ -377,9 +388,9 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
             const uint32_t* rw = rows[q];
-            c[q * 3 + 0] = (rw && hasM) ? rw[xm] : kNone;
-            c[q * 3 + 1] = rw ? rw[x] : kNone;
-            c[q * 3 + 2] = (rw && hasP) ? rw[xp] : kNone;
+            c[q * 3 + 0] = (rw && hasM) ? rw[xm] : ID::none();
+            c[q * 3 + 1] = rw ? rw[x] : ID::none();
+            c[q * 3 + 2] = (rw && hasP) ? rw[xp] : ID::none();
         }
         uint32_t best = c[13];
         float bestd = INFINITY;
@@ -393,7 +404,7 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
             const float dz2 = *reinterpret_cast<const float*>(tz + ID::zoff(id));
             const float dxv = sx - px;
             const float d = ((dxv * dxv) + dy2) + dz2;
-            const bool take = (id != kNone) && (d < bestd);
+            const bool take = !ID::is_none(id) && (d < bestd);
             bestd = take ? d : bestd;
             best = take ? id : best;
         }
@@ -537,8 +548,12 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
     using T = typename ID::T;
     constexpr int kTab = TAB;                                      // table entries; fields are masked to it
     constexpr uint32_t kField = (uint32_t)(TAB - 1) * 4u;
-    constexpr uint32_t kFieldX = (uint32_t)(PXT - 1) * 4u;          // PXT = 2*TAB: slot PXT-1 (the x field of "none") holds +inf
-    static_assert(PXT == TAB || !CHECK_NONE, "a wide x table replaces the none check");
+    // 32-bit ids: PXT = TAB + 1, slots n .. TAB hold +inf -- the x index of "none" is TAB (IdU), so "none" gets an infinite
+    // distance through the ordinary lookup and the offset needs no mask.  64-bit ids: PXT = TAB, fields masked to the table,
+    // "none" (all ones) is caught by the spare y / z slot or a test.
+    constexpr bool kU = !std::is_same<ID, Id64>::value;
+    constexpr uint32_t kFieldX = (uint32_t)(PXT - 1) * 4u;
+    static_assert(!kU || PXT == TAB + 1, "x table of the 32-bit formats");
     constexpr int NR = RY + 2;                                     // source rows of a plane: ybase - k .. ybase + RY*k
     constexpr int NI = NR * 3;                                     // ids per thread and plane
     __shared__ float PX[PXT];
@@ -672,7 +687,7 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                 const int rr = q / 3, c = q % 3;
                 const T id = w[q];
                 auto body = [&]() {
-                    const float sx = lds_f32(tx + (ID::xoff(id) & kFieldX));
+                    const float sx = lds_f32(tx + (kU ? ID::xoff(id) : (ID::xoff(id) & kFieldX)));
                     const float dxv = sx - px;
                     // FINAL keeps distances only: "none" is given an infinite distance here, once per id
                     // n == table size has no spare +inf table slot for "none": the dense variants give it an infinite distance
@@ -863,22 +878,15 @@ __device__ __forceinline__ void lds_span(const char* base, uint32_t off, int lo,
 
 // occupancy the register allocation aims at: six waves per SIMD where the LDS footprint allows six workgroups (2-KB tables)
 // or three 512-thread ones (4-KB tables); the 256-thread variant with 4-KB tables is LDS-limited to four
-template <int TAB, int RY, int CH, int EY, int EZ, int NT, bool CHECK_NONE, bool FINAL, bool ROLL, bool SKIP>
-__global__ void __launch_bounds__(NT, (TAB == 512 || NT == 512) ? 6 : 4)
+template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP>
+__global__ void __launch_bounds__(NT, (ID::kTab == 512 || NT == 512) ? 6 : 4)
 jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
 {
-    using ID = Id32;
     using T = uint32_t;
-    // x table: n <= 512: 513 entries, slot 512 (the x field of "none") = +inf; else every 10-bit field, and "none" gets its
-    // infinite distance from the z tables (slot 1023 is no real scrambled coordinate for n < 1024) or from a test (n = 1024)
-    constexpr int PXT = TAB == 512 ? 513 : 1024;
-    constexpr uint32_t kFieldX = 0xFFCu;
-    static_assert(((kNone >> 2) & 1023u) == 512u, "x field of none = 512");
-    constexpr int YB = EY * 4, ZB = EZ * 4;                        // bytes per TY / TZ entry (EY / EZ floats: 1, 2 or 4)
-    static_assert(RY % EY == 0 && CH % EZ == 0, "sub-tables");
-    constexpr int YSH = 22 - (EY == 1 ? 2 : EY == 2 ? 3 : 4), ZSH = 12 - (EZ == 1 ? 2 : EZ == 2 ? 3 : 4);   // field position -> entry byte offset
-    constexpr uint32_t kFieldY = (uint32_t)(TAB - 1) * YB, kFieldZ = (uint32_t)(TAB - 1) * ZB;
+    constexpr int TAB = ID::kTab;
+    constexpr int PXT = TAB + 1;                                   // slot TAB = the x index of "none" = +inf
+    constexpr int EY = 1, EZ = 1;                                  // floats per table entry (wider entries: measured slower)
     constexpr int NR = RY + 2;
     constexpr int NI = NR * 3;
     using B = typename std::conditional<FINAL, float, double>::type;
@@ -924,11 +932,11 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
             for (int j = 0; j < RY; ++j) { const float d = sy - py[j]; TY[j / EY][si][j % EY] = d * d; }
 #pragma unroll
             for (int j = 0; j < CH; ++j) { const float d = sz - pz[j]; TZ[j / EZ][si][j % EZ] = d * d; }
-        } else {                                                   // slots no real id refers to ("none" does: TAB - 1)
+        } else {                                                   // slots no real id refers to ("none" does: TAB - 1); finite: inf + it = inf
 #pragma unroll
             for (int j = 0; j < RY; ++j) TY[j / EY][i][j % EY] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < CH; ++j) TZ[j / EZ][i][j % EZ] = INFINITY;
+            for (int j = 0; j < CH; ++j) TZ[j / EZ][i][j % EZ] = 0.0f;
         }
     }
     if (FINAL) {
@@ -1017,10 +1025,10 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
                     for (int c = 0; c < 3; ++c) {
                         if (SKIP && ((c == 0 && !anyM) || (c == 2 && !anyP))) continue;
                         const T id = w[rr * 3 + c];
-                        const float sx = lds_f32(tx + (id & kFieldX));
+                        const float sx = lds_f32(tx + ID::xoff(id));                   // "none": slot TAB = +inf
                         const float dxv = sx - px;
-                        const float dx2 = (CHECK_NONE && ID::is_none(id)) ? INFINITY : dxv * dxv;   // n == 1024: no spare x slot for "none"
-                        const uint32_t yo = (id >> YSH) & kFieldY, zo = (id >> ZSH) & kFieldZ;
+                        const float dx2 = dxv * dxv;
+                        const uint32_t yo = ID::yoff(id), zo = ID::zoff(id);
                         float dy2[RY], dz2[CH];
 #if defined(VP_ABL_NOLDS)
                         for (int a = 0; a < RY; ++a) dy2[a] = __uint_as_float(yo + a);
@@ -1212,7 +1220,8 @@ int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const 
     if (wide(f)) {
         if (d_ids && d_border_words) VP_INIT(Id64, true, true); else if (d_ids) VP_INIT(Id64, true, false); else VP_INIT(Id64, false, true);
     } else {
-        if (d_ids && d_border_words) VP_INIT(Id32, true, true); else if (d_ids) VP_INIT(Id32, true, false); else VP_INIT(Id32, false, true);
+        if (f.n <= 512) { if (d_ids && d_border_words) VP_INIT(Id9, true, true); else if (d_ids) VP_INIT(Id9, true, false); else VP_INIT(Id9, false, true); }
+        else            { if (d_ids && d_border_words) VP_INIT(Id10, true, true); else if (d_ids) VP_INIT(Id10, true, false); else VP_INIT(Id10, false, true); }
     }
 #undef VP_INIT
     VP_HIP(hipGetLastError());
@@ -1233,7 +1242,8 @@ int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border,
     ProfScope p(ctx, VP_K_JFA_FIRST);
     const dim3 grid((f.n + 255) / 256, f.n / kFirstRows, f.z1 - f.z0);
     if (wide(f)) hipLaunchKernelGGL(jfa_first_pass<Id64>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint2*)d_out);
-    else         hipLaunchKernelGGL(jfa_first_pass<Id32>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint32_t*)d_out);
+    else if (f.n <= 512) hipLaunchKernelGGL(jfa_first_pass<Id9>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint32_t*)d_out);
+    else         hipLaunchKernelGGL(jfa_first_pass<Id10>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint32_t*)d_out);
     VP_HIP(hipGetLastError());
     return 0;
 }
@@ -1244,14 +1254,24 @@ bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo)
     return algo == VP_ALGO_TILED && f.n >= 256;
 }
 
-// One row of "none" per id format for out-of-grid reads: 2048 x 8 bytes of the 64-bit "none", then 1024 x 4 of the 32-bit one.
+// One row of "none" per id format for out-of-grid reads: 2048 x 8 bytes of the 64-bit "none", then 1024 x 4 of each 32-bit one.
 static int ensure_none_rows(vp_ctx* ctx)
 {
     if (ctx->none_row.ptr) return 0;
-    VP_TRY(reserve(ctx, ctx->none_row, 2048 * 8 + 1024 * 4));
-    VP_HIP(hipMemsetAsync(ctx->none_row.ptr, 0xFF, 2048 * 8, ctx->stream));
-    VP_HIP(hipMemsetD32Async((hipDeviceptr_t)((char*)ctx->none_row.ptr + 2048 * 8), (int)kNone, 1024, ctx->stream));
+    VP_TRY(reserve(ctx, ctx->none_row, 2048 * 8 + 2 * 1024 * 4));
+    char* p = (char*)ctx->none_row.ptr;
+    VP_HIP(hipMemsetAsync(p, 0xFF, 2048 * 8, ctx->stream));
+    VP_HIP(hipMemsetD32Async((hipDeviceptr_t)(p + 2048 * 8), (int)kNone9, 1024, ctx->stream));
+    VP_HIP(hipMemsetD32Async((hipDeviceptr_t)(p + 2048 * 8 + 1024 * 4), (int)kNone10, 1024, ctx->stream));
     return 0;
+}
+template <class ID>
+static const typename ID::T* none_row_of(vp_ctx* ctx)
+{
+    const char* p = (const char*)ctx->none_row.ptr;
+    if (std::is_same<ID, Id9>::value) p += 2048 * 8;
+    if (std::is_same<ID, Id10>::value) p += 2048 * 8 + 1024 * 4;
+    return (const typename ID::T*)p;
 }
 
 template <class ID>
@@ -1261,122 +1281,90 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     using T = typename ID::T;
     const uint32_t nz = f.z1 - f.z0;
     VP_TRY(ensure_none_rows(ctx));
-    const T* none_row = (const T*)((const char*)ctx->none_row.ptr + (sizeof(T) == 8 ? 0 : 2048 * 8));
+    const T* none_row = none_row_of<ID>(ctx);
     const bool skip = k * 4 >= f.n, fin = d_sdf != nullptr;
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k; // residue classes of the local plane index, planes per class
     const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
-    // Tile = RY rows x CH planes per workgroup and the table size; "none" needs an explicit check when the tables have no
-    // spare slot for it (n == table size).
+    // Tile = RY rows x CH planes per workgroup and the table size.
 #define VP_LAUNCH_CHAIN(TAB, PXT, RY, CH, S, C, F)                                                                                   \
     hipLaunchKernelGGL((jfa_pass_zstream<ID, TAB, PXT, RY, CH, S, C, F>),                                                            \
                        dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(256), 0, ctx->stream, f, k,         \
                        (const T*)d_in, (const T*)d_minus, (const T*)d_plus, (T*)d_out, none_row, d_words, fill, d_sdf)
-    // chk: n == table size, "none" has no spare table slot.  WIDEX: the dense variants then use an x table of twice the
-    // size whose last slot (the x field of "none") holds +inf, instead of testing every id.
-#define VP_LAUNCH_TILE(TAB, WIDEX, RY, CH, CHD)                                                                                      \
+    // 64-bit ids: chk = n == table size, "none" has no spare table slot -> explicit test.  32-bit ids (U): the x table has one
+    // more slot (+inf, the x index of "none"), "none" needs no test; the sparse variant keeps the flag all the same (most ids
+    // are "none" there and the flag skips their updates: 0.355 vs 0.377 ms, round 1).
+#define VP_LAUNCH_TILE(TAB, U, RY, CH, CHD)                                                                                          \
     do {                                                                                                                             \
-        const bool chk = (int)f.n >= TAB;                                                                                            \
+        const bool chk = !U && (int)f.n >= TAB;                                                                                      \
         const bool deep = zlen % CHD == 0;                        /* dense / last pass: longer plane chains when they divide evenly */ \
-        constexpr int PXW = WIDEX ? 2 * TAB : TAB;                                                                                   \
-        constexpr bool CW = !WIDEX;                               /* none check of the dense variants when n == TAB */                \
-        if (skip)      { if (chk) VP_LAUNCH_CHAIN(TAB, TAB, RY, CH, true, true, false);  else VP_LAUNCH_CHAIN(TAB, TAB, RY, CH, true, false, false); }  \
-        else if (fin && deep) { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, CW, true);  else VP_LAUNCH_CHAIN(TAB, TAB, RY, CHD, false, false, true); }  \
-        else if (fin)  { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, CW, true);   else VP_LAUNCH_CHAIN(TAB, TAB, RY, CH, false, false, true); }  \
-        else if (deep) { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, CW, false); else VP_LAUNCH_CHAIN(TAB, TAB, RY, CHD, false, false, false); } \
-        else           { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, CW, false);  else VP_LAUNCH_CHAIN(TAB, TAB, RY, CH, false, false, false); } \
+        constexpr int PXW = U ? TAB + 1 : TAB;                                                                                       \
+        if (skip)      { if (chk || U) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, true, true, false);  else VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, true, false, false); }  \
+        else if (fin && deep) { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, !U, true);  else VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, false, true); }  \
+        else if (fin)  { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, !U, true);   else VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, false, true); }  \
+        else if (deep) { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, !U, false); else VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, false, false); } \
+        else           { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, !U, false);  else VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, false, false); } \
     } while (0)
     if constexpr (std::is_same<ID, Id64>::value) VP_LAUNCH_TILE(Id64::kTab, false, kRowsWide, kPlanesWide, kPlanesWideDense);
-    else if (f.n <= 512) VP_LAUNCH_TILE(512, true, kRows, kPlanes, kPlanesDense);   // 2-KB tables (x: 4 KB at n = 512, -1.5 %)
-    else VP_LAUNCH_TILE(Id32::kTab, false, kRows, kPlanes, kPlanes);   // 4-KB tables: 4x8 costs occupancy (4.93 vs 4.70 ms at n = 1024)
+    else if constexpr (std::is_same<ID, Id9>::value) VP_LAUNCH_TILE(512, true, kRows, kPlanes, kPlanesDense);     // 2-KB tables
+    else VP_LAUNCH_TILE(1024, true, kRows, kPlanes, kPlanes);     // 4-KB tables: 4x8 costs occupancy (4.93 vs 4.70 ms at n = 1024)
 #undef VP_LAUNCH_TILE
 #undef VP_LAUNCH_CHAIN
     return 0;
 }
 
-#ifndef VP_DENSE_EY
-#define VP_DENSE_EY 1
-#endif
-#ifndef VP_DENSE_EZ
-#define VP_DENSE_EZ 1
-#endif
-// Dense tile kernel (jfa_pass_dense): 32-bit ids, dense passes and the fused last pass, id buffers contiguous.
+// Dense tile kernel (jfa_pass_dense): 32-bit ids, dense passes (and, as build options, the wide passes and the fused last
+// pass), id buffers contiguous.
 static int env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static bool dense_applies(const Frame& f, uint32_t k, const void* d_in, const void* d_minus, const void* d_plus, bool fin)
-{
-    // The fused last pass stays on jfa_pass_zstream: its distance-only update (v_min_f32) gains nothing from the pair
-    // minimum, and interleaved A/B runs have the round-1 kernel 0 - 5 % ahead on it (tools/ab_pass.py); build with
-    // -DVP_JFA_DENSE_FINAL=1 to route it here.
 #ifndef VP_JFA_DENSE_FINAL
-#define VP_JFA_DENSE_FINAL 0
+#define VP_JFA_DENSE_FINAL 0      // 1: route the fused last pass here too (measured 0 - 5 % behind jfa_pass_zstream<FINAL>, tools/ab_pass.py)
 #endif
-    if (fin && !VP_JFA_DENSE_FINAL) return false;
-    #ifndef VP_JFA_DENSE_DEFAULT
+#ifndef VP_JFA_DENSE_WIDEK
+#define VP_JFA_DENSE_WIDEK 0      // 1: route the wide passes (k >= n/4) here too (SKIP form; measured 5 - 9 % behind: they wait on
+#endif                            //    scattered row segments, not on VALU issue)
+#ifndef VP_JFA_DENSE_DEFAULT
 #define VP_JFA_DENSE_DEFAULT 1
 #endif
+
+static bool dense_applies(const Frame& f, uint32_t k, const void* d_in, const void* d_minus, const void* d_plus, bool fin)
+{
+    if (fin && !VP_JFA_DENSE_FINAL) return false;
     static const int enabled = env_int("VP_JFA_DENSE", VP_JFA_DENSE_DEFAULT);         // dev switch: 0 = round-1 kernel for every pass
-    // Wide passes (k >= n/4) stay on jfa_pass_zstream<SKIP>: the SKIP form of this kernel was measured 5 - 9 % slower there
-    // (those passes wait on scattered row segments, not on VALU issue); build with -DVP_JFA_DENSE_WIDEK=1 to try it.
-#ifndef VP_JFA_DENSE_WIDEK
-#define VP_JFA_DENSE_WIDEK 0
-#endif
     if (!enabled || wide(f) || (k * 4 >= f.n && !VP_JFA_DENSE_WIDEK)) return false;
     const size_t plane = (size_t)f.n * f.n * 4;
     const char* in = (const char*)d_in;
-    if (f.z0 > 0 && (const char*)d_minus + (size_t)k * plane != in) return false;
+    if (f.z0 > 0 && (const char*)d_minus + (size_t)k * plane != in) return false;      // the three id buffers must be one volume
     const uint32_t pbase = std::max(f.z1, f.z0 + k);
     if (f.z1 < f.n && (const char*)d_plus != in + (size_t)(pbase - f.z0) * plane) return false;
     return true;
 }
 
+template <class ID>
 static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
 {
     const uint32_t nz = f.z1 - f.z0;
     VP_TRY(ensure_none_rows(ctx));
-    const uint32_t* none_row = (const uint32_t*)((const char*)ctx->none_row.ptr + 2048 * 8);
+    const uint32_t* none_row = none_row_of<ID>(ctx);
     const bool fin = d_sdf != nullptr;
     const bool wideK = k * 4 >= f.n;                               // half of the neighbour rows / planes are outside the grid: SKIP variant
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k;
     const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
-    static const int forceCH = env_int("VP_JFA_DENSE_CH", 0), forceNT = env_int("VP_JFA_DENSE_NT", 0);
-#define VP_LAUNCH_DENSE(TAB, RY, CH, NT, C, F, S)                                                                                   \
-    hipLaunchKernelGGL((jfa_pass_dense<TAB, RY, CH, VP_DENSE_EY, VP_DENSE_EZ, NT, C, F, (TAB > 512 || VP_DENSE_ROLL512), S>),                                                                    \
-                       dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(NT), 0, ctx->stream, f, k,        \
+    // Tile 4 rows x 8 planes when the plane chains divide by 8, else 4 x 4.  2-KB tables (n <= 512): 256 threads, 26 KB of LDS,
+    // six workgroups per CU.  4-KB tables: the 4 x 8 tile takes 52 KB, shared by the 8 waves of a 512-thread workgroup (three per CU).
+#define VP_LAUNCH_DENSE(CH, NT, F, S)                                                                                              \
+    hipLaunchKernelGGL((jfa_pass_dense<ID, 4, CH, NT, F, true, S>),                                                                \
+                       dim3(nresY * ((ylen + 3) / 4), nres * ((zlen + CH - 1) / CH)), dim3(NT), 0, ctx->stream, f, k,              \
                        (const uint32_t*)d_in, (uint32_t*)d_out, none_row, d_words, fill, d_sdf)
-#ifndef VP_DENSE_ROLL512
-#define VP_DENSE_ROLL512 1
-#endif
-#ifndef VP_DENSE_RY
-#define VP_DENSE_RY 4
-#endif
-#define VP_DENSE_F(TAB, CH, NT, C) do { if (fin) VP_LAUNCH_DENSE(TAB, 4, CH, NT, C, (VP_JFA_DENSE_FINAL != 0), false); else if (wideK) VP_LAUNCH_DENSE(TAB, 4, CH, NT, C, false, (VP_JFA_DENSE_WIDEK != 0)); \
-                                          else VP_LAUNCH_DENSE(TAB, VP_DENSE_RY, CH, NT, C, false, false); } while (0)
-    bool deep = zlen % 8 == 0;
-    if (forceCH) deep = forceCH == 8;
-#ifndef VP_DENSE_NT512
-#define VP_DENSE_NT512 256
-#endif
-#ifndef VP_DENSE_NT512_WIDE
-#define VP_DENSE_NT512_WIDE 256
-#endif
-    if (f.n <= 512) {
-        if (wideK) { if (deep) VP_DENSE_F(512, 8, VP_DENSE_NT512_WIDE, false); else VP_DENSE_F(512, 4, VP_DENSE_NT512_WIDE, false); }
-        else       { if (deep) VP_DENSE_F(512, 8, VP_DENSE_NT512, false); else VP_DENSE_F(512, 4, VP_DENSE_NT512, false); }
-    } else {
-        // 4-KB x table + 16-byte / 32-byte entries: 4x8 tiles take 52 KB of LDS, shared by the 8 waves of a 512-thread workgroup
-        const bool chk = f.n >= 1024;
-#ifndef VP_DENSE_1024_BIG
-#define VP_DENSE_1024_BIG 1
-#endif
-        bool big = deep && VP_DENSE_1024_BIG;
-        if (forceNT) big = forceNT == 512;
-        if (big) { if (chk) VP_DENSE_F(1024, 8, 512, true); else VP_DENSE_F(1024, 8, 512, false); }
-        else     { if (chk) VP_DENSE_F(1024, 4, 256, true); else VP_DENSE_F(1024, 4, 256, false); }
-    }
+#define VP_DENSE_F(CH, NT) do { if (fin) VP_LAUNCH_DENSE(CH, NT, (VP_JFA_DENSE_FINAL != 0), false);                                \
+                                else if (wideK) VP_LAUNCH_DENSE(CH, NT, false, (VP_JFA_DENSE_WIDEK != 0));                          \
+                                else VP_LAUNCH_DENSE(CH, NT, false, false); } while (0)
+    const bool deep = zlen % 8 == 0;
+    if constexpr (ID::kTab == 512) { if (deep) VP_DENSE_F(8, 256); else VP_DENSE_F(4, 256); }
+    else                           { if (deep) VP_DENSE_F(8, 512); else VP_DENSE_F(4, 256); }
 #undef VP_DENSE_F
 #undef VP_LAUNCH_DENSE
     return 0;
@@ -1396,18 +1384,23 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
         if (wide(f))
             hipLaunchKernelGGL(jfa_pass_direct<Id64>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint2*)d_in,
                                (const uint2*)d_minus, (const uint2*)d_plus, (uint2*)d_out);
+        else if (f.n <= 512)
+            hipLaunchKernelGGL(jfa_pass_direct<Id9>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
+                               (const uint32_t*)d_minus, (const uint32_t*)d_plus, (uint32_t*)d_out);
         else
-            hipLaunchKernelGGL(jfa_pass_direct<Id32>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
+            hipLaunchKernelGGL(jfa_pass_direct<Id10>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
                                (const uint32_t*)d_minus, (const uint32_t*)d_plus, (uint32_t*)d_out);
     } else if (f.n >= 256 && dense_applies(f, k, d_in, d_minus, d_plus, d_sdf != nullptr)) {
-        VP_TRY(launch_dense(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        if (f.n <= 512) VP_TRY(launch_dense<Id9>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        else            VP_TRY(launch_dense<Id10>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
     } else if (f.n >= 256) {
         if (wide(f)) VP_TRY(launch_chain<Id64>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
-        else         VP_TRY(launch_chain<Id32>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
+        else if (f.n <= 512) VP_TRY(launch_chain<Id9>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
+        else         VP_TRY(launch_chain<Id10>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
     } else {
         const int RY = (int)(256 / f.n);
         const dim3 grid((f.n + RY - 1) / RY, nz);
-        const size_t lds = (size_t)(2 + RY) * Id32::kTab * sizeof(float);
+        const size_t lds = (size_t)(2 + RY) * kTableKernelTab * sizeof(float);
         hipLaunchKernelGGL(jfa_pass_table, grid, dim3(256), lds, ctx->stream, f, k, (const uint32_t*)d_in, (const uint32_t*)d_minus,
                            (const uint32_t*)d_plus, (uint32_t*)d_out, RY);
     }
@@ -1421,7 +1414,8 @@ int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const
     const unsigned blocks = (unsigned)((total4 + 255) / 256);
     ProfScope p(ctx, VP_K_JFA_FINAL);
     if (wide(f)) hipLaunchKernelGGL(jfa_final<Id64>, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint2*)d_ids, fill, (float4*)d_sdf);
-    else         hipLaunchKernelGGL(jfa_final<Id32>, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint32_t*)d_ids, fill, (float4*)d_sdf);
+    else if (f.n <= 512) hipLaunchKernelGGL(jfa_final<Id9>, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint32_t*)d_ids, fill, (float4*)d_sdf);
+    else         hipLaunchKernelGGL(jfa_final<Id10>, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint32_t*)d_ids, fill, (float4*)d_sdf);
     VP_HIP(hipGetLastError());
     return 0;
 }

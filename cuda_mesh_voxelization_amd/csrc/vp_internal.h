@@ -10,7 +10,9 @@
 
 namespace vp {
 
-constexpr uint32_t kNone = 0xFFFFF803u;   // JFA state (32-bit ids): no seed yet -- y, z fields all ones, x field 512 (jfa.hip, Id32)
+// JFA state "no seed yet" of the two 32-bit id formats (jfa.hip, IdU<9> / IdU<10>): y and z fields all ones, x = 2^BITS
+constexpr uint32_t kNone9 = 0xFF9FF200u;    // n <= 512
+constexpr uint32_t kNone10 = 0xFFDFFC00u;   // 512 < n <= 1024
 constexpr int kTile = 8;                  // voxelizer tile: 8x8 (y,z) columns = one wave64
 constexpr int kRecDwords = 20;            // per-triangle record, see vox.hip
 

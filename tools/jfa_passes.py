@@ -30,7 +30,8 @@ for algo in [int(x) for x in a.algos.split(",")]:
     out = torch.empty_like(cur)
     tot = 0.0
     for k, st in states:
-        seeds = int(((st[::idw] & 3) == 0).sum().item())         # real ids have bits 0,1 of their first word clear
+        none = -1 if idw == 2 else (0xFF9FF200 if n <= 512 else 0xFFDFFC00) - (1 << 32)   # jfa.hip: Id64 / IdU<9> / IdU<10> as int32
+        seeds = int((st[::idw] != none).sum().item())
         ctx.prof_reset(); ctx.prof_enable(True)
         for _ in range(a.reps):
             ctx.jfa_pass(fr, k, st.data_ptr(), None, None, out.data_ptr(), algo)
