@@ -1010,6 +1010,52 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
 
         B best[RY][CH];
 
+        // What an id turns into before its candidate steps: seed x, squared y differences to the output rows it serves, squared
+        // z differences to the output planes -- one LDS lookup each.
+        struct Dec { float sx; float dy2[RY]; float dz2[CH]; };
+        auto lookup = [&](int P, int rr, T id, Dec& d) {
+            const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
+            d.sx = lds_f32(tx + ID::xoff(id));                              // "none": slot TAB = +inf
+            const uint32_t yo = ID::yoff(id), zo = ID::zoff(id);
+#if defined(VP_ABL_NOLDS)
+            for (int a = 0; a < RY; ++a) d.dy2[a] = __uint_as_float(yo + a);
+            for (int o = 0; o < CH; ++o) d.dz2[o] = __uint_as_float(zo + o);
+#else
+            lds_span<RY, EY, TAB>(ty, yo, alo, ahi, d.dy2);
+            lds_span<CH, EZ, TAB>(tz, zo, olo, ohi, d.dz2);
+#endif
+        };
+        auto steps = [&](int P, int rr, int c, const Dec& d, uint32_t prank) {
+            const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
+            const float dxv = d.sx - px;
+            const float dx2 = dxv * dxv;
+            u32x2 cand;
+            if (!FINAL) cand.x = prank + ro[rr] + (c == 0 ? xmo : c == 1 ? xo : xpo);
+#pragma unroll
+            for (int a = alo; a <= ahi; ++a) {
+                const float pre = dx2 + d.dy2[a];
+                const bool ownRow = (rr == a + 1) && (c == 1);
+#pragma unroll
+                for (int o = olo; o <= ohi; ++o) {
+                    const float dd = pre + d.dz2[o];
+                    if constexpr (FINAL) {
+                        best[a][o] = min_f32(best[a][o], dd);
+                    } else {
+                        u32x2 cd = cand;
+                        if (ownRow && o == P) cd.x = 0u;                   // the voxel's own state wins every tie (sequential.cpp:84,106)
+                        cd.y = __float_as_uint(dd);
+#if defined(VP_ABL_NOMIN)
+                        { u32x2 t = __builtin_bit_cast(u32x2, best[a][o]); t.y = __float_as_uint(min_f32(__uint_as_float(t.y), dd)); best[a][o] = __builtin_bit_cast(double, t); }
+#else
+                        best[a][o] = min_f64(best[a][o], __builtin_bit_cast(double, cd));
+#endif
+                    }
+                }
+            }
+        };
+#ifndef VP_DENSE_PIPE
+#define VP_DENSE_PIPE (ID::kTab == 512)      // measured (tools/ab_step.py): -1.3 % at n = 512, +0.8 % at n = 1024
+#endif
         auto scatter = [&](int P, T (&w)[NI]) {
             // rank of the ids of this plane: byte offset of the row inside the gather window + 1 (wave-uniform) + the column offset
             const uint32_t prank = (uint32_t)((zbase + P * K - zlo) * (ptrdiff_t)planeBytes) + 1u;
@@ -1017,6 +1063,30 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
             const bool curOk = P <= nout && zbase + P * K >= 0 && zbase + P * K < N;      // SKIP: does this source plane exist
             Plane next{nullptr, false};
             if (ROLL && P + 1 <= CH) next = plane_of(zbase + (P + 1) * K, P + 1 <= nout);
+            if (VP_DENSE_PIPE && !SKIP) {
+                // Software pipeline over the 18 ids of the plane: the table lookups of id j + 1 are issued BEFORE the candidate
+                // steps of id j (the scheduling barriers keep the compiler from sinking them back to their first use), so a wave
+                // waits for LDS data a whole id of VALU work after asking for it instead of immediately.
+                Dec d[2];
+                lookup(P, 0, w[0], d[0]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int rr = j / 3, c = j % 3;
+                    if (j + 1 < NI) lookup(P, (j + 1) / 3, w[j + 1], d[(j + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    steps(P, rr, c, d[j & 1], prank);
+                    if (c == 2) {
+                        const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1);
+#pragma unroll
+                        for (int a = alo; a <= ahi; ++a)
+#pragma unroll
+                            for (int o = olo; o <= ohi; ++o) pin(best[a][o]);
+                        if (ROLL && P + 1 <= CH) load_row(next, rr, w);     // rolling prefetch (see below)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
                 const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1);
@@ -1024,42 +1094,9 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         if (SKIP && ((c == 0 && !anyM) || (c == 2 && !anyP))) continue;
-                        const T id = w[rr * 3 + c];
-                        const float sx = lds_f32(tx + ID::xoff(id));                   // "none": slot TAB = +inf
-                        const float dxv = sx - px;
-                        const float dx2 = dxv * dxv;
-                        const uint32_t yo = ID::yoff(id), zo = ID::zoff(id);
-                        float dy2[RY], dz2[CH];
-#if defined(VP_ABL_NOLDS)
-                        for (int a = 0; a < RY; ++a) dy2[a] = __uint_as_float(yo + a);
-                        for (int o = 0; o < CH; ++o) dz2[o] = __uint_as_float(zo + o);
-#else
-                        lds_span<RY, EY, TAB>(ty, yo, alo, ahi, dy2);
-                        lds_span<CH, EZ, TAB>(tz, zo, olo, ohi, dz2);
-#endif
-                        u32x2 cand;
-                        if (!FINAL) cand.x = prank + ro[rr] + (c == 0 ? xmo : c == 1 ? xo : xpo);
-#pragma unroll
-                        for (int a = alo; a <= ahi; ++a) {
-                            const float pre = dx2 + dy2[a];
-                            const bool ownRow = (rr == a + 1) && (c == 1);
-#pragma unroll
-                            for (int o = olo; o <= ohi; ++o) {
-                                const float d = pre + dz2[o];
-                                if constexpr (FINAL) {
-                                    best[a][o] = min_f32(best[a][o], d);
-                                } else {
-                                    u32x2 cd = cand;
-                                    if (ownRow && o == P) cd.x = 0u;           // the voxel's own state wins every tie (sequential.cpp:84,106)
-                                    cd.y = __float_as_uint(d);
-#if defined(VP_ABL_NOMIN)
-                                    { u32x2 t = __builtin_bit_cast(u32x2, best[a][o]); t.y = __float_as_uint(min_f32(__uint_as_float(t.y), d)); best[a][o] = __builtin_bit_cast(double, t); }
-#else
-                                    best[a][o] = min_f64(best[a][o], __builtin_bit_cast(double, cd));
-#endif
-                                }
-                            }
-                        }
+                        Dec d;
+                        lookup(P, rr, w[rr * 3 + c], d);
+                        steps(P, rr, c, d, prank);
                     }
 #pragma unroll
                     for (int a = alo; a <= ahi; ++a)
