@@ -641,17 +641,25 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
     for (int j = 1; j < RY; ++j) yout += (ybase + j * K < N) ? 1 : 0;
 #pragma unroll
     for (int j = 1; j < CH; ++j) nout += (zbase + j * K < (int)f.z1) ? 1 : 0;
-    uint32_t ro[NR];                                               // byte offsets of the source rows inside a plane
-    bool yv[NR];
-#pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {
-        const int ny = ybase + (rr - 1) * K;
-        yv[rr] = ny >= 0 && ny < N && max(rr - 2, 0) < yout;       // row rr serves output rows rr-2 .. rr
-        ro[rr] = (uint32_t)(yv[rr] ? ny : 0) * rowBytes;
-    }
     const uint32_t kb = k * (uint32_t)sizeof(T);
+#ifndef VP_ZSTREAM_OPAQUE
+#define VP_ZSTREAM_OPAQUE (TAB <= 512)      // measured (tools/ab_step.py): sparse -7.5 %, last -2 % at n = 512; +0.5 .. 1 % with the 4-KB tables
+#endif
+    const int zbase0 = zbase, ybase0 = ybase;
 
     for (uint32_t x = tid; x < (uint32_t)N; x += 256) {
+        // the uniform bases are re-read through an empty asm per x iteration, as in jfa_pass_dense: otherwise the addresses of
+        // all planes of the tile are hoisted out of the x loop and spilled to VGPR lanes
+        const int zbase = VP_ZSTREAM_OPAQUE ? (int)opaque_uniform((size_t)(uint32_t)zbase0) : zbase0;
+        const int ybase = VP_ZSTREAM_OPAQUE ? (int)opaque_uniform((size_t)(uint32_t)ybase0) : ybase0;
+        uint32_t ro[NR];                                           // byte offsets of the source rows inside a plane
+        bool yv[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const int ny = ybase + (rr - 1) * K;
+            yv[rr] = ny >= 0 && ny < N && max(rr - 2, 0) < yout;   // row rr serves output rows rr-2 .. rr
+            ro[rr] = (uint32_t)(yv[rr] ? ny : 0) * rowBytes;
+        }
         const float px = PX[x];
         const uint64_t ex = wave_exec();                           // EXEC of this iteration (the last one may be partial)
         const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
