@@ -57,7 +57,8 @@ struct Options {
 
 const char* kUsage =
     "CLI apps to test csg voxelization\nUsage:\n  cli [OPTION...] filenames...\n\n"
-    "  -n, --num-voxels arg  Number of voxel per side (default: 32)\n"
+    "  -n, --num-voxels arg  Number of voxel per side (default: 32); the GPU types (-t 1, -t 2) need a multiple of 32\n"
+    "                        in [32, 2048], the CPU types take any size\n"
     "  -t, --type arg        Type of processing (0 = sequential, 1 = naive, 2 = tiled, 3 = openmp) (default: 2)\n"
     "  -o, --output arg      Output filename (default: out.obj)\n"
     "  -p, --operation arg   CSG Operations (1 = union, 2 = inter, 3 = diff) (default: 0)\n"

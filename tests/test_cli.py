@@ -250,3 +250,14 @@ def test_cli_mesh_cache(cli, tmp_path):
     with open(obj + ".vpmesh", "r+b") as f:                                                # truncate: malformed cache is ignored
         f.truncate(100)
     assert np.array_equal(grid(env, "corrupt"), O.voxelize(xyz, tri, 64, vs, origin))
+
+
+@pytest.mark.gpu
+def test_cli_gpu_types_reject_unsupported_sizes_loudly(cli, tmp_path):
+    """The GPU variants need n % 32 == 0 (like the reference's kernels, vox/naive.cu:72-79): any other size exits non-zero with
+    the reference-style assert line instead of computing something else; the CPU types take the same size."""
+    p = subprocess.run([cli, M.asset("d20.obj"), "-n", "100", "-t", "2"], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "HIP Assert" in p.stdout and "n=100 unsupported" in p.stdout
+    p = subprocess.run([cli, M.asset("d20.obj"), "-n", "100", "-t", "0"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0
+    assert "multiple of 32" in subprocess.run([cli, "-h"], capture_output=True, text=True).stdout
