@@ -57,20 +57,22 @@ dx = torch.from_numpy(xyz).to(dev); dt = torch.from_numpy(tri.astype("int32")).t
 g = torch.zeros(fr.words, dtype=torch.int32, device=dev)
 L0 = libs[0]
 L0.ok(L0.L.vp_voxelize(L0.ctx, fr, g.data_ptr(), dx.data_ptr(), dx.shape[0], dt.data_ptr(), dt.shape[0], 2, 0))
-cur = torch.empty(fr.voxels, dtype=torch.int32, device=dev)
+idt = torch.int64 if n > 1024 else torch.int32                  # ids are 8 bytes above n = 1024
+cur = torch.empty(fr.voxels, dtype=idt, device=dev)
 L0.ok(L0.L.vp_jfa_init(L0.ctx, fr, g.data_ptr(), None, None, cur.data_ptr()))
 want = sorted({int(x) for x in a.k.split(",")} | ({1} if a.final else set()), reverse=True)
 states = {}
 k = n // 2
 while k >= 1:
-    if k in want: states[k] = cur.clone()
+    if k in want: states[k] = cur.clone() if len(want) > 1 else cur
     if k == min(want): break
     nxt = torch.empty_like(cur)
     L0.ok(L0.L.vp_jfa_pass(L0.ctx, fr, k, cur.data_ptr(), None, None, nxt.data_ptr(), 2))
     cur = nxt; k //= 2
 L0.L.vp_ctx_sync(L0.ctx)
-out = torch.empty(fr.voxels, dtype=torch.int32, device=dev)
-sdf = torch.empty(fr.voxels, dtype=torch.float32, device=dev)
+del cur
+out = torch.empty(fr.voxels, dtype=idt, device=dev)
+sdf = torch.empty(fr.voxels if a.final else 1, dtype=torch.float32, device=dev)
 cases = [("k=%d" % k, k) for k in [int(x) for x in a.k.split(",")]] + ([("final", 0)] if a.final else [])
 res = {(l.name, c): [] for l in libs for c, _ in cases}
 ref = {}
@@ -88,7 +90,8 @@ for r in range(a.rounds + 1):
                 chk = sdf.view(torch.int32)
             if r == 0:                                            # warm-up round: also compare results between the libraries
                 l.L.vp_ctx_sync(l.ctx)
-                h = int(chk.to(torch.int64).sum().item()) ^ int((chk.to(torch.int64) * torch.arange(chk.numel(), device=dev) % 1000003).sum().item())
+                c32 = chk.view(torch.int32)
+                h = sum(int(c.to(torch.int64).sum().item()) * (i + 1) for i, c in enumerate(c32.chunk(64))) & (2**63 - 1)
                 same = ref.setdefault(cname, h) == h
                 print("check %-10s %-8s %s" % (l.name, cname, "same as " + libs[0].name if same else "DIFFERENT RESULT"))
             else:

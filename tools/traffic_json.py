@@ -3,7 +3,7 @@ of tools/profile_round.sh:  python tools/traffic_json.py gpurun_out/r02 > profil
 import json, os, re, sys
 d = sys.argv[1]
 
-def counters(name, n, kernel_prefix):
+def counters(name, n, kernel_re):
     out = {}
     path = os.path.join(d, "pmc_%s_n%d.summary.txt" % (name, n))
     if not os.path.exists(path):
@@ -12,7 +12,7 @@ def counters(name, n, kernel_prefix):
     for line in open(path):
         if not line.startswith(" "):
             cur = line.strip()
-        elif cur and cur.startswith(kernel_prefix):
+        elif cur and re.match(kernel_re, cur):
             m = re.match(r"\s+(\S+)\s+n=\s*(\d+)\s+mean=(\S+)", line)
             if m:
                 out[m.group(1)] = float(m.group(3))
@@ -20,19 +20,21 @@ def counters(name, n, kernel_prefix):
 
 res = {"round": 2, "source": "separate rocprofv3 --pmc passes over tools/run_passes.py <n> 1 (tools/profile_round.sh), per-kernel means",
        "correction": "gfx950: read bytes = 2 x FETCH_SIZE (128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section); FETCH_SIZE / WRITE_SIZE are in KB"}
-for n, prefix in ((512, "jfa_pass_dense<512, 4, 8"), (1024, "jfa_pass_dense<1024, 4, 8")):
+# the dense-pass instantiations of jfa_pass_dense (template arguments: id format, rows, planes, threads, ...)
+for n, prefix, kre in ((512, "jfa_pass_dense<IdU<9>, 4, 8, 256", r"jfa_pass_dense<(vp::)?(\(anonymous namespace\)::)?IdU<9>, 4, 8, 256"),
+                       (1024, "jfa_pass_dense<IdU<10>, 4, 8, 512", r"jfa_pass_dense<(vp::)?(\(anonymous namespace\)::)?IdU<10>, 4, 8, 512")):
     c = {}
     for grp in ("fetch", "write", "l2", "sq1", "sq2"):
-        c.update(counters(grp, n, prefix))
+        c.update(counters(grp, n, kre))
     if "FETCH_SIZE" not in c:
         continue
     hbm = int(2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024)
     alg = 2 * 4 * n ** 3
     cycles = c.get("GRBM_GUI_ACTIVE", 0) / 8.0                       # summed over the 8 XCDs
     # VALU issue: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles, v_min_f64 for 4 (tools/ubench/probe.hip);
-    # 864 of the 3,890 VALU instructions of the tile loop are v_min_f64 (ISA of the kernel)
+    # every output voxel takes exactly 27 v_min_f64 steps, i.e. 27 n^3 / 64 wave instructions per launch
     valu = c.get("SQ_INSTS_VALU", 0)
-    issue = valu * (2.0 + 2.0 * 864.0 / 3890.0)
+    issue = valu * 2.0 + 2.0 * 27.0 * n ** 3 / 64.0
     entry = {"kernel": prefix + ", ...> (dense passes, bunny x24)", "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
              "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round(hbm / alg, 3),
              "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3) if "TCC_HIT_sum" in c else None,
