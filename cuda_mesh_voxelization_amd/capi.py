@@ -25,7 +25,7 @@ SYMBOLS = [
     "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa", "vp_jfa_start", "vp_jfa_run", "vp_jfa_init", "vp_jfa_pass",
     "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass",
     "vp_surface", "vp_extract_count", "vp_extract", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
-    "vp_prof_enable", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
+    "vp_prof_enable", "vp_prof_select", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
 ]
 
 
@@ -118,6 +118,7 @@ def lib():
         "vp_csg_host": (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int]),
         "vp_jfa_host": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_float, _vp, ctypes.c_int]),
         "vp_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
+        "vp_prof_select": (ctypes.c_int, [_vp, ctypes.c_uint64]),
         "vp_prof_reset": (ctypes.c_int, [_vp]),
         "vp_prof_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
         "vp_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -268,6 +269,11 @@ class Context:
     # -- per-kernel device timing
     def prof_enable(self, on: bool = True):
         check(lib().vp_prof_enable(self._h, 1 if on else 0))
+
+    def prof_select(self, names=None):
+        """Time only the kernels whose timing keys are named (None = all): every event pair costs stream time."""
+        mask = (1 << 64) - 1 if names is None else sum(1 << KERNELS.index(k) for k in names)
+        check(lib().vp_prof_select(self._h, mask))
 
     def prof_reset(self):
         check(lib().vp_prof_reset(self._h))

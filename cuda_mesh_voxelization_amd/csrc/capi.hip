@@ -48,7 +48,7 @@ int reserve(vp_ctx* ctx, Buffer& b, size_t bytes)
 
 ProfScope::ProfScope(vp_ctx* c, int k) : ctx(c), kernel(k)
 {
-    if (!ctx->prof_on) return;
+    if (!ctx->prof_on || !((ctx->prof_mask >> k) & 1u)) return;
     auto take = [&]() -> hipEvent_t {
         if (!ctx->prof_pool.empty()) { hipEvent_t e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
@@ -495,6 +495,13 @@ int vp_prof_enable(vp_ctx* ctx, int on)
     VP_TRY(bind_device(ctx));
     if (!on) VP_TRY(prof_fold(ctx));
     ctx->prof_on = on != 0;
+    return 0;
+}
+
+int vp_prof_select(vp_ctx* ctx, uint64_t kernel_mask)
+{
+    if (!ctx) return set_error(VP_ERR_INVALID, "vp_prof_select: null ctx");
+    ctx->prof_mask = kernel_mask;
     return 0;
 }
 

@@ -62,6 +62,7 @@ struct vp_ctx {
     uint64_t vox_total_seen = 0;
     // profiling
     bool prof_on = false;
+    uint64_t prof_mask = ~0ull;                                    // timing keys that get events (vp_prof_select)
     std::vector<vp::ProfSpan> prof_pending;
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[VP_K_COUNT] = {};

@@ -210,6 +210,10 @@ enum {
     VP_K_COUNT
 };
 int vp_prof_enable(vp_ctx* ctx, int on);
+/* Restricts the bracketing to the keys whose bit is set (bit i = key i; default: all).  An event pair costs ~3 us of stream
+ * time (0.11 ms over the 18 launches of a 512^3 step, 3 %): a caller that times ONE kernel inside a wall-clock region
+ * selects just that key. */
+int vp_prof_select(vp_ctx* ctx, uint64_t kernel_mask);
 int vp_prof_reset(vp_ctx* ctx);
 /* Synchronises the stream, folds pending events in, returns total ms and launch count. */
 int vp_prof_get(vp_ctx* ctx, int kernel, double* total_ms, uint64_t* launches);
