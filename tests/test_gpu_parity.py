@@ -118,6 +118,30 @@ def test_voxelize_work_queue_overflow_path(engine, monkeypatch):
         assert np.array_equal(got, exp), (name, n)
 
 
+def test_prof_select_times_only_the_named_kernels(engine):
+    """vp_prof_select: bench.py brackets only the dominant kernel inside its timed region; the launch counts are exact."""
+    n = 256
+    xyz, tri = M.import_mesh(M.asset("bunny.obj"))
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    g = engine.voxelize(fr, dx, dt)
+    ctx = engine.ctx
+    try:
+        ctx.prof_reset(); ctx.prof_select(["jfa_dense"]); ctx.prof_enable(True)
+        engine.jfa(fr, g); engine.jfa(fr, g)
+        ctx.prof_enable(False)
+        got = ctx.prof()
+        assert set(got) == {"jfa_dense"}
+        assert got["jfa_dense"]["launches"] == 2 * (int(math.log2(n)) - 3)      # all passes but first, sparse and last
+        ctx.prof_reset(); ctx.prof_select(None); ctx.prof_enable(True)
+        engine.jfa(fr, g)
+        ctx.prof_enable(False)
+        assert {"surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last"} <= set(ctx.prof())
+    finally:
+        ctx.prof_enable(False); ctx.prof_select(None); ctx.prof_reset()
+
+
 def test_jfa_start_run_equals_jfa(engine):
     """vp_jfa == vp_jfa_start + vp_jfa_run (the split the C++ JFA::Compute uses for its Initialization / Processing timers),
     with the caller's workspace and with the context's own."""
