@@ -173,3 +173,29 @@ def test_config5_n2048_eight_ghost_slabs(engine):
         del s
     del pipe, ref_s
     gc.collect(); torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_process_launch_on_shared_gpu(world):
+    """The driver's multi-GPU invocation (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) end to end
+    with one process per rank and the real kernels.  A one-GPU box cannot give every rank a device, so the ranks share it and
+    rendezvous over gloo (VP_BENCH_SHARE_GPU=1, bench.py); everything else -- launcher env, barriers, max-over-ranks timing,
+    the ghost-plane pipeline, the JSON line -- is the code the 8-GPU run executes."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, VP_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--grid-n", "256"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]                        # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["steps"] == 3 and out["scaling"] == "strong"
+    assert out["config"]["world_size_seen"] == world and out["config"]["n"] == 256
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert out["multi"]["pipeline"] == "ghost"
+    assert out["roofline"]["kernel"] == "jfa_dense" and out["roofline"]["launches"] > 0
