@@ -132,6 +132,7 @@ int vp_ctx_create(int device, vp_ctx** out)
     vp_ctx* c = new (std::nothrow) vp_ctx();
     if (!c) return set_error(VP_ERR_NOMEM, "vp_ctx_create: out of host memory");
     c->device = device;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->cus = v; }
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     c->stream = c->own_stream;

@@ -902,7 +902,8 @@ __device__ __forceinline__ void lds_span(const char* base, uint32_t off, int lo,
 template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP>
 __global__ void __launch_bounds__(NT, (ID::kTab == 512 || NT == 512) ? 6 : 4)
 jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-               const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
+               const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf,
+               uint32_t tilesY, uint32_t tiles, uint32_t splitTiles)
 {
     using T = uint32_t;
     constexpr int TAB = ID::kTab;
@@ -929,11 +930,18 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
     // which share halo rows and planes -- land on different L2s.  Re-mapping the dispatch index so that each XCD walks one
     // contiguous eighth of the tile sequence (-DVP_DENSE_XCD=1) was measured twice (round 1: +-0; round 2, tools/ab_pass.py:
     // -1 % .. +1 % at n = 512, 0 .. -4 % at n = 1024): the halos come from the Infinity Cache either way.  Off.
-    uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const uint32_t total = gridDim.x * gridDim.y;
+    // Units in dispatch order: whole tiles first, then the last `splitTiles` tiles as two half-row units each (x halves), so
+    // that what the chip runs while it drains is made of short units (see launch_dense).
+    uint32_t lin = blockIdx.x;
+    const uint32_t total = tiles;
+    uint32_t xpart = 0, xparts = 1;
+    if (lin >= total - splitTiles) {
+        const uint32_t u = lin - (total - splitTiles);
+        lin = total - splitTiles + (u >> 1); xpart = u & 1u; xparts = 2;
+    }
     if (VP_DENSE_XCD && total % 8u == 0u) lin = (lin % 8u) * (total / 8u) + lin / 8u;
     if (rev) lin = total - 1u - lin;
-    const uint32_t bx = lin % gridDim.x, by = lin / gridDim.x;
+    const uint32_t bx = lin % tilesY, by = lin / tilesY;
     const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
     const int nres = min(K, nzl);
     const int lbase = (int)(by % nres) + (int)(by / nres) * CH * K;
@@ -984,7 +992,9 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
     // the whole volume, 4 GiB at n = 1024, so byte offset + 1 <= 2^32 - 3 fits the low word.
 
     const int zbase0 = zbase, lbase0 = lbase, ybase0 = ybase;
-    for (uint32_t x = tid; x < (uint32_t)N; x += NT) {
+    const uint32_t xiters = ((uint32_t)N + NT - 1) / NT, xper = (xiters + xparts - 1) / xparts * NT;
+    const uint32_t xbeg = xpart * xper, xend = min((uint32_t)N, xbeg + xper);
+    for (uint32_t x = xbeg + tid; x < xend; x += NT) {
         // The uniform bases are re-read through an empty asm in every x iteration: otherwise every address of the ~10
         // planes of the tile is hoisted out of the x loop, does not fit the SGPR file and is spilled to VGPR lanes
         // (v_readlane / v_writelane were 6 % of the VALU instructions of the loop).
@@ -1401,6 +1411,19 @@ static bool dense_applies(const Frame& f, uint32_t k, const void* d_in, const vo
     return true;
 }
 
+// Tail of a dense launch.  A launch of T tiles on S = CUs x workgroups-per-CU slots runs ~T/S rounds; at n = 512 that is 5.3:
+// while the chip drains, slots stand empty for about half a tile time (77 us of a 410-us pass).  The last ~4/3 S tiles are
+// therefore dispatched as two half-row units each (x halves, one table prologue more per split tile): -1.9 % on the dense passes
+// at n = 512 (profiles/r02/ab17.txt, ab18.txt).  Launches of 16 rounds and more (n = 1024: 43) are left whole (measured +-0).
+static uint32_t tail_split(const vp_ctx* ctx, uint32_t tiles, uint32_t wgPerCu)
+{
+    static const int forced = env_int("VP_DENSE_SPLIT", -1);       // dev switch: number of tiles to split
+    if (forced >= 0) return std::min(tiles, (uint32_t)forced);
+    const uint32_t slots = (uint32_t)ctx->cus * wgPerCu;
+    if (tiles >= 16u * slots) return 0;
+    return std::min(tiles / 2u, slots * 4u / 3u);
+}
+
 template <class ID>
 static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
 {
@@ -1414,9 +1437,12 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     // Tile 4 rows x 8 planes when the plane chains divide by 8, else 4 x 4.  2-KB tables (n <= 512): 256 threads, 26 KB of LDS,
     // six workgroups per CU.  4-KB tables: the 4 x 8 tile takes 52 KB, shared by the 8 waves of a 512-thread workgroup (three per CU).
 #define VP_LAUNCH_DENSE(CH, NT, F, S)                                                                                              \
-    hipLaunchKernelGGL((jfa_pass_dense<ID, 4, CH, NT, F, true, S>),                                                                \
-                       dim3(nresY * ((ylen + 3) / 4), nres * ((zlen + CH - 1) / CH)), dim3(NT), 0, ctx->stream, f, k,              \
-                       (const uint32_t*)d_in, (uint32_t*)d_out, none_row, d_words, fill, d_sdf)
+    do {                                                                                                                           \
+        const uint32_t ty_ = nresY * ((ylen + 3) / 4), t_ = ty_ * nres * ((zlen + CH - 1) / CH);                                   \
+        const uint32_t sp_ = tail_split(ctx, t_, ID::kTab == 512 ? 6u : NT == 512 ? 3u : 4u);                                      \
+        hipLaunchKernelGGL((jfa_pass_dense<ID, 4, CH, NT, F, true, S>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,            \
+                           (const uint32_t*)d_in, (uint32_t*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                 \
+    } while (0)
 #define VP_DENSE_F(CH, NT) do { if (fin) VP_LAUNCH_DENSE(CH, NT, (VP_JFA_DENSE_FINAL != 0), false);                                \
                                 else if (wideK) VP_LAUNCH_DENSE(CH, NT, false, (VP_JFA_DENSE_WIDEK != 0));                          \
                                 else VP_LAUNCH_DENSE(CH, NT, false, false); } while (0)

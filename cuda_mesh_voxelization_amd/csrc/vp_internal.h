@@ -43,6 +43,7 @@ struct Buffer {
 
 struct vp_ctx {
     int device = 0;
+    int cus = 256;                             // compute units of the device (workgroup slots = cus x workgroups per CU)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only workspaces
