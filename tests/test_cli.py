@@ -200,7 +200,8 @@ def test_cli_runs_the_benchmarked_kernel_sequence(cli, engine, tmp_path):
         assert {k: v["launches"] for k, v in pr.items()} == want
         if i:
             best = min(best, sum(v["ms"] for v in pr.values()))
-    assert abs(cli_ms - best) <= 0.05 * best, (cli_ms, best)
+    # the product path may not be slower than the timed one by more than 5 %; faster only within what clock states explain
+    assert 0.85 * best <= cli_ms <= 1.05 * best, (cli_ms, best)
 
 
 @pytest.mark.gpu
