@@ -53,6 +53,15 @@ __global__ void __launch_bounds__(256) rate(float* out, int iters, float seed)
         if (OP == 8) { REP8(asm volatile("v_add_f32 v101, %4, %5\n v_add_u32 v100, %6, %7\n v_min_f64 %0, %0, v[100:101]\n v_add_f32 v103, %4, %5\n v_add_u32 v102, %6, %7\n v_min_f64 %1, %1, v[102:103]\n"
                                          "v_add_f32 v101, %4, %5\n v_add_u32 v100, %6, %7\n v_min_f64 %2, %2, v[100:101]\n v_add_f32 v103, %4, %5\n v_add_u32 v102, %6, %7\n v_min_f64 %3, %3, v[102:103]"
                                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a0), "v"(b), "v"(addr4), "v"(addr8) : "v100", "v101", "v102", "v103");) }
+        // packed f32: two adds / multiplies per lane and instruction
+        if (OP == 10) { REP8(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8"
+                                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(db));) }
+        if (OP == 11) { REP8(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8"
+                                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(db));) }
+        // mixed stream as in the tile loop: one packed add per two plain adds and one v_min_f64
+        if (OP == 12) { REP8(asm volatile("v_pk_add_f32 %4, %4, %8\n v_add_f32 v101, %6, %7\n v_min_f64 %0, %0, v[100:101]\n v_add_f32 v103, %6, %7\n v_min_f64 %1, %1, v[102:103]\n"
+                                          "v_pk_add_f32 %5, %5, %8\n v_add_f32 v101, %6, %7\n v_min_f64 %2, %2, v[100:101]\n v_add_f32 v103, %6, %7\n v_min_f64 %3, %3, v[102:103]"
+                                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5) : "v"(a0), "v"(b), "v"(db) : "v100", "v101", "v102", "v103");) }
         // f32 variant of the final pass: add + v_min_f32
         if (OP == 9) { REP8(asm volatile("v_add_f32 v100, %4, %5\n v_min_f32 %0, %0, v100\n v_add_f32 v101, %4, %5\n v_min_f32 %1, %1, v101\n v_add_f32 v100, %4, %5\n v_min_f32 %2, %2, v100\n v_add_f32 v101, %4, %5\n v_min_f32 %3, %3, v101"
                                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(seed) : "v100", "v101");) }
@@ -119,6 +128,9 @@ int main()
         run<8>("step: add_f32 + add_u32 + min_f64 (unit = step)", out, w, 4);
         run<2>("step r1: add + cmpx + 2 mov + s_mov (unit = step)", out, w, 4);
         run<9>("step f32: add + min_f32 (unit = step)", out, w, 4);
+        run<10>("v_pk_add_f32 (unit = 1 instr)", out, w, 8);
+        run<11>("v_pk_mul_f32 (unit = 1 instr)", out, w, 8);
+        run<12>("pk_add + 2 x (add_f32 + min_f64) (unit = 5 instr)", out, w, 2);
         run<4>("ds_read_b32 x4 (unit = 1 instr)", out, w, 4);
         run<5>("ds_read_b64 x4 (unit = 1 instr)", out, w, 4);
         run<6>("ds_read_b128 x4 (unit = 1 instr)", out, w, 4);
