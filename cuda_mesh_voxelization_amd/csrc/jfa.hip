@@ -1439,7 +1439,8 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 #define VP_LAUNCH_DENSE(CH, NT, F, S)                                                                                              \
     do {                                                                                                                           \
         const uint32_t ty_ = nresY * ((ylen + 3) / 4), t_ = ty_ * nres * ((zlen + CH - 1) / CH);                                   \
-        const uint32_t sp_ = tail_split(ctx, t_, ID::kTab == 512 ? 6u : NT == 512 ? 3u : 4u);                                      \
+        /* a row of <= NT voxels has no halves */                                                                                  \
+        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, ID::kTab == 512 ? 6u : NT == 512 ? 3u : 4u) : 0u;                      \
         hipLaunchKernelGGL((jfa_pass_dense<ID, 4, CH, NT, F, true, S>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,            \
                            (const uint32_t*)d_in, (uint32_t*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                 \
     } while (0)
