@@ -532,3 +532,47 @@ def test_extract_records_match_numpy(engine):
                 engine.sync()
                 r2 = rec.cpu().numpy()
                 assert np.array_equal(r2[:10].view(np.uint64), exp[:10]) and (r2[10:] == -1).all()
+
+
+@pytest.mark.parametrize("n,kind", [(512, "noise"), (512, "sparse"), (512, "mesh"), (1024, "sparse"), (288, "noise")])
+def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
+    """Pass by pass, on the SAME input state: the packed seed ids the tile kernels write (sparse, dense with the
+    v_min_f64 pair update, every k; and the first pass in its from-the-border-mask form) equal those of the one-thread-per-voxel kernel, which walks the 27
+    candidates in the reference's order with its strict '<' (sequential.cpp:84-112).  Random grids are full of equidistant
+    seeds, so this is the test of the first-minimum rule itself -- the sdf alone would forgive a wrong winner of a tie."""
+    import torch
+    rng = np.random.default_rng(n + len(kind))
+    if kind == "mesh":
+        xyz, tri = M.import_mesh(M.asset("bimba.obj"))
+        origin, vs = M.frame([xyz], n)
+        fr = Frame.make(n, vs, origin)
+        dx, dt = engine.mesh_to_device(xyz, tri)
+        g = engine.voxelize(fr, dx, dt)
+    else:
+        fr = Frame.make(n, 0.03125, (0.25, -1.0, 3.5))
+        nw = fr.words
+        if kind == "noise":
+            words = rng.integers(0, 2**32, nw, dtype=np.uint32)
+        else:
+            words = (rng.random(nw) < 0.004).astype(np.uint32) << rng.integers(0, 32, nw).astype(np.uint32)
+        g = engine.to_device(words, np.uint32)
+    assert engine.ctx.jfa_id_bytes(fr) == 4
+    cur = torch.empty(fr.voxels, dtype=torch.int32, device=engine.device)
+    engine.ctx.jfa_init(fr, g.data_ptr(), None, None, cur.data_ptr())
+    a = torch.empty_like(cur)
+    b = torch.empty_like(cur)
+    k = n // 2
+    while k >= 1:
+        engine.ctx.jfa_pass(fr, k, cur.data_ptr(), None, None, a.data_ptr(), ALGO_TILED)
+        engine.ctx.jfa_pass(fr, k, cur.data_ptr(), None, None, b.data_ptr(), ALGO_NAIVE)
+        engine.sync()
+        assert torch.equal(a, b), (n, kind, k, int((a != b).sum().item()))
+        if k == n // 2 and engine.ctx.jfa_can_start_from_mask(fr, ALGO_TILED):
+            # what vp_jfa really runs first: the pass straight from the border bitmask, no id volume read
+            border = torch.empty(fr.words, dtype=torch.int32, device=engine.device)
+            engine.ctx.surface(fr, g.data_ptr(), None, None, border.data_ptr())
+            engine.ctx.jfa_first_pass(fr, border.data_ptr(), a.data_ptr())
+            engine.sync()
+            assert torch.equal(a, b), (n, kind, "first pass from the mask", int((a != b).sum().item()))
+        cur, a = a, cur
+        k //= 2
