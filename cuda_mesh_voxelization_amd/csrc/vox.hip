@@ -140,7 +140,10 @@ __device__ __forceinline__ void for_each_tile(bool valid, uint32_t t, int ty0, i
 }
 
 // ---------------------------------------------------------------------------------------------
-constexpr int kSmallCells = 16;   // triangles whose y/z voxel range holds at most this many columns skip the binning
+#ifndef VP_VOX_SMALL_CELLS
+#define VP_VOX_SMALL_CELLS 64       // 16 -> 64: bunny (56 k faces) 0.092 -> 0.053 ms at n = 512, 0.188 -> 0.172 at 1024; finer meshes unchanged (profiles/r02/vox_small.txt)
+#endif
+constexpr int kSmallCells = VP_VOX_SMALL_CELLS;   // triangles whose y/z voxel range holds at most this many columns skip the binning
 
 __global__ void __launch_bounds__(256)
 vox_setup(Frame f, const float* __restrict__ xyz, size_t nverts, const uint32_t* __restrict__ tri, size_t ntris,
