@@ -900,7 +900,7 @@ __device__ __forceinline__ void lds_span(const char* base, uint32_t off, int lo,
 // occupancy the register allocation aims at: six waves per SIMD where the LDS footprint allows six workgroups (2-KB tables)
 // or three 512-thread ones (4-KB tables); the 256-thread variant with 4-KB tables is LDS-limited to four
 template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP>
-__global__ void __launch_bounds__(NT, (ID::kTab == 512 || NT == 512) ? 6 : 4)
+__global__ void __launch_bounds__(NT, FINAL ? (ID::kTab == 512 ? 5 : 4) : (ID::kTab == 512 || NT == 512) ? 6 : 4)   // FINAL: + the bitmask rows in LDS
 jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf,
                uint32_t tilesY, uint32_t tiles, uint32_t splitTiles)
@@ -1389,7 +1389,8 @@ static int env_int(const char* name, int dflt)
 }
 
 #ifndef VP_JFA_DENSE_FINAL
-#define VP_JFA_DENSE_FINAL 0      // 1: route the fused last pass here too (measured 0 - 5 % behind jfa_pass_zstream<FINAL>, tools/ab_pass.py)
+#define VP_JFA_DENSE_FINAL 1      // the fused last pass runs here too: 0.397 -> 0.368 ms at n = 512, 3.62 -> 3.42 ms at n = 1024 against
+                                  // jfa_pass_zstream<FINAL> (profiles/r02/ab19.txt; it was 0 - 5 % behind before the IdU ids, the pipelined lookups and tail_split)
 #endif
 #ifndef VP_JFA_DENSE_WIDEK
 #define VP_JFA_DENSE_WIDEK 0      // 1: route the wide passes (k >= n/4) here too (SKIP form; measured 5 - 9 % behind: they wait on
@@ -1440,7 +1441,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     do {                                                                                                                           \
         const uint32_t ty_ = nresY * ((ylen + 3) / 4), t_ = ty_ * nres * ((zlen + CH - 1) / CH);                                   \
         /* a row of <= NT voxels has no halves */                                                                                  \
-        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, ID::kTab == 512 ? 6u : NT == 512 ? 3u : 4u) : 0u;                      \
+        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, ID::kTab == 512 ? ((F) ? 5u : 6u) : NT == 512 ? ((F) ? 2u : 3u) : 4u) : 0u;                      \
         hipLaunchKernelGGL((jfa_pass_dense<ID, 4, CH, NT, F, true, S>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,            \
                            (const uint32_t*)d_in, (uint32_t*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                 \
     } while (0)
