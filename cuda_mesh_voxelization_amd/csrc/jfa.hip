@@ -845,6 +845,13 @@ __device__ __forceinline__ double min_f64(double a, double b)
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));      // not fmin(): that canonicalises both operands first
     return r;
 }
+__device__ __forceinline__ float min3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ float min_f32(float a, float b)
 {
     float r;
@@ -899,8 +906,15 @@ __device__ __forceinline__ void lds_span(const char* base, uint32_t off, int lo,
 
 // occupancy the register allocation aims at: six waves per SIMD where the LDS footprint allows six workgroups (2-KB tables)
 // or three 512-thread ones (4-KB tables); the 256-thread variant with 4-KB tables is LDS-limited to four
+// FINAL form: the bitmask words of the output rows (the sign of the sdf) come from LDS (staged with the tables: 2 / 4 KB more,
+// one workgroup per CU less) or straight from global memory.  Measured in the whole JFA (profiles/r02/ab22.txt): global is
+// +3.4 % at n = 512 (5 -> 6 workgroups per CU does not pay for the loads) and -4.7 % at n = 1024 (2 -> 3 workgroups of 512).
+#ifndef VP_FINAL_GLOBAL_MASK
+#define VP_FINAL_GLOBAL_MASK 2      // 0: LDS, 1: global, 2: global with the 4-KB tables only
+#endif
+template <class ID> constexpr bool final_mask_global() { return VP_FINAL_GLOBAL_MASK == 1 || (VP_FINAL_GLOBAL_MASK == 2 && ID::kTab > 512); }
 template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP>
-__global__ void __launch_bounds__(NT, FINAL ? (ID::kTab == 512 ? 5 : 4) : (ID::kTab == 512 || NT == 512) ? 6 : 4)   // FINAL: + the bitmask rows in LDS
+__global__ void __launch_bounds__(NT, (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (ID::kTab == 512 || NT == 512) ? 6 : 4)
 jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf,
                uint32_t tilesY, uint32_t tiles, uint32_t splitTiles)
@@ -915,7 +929,8 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
     __shared__ float PX[PXT];
     __shared__ __attribute__((aligned(16))) float TY[RY / EY][TAB][EY];
     __shared__ __attribute__((aligned(16))) float TZ[CH / EZ][TAB][EZ];
-    __shared__ uint32_t WM[FINAL ? RY * CH * (TAB / 32) : 1];
+    constexpr bool GM = final_mask_global<ID>();
+    __shared__ uint32_t WM[(FINAL && !GM) ? RY * CH * (TAB / 32) : 1];
 
     const int N = (int)f.n;
     const int K = (int)k;
@@ -968,7 +983,7 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
             for (int j = 0; j < CH; ++j) TZ[j / EZ][i][j % EZ] = 0.0f;
         }
     }
-    if (FINAL) {
+    if (FINAL && !GM) {
         for (uint32_t i = tid; i < (uint32_t)(RY * CH) * f.w; i += NT) {
             const int o = (int)(i / f.w), a = o / CH, j = o % CH;
             const int oy = ybase + a * K, oz = zbase + j * K;
@@ -1056,6 +1071,10 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
             lds_span<CH, EZ, TAB>(tz, zo, olo, ohi, d.dz2);
 #endif
         };
+#ifndef VP_FINAL_MIN3
+#define VP_FINAL_MIN3 1
+#endif
+        float hold[3][3];                                                   // FINAL: distances of column x - k of the current source row
         auto steps = [&](int P, int rr, int c, const Dec& d, uint32_t prank) {
             const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
             const float dxv = d.sx - px;
@@ -1070,7 +1089,11 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
                 for (int o = olo; o <= ohi; ++o) {
                     const float dd = pre + d.dz2[o];
                     if constexpr (FINAL) {
-                        best[a][o] = min_f32(best[a][o], dd);
+                        // distances only, so the order of the candidates no longer matters: the left column's distance waits for
+                        // the centre column's and both go through one v_min3_f32 (27 -> 18 minimum instructions per voxel)
+                        if (VP_FINAL_MIN3 && c == 0) hold[a - alo][o - olo] = dd;
+                        else if (VP_FINAL_MIN3 && c == 1) best[a][o] = min3_f32(best[a][o], hold[a - alo][o - olo], dd);
+                        else best[a][o] = min_f32(best[a][o], dd);
                     } else {
                         u32x2 cd = cand;
                         if (ownRow && o == P) cd.x = 0u;                   // the voxel's own state wins every tie (sequential.cpp:84,106)
@@ -1167,6 +1190,17 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
                     else best[a][P + 1] = __builtin_bit_cast(double, (u32x2){0xFFFFFFFFu, 0x7F800000u});   // (+inf, last rank)
                 }
             }
+            uint32_t mw[RY] = {};
+            if constexpr (FINAL && GM) {         // bitmask words of the rows stored after this plane: requested before its evaluation
+                if (P >= 1 && P - 1 < nout) {
+#pragma unroll
+                    for (int a = 0; a < RY; ++a) {
+                        if (a >= yout) continue;
+                        const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (P - 1) * K) * N + (ybase + a * K);
+                        mw[a] = words[rowIdx * f.w + (x >> 5)];
+                    }
+                }
+            }
             scatter(P, cur);
             if constexpr (FINAL) {
                 if (P >= 1 && P - 1 < nout) {
@@ -1174,7 +1208,7 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
                     for (int a = 0; a < RY; ++a) {
                         if (a >= yout) continue;
                         const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (P - 1) * K) * N + (ybase + a * K);
-                        const bool set = (WM[(a * CH + (P - 1)) * (TAB / 32) + (x >> 5)] >> (x & 31)) & 1u;
+                        const bool set = ((GM ? mw[a] : WM[(a * CH + (P - 1)) * (TAB / 32) + (x >> 5)]) >> (x & 31)) & 1u;
                         row_store(set ? best[a][P - 1] : copysignf(best[a][P - 1], fill), row_resource(sdf + rowIdx * N, rowBytes), xo);
                     }
                 }
@@ -1441,7 +1475,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     do {                                                                                                                           \
         const uint32_t ty_ = nresY * ((ylen + 3) / 4), t_ = ty_ * nres * ((zlen + CH - 1) / CH);                                   \
         /* a row of <= NT voxels has no halves */                                                                                  \
-        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, ID::kTab == 512 ? ((F) ? 5u : 6u) : NT == 512 ? ((F) ? 2u : 3u) : 4u) : 0u;                      \
+        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, ID::kTab == 512 ? ((F) && !final_mask_global<ID>() ? 5u : 6u) : NT == 512 ? ((F) && !final_mask_global<ID>() ? 2u : 3u) : 4u) : 0u;                      \
         hipLaunchKernelGGL((jfa_pass_dense<ID, 4, CH, NT, F, true, S>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,            \
                            (const uint32_t*)d_in, (uint32_t*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                 \
     } while (0)
