@@ -576,3 +576,31 @@ def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
             assert torch.equal(a, b), (n, kind, "first pass from the mask", int((a != b).sum().item()))
         cur, a = a, cur
         k //= 2
+
+
+def test_round1_tile_kernel_path_still_matches(engine):
+    """VP_JFA_DENSE=0 routes every pass of a 32-bit-id JFA through jfa_pass_zstream (the kernel that still serves 8-byte ids, the
+    sparse pass and slabs whose halo buffers are not contiguous): same sdf, bit for bit, as the default path.  The switch is read
+    once per process, hence the child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from cuda_mesh_voxelization_amd import mesh as M\n"
+        "from cuda_mesh_voxelization_amd.capi import Frame\n"
+        "from cuda_mesh_voxelization_amd.pipeline import Engine\n"
+        "from oracle import oracle as O\n"
+        "eng = Engine(0)\n"
+        "xyz, tri = M.import_mesh(M.asset('bunny.obj'))\n"
+        "for n in (256, 288, 512):\n"
+        "    origin, vs = M.frame([xyz], n); fr = Frame.make(n, vs, origin)\n"
+        "    dx, dt = eng.mesh_to_device(xyz, tri)\n"
+        "    g = eng.voxelize(fr, dx, dt)\n"
+        "    print(n, O.fnv(eng.jfa(fr, g).cpu().numpy()))\n" % root)
+    outs = []
+    for v in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VP_JFA_DENSE=v), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l and l[0].isdigit()])
+    assert len(outs[0]) == 3 and outs[0] == outs[1], outs
