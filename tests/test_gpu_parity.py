@@ -604,3 +604,50 @@ def test_round1_tile_kernel_path_still_matches(engine):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l and l[0].isdigit()])
     assert len(outs[0]) == 3 and outs[0] == outs[1], outs
+
+
+@pytest.mark.parametrize("n,seed", [(96, 1), (160, 2), (256, 3), (512, 4)])
+def test_voxelize_triangle_soup_matches_oracle(engine, n, seed):
+    """Triangle soups (not closed surfaces: every triangle toggles on its own): random sizes from sub-voxel to grid-spanning,
+    slivers, triangles in axis planes (A == 0 or vertices exactly on voxel centres / borders), triangles that leave the frame on
+    every side.  Both GPU algorithms against the oracle's scanline, bit for bit -- the edge-function signs, the startX rounding
+    and the clamping are all in play here, on the small-triangle path, the tile path and (seed 4, many big triangles) the
+    work-queue paths."""
+    rng = np.random.default_rng(seed)
+    vs = 0.125
+    origin = np.array([-3.0, 1.5, 0.25], np.float32)
+    side = n * vs
+    tris = []
+
+    def add(p, q, r):
+        tris.append(np.stack([p, q, r]))
+
+    for _ in range(400):                                          # random size classes
+        c = origin + rng.random(3) * side
+        ext = side * 10.0 ** rng.uniform(-3.2, 0.0)
+        add(*(c + (rng.random((3, 3)) - 0.5) * ext))
+    for _ in range(100):                                          # slivers
+        c = origin + rng.random(3) * side
+        d = (rng.random(3) - 0.5) * side * 0.5
+        add(c, c + d, c + d * 0.5 + (rng.random(3) - 0.5) * vs * 0.01)
+    for _ in range(100):                                          # vertices snapped to voxel corners / centres: exact ties in the edge functions
+        v = origin + (rng.integers(0, n, (3, 3)) + rng.choice([0.0, 0.5], (3, 3))) * vs
+        add(*v)
+    for ax in range(3):                                           # triangles inside planes of constant x / y / z
+        for _ in range(30):
+            v = origin + rng.random((3, 3)) * side
+            v[:, ax] = origin[ax] + (rng.integers(0, n) + rng.choice([0.0, 0.5])) * vs
+            add(*v)
+    for _ in range(60):                                           # partly or wholly outside the frame
+        c = origin + (rng.random(3) * 1.6 - 0.3) * side
+        add(*(c + (rng.random((3, 3)) - 0.5) * side * 0.8))
+    xyz = np.concatenate(tris).astype(np.float32)
+    tri = np.arange(xyz.shape[0], dtype=np.uint32).reshape(-1, 3)
+    fr = Frame.make(n, vs, tuple(float(v) for v in origin))
+    exp = O.voxelize(xyz, tri, n, vs, origin)
+    assert exp.any()
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    for algo in (ALGO_TILED, ALGO_NAIVE):
+        got = engine.words_to_numpy(engine.voxelize(fr, dx, dt, algo=algo))
+        bad = int(np.count_nonzero(got != exp))
+        assert bad == 0, (n, seed, algo, bad)
