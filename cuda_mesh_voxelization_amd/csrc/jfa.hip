@@ -1256,6 +1256,110 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
     }
 }
 
+// ------------------------------------------------------------------------------------------ seed scatter (k = n/4)
+// The pass with k = n/4 sees a state in which few voxels hold a seed yet (5 % on the headline mesh; tools/seed_occupancy.py),
+// but three quarters of the 64-voxel row segments hold at least one, so wave-uniform skipping barely helps the gather form:
+// it evaluates 27 candidate slots per voxel and 87 % of a dense pass's instructions.  This kernel turns the pass around.
+// With k = n/4 the chain {r, r+k, r+2k, r+3k} along an axis is closed under +-k, so a tile of 4 planes x 4 rows x 4 x-segments
+// (XR residues wide) reads exactly the voxels it writes.  The tile's ids go to LDS, the few that are seeds are compacted into a
+// list, and every list entry PROPOSES itself to the up to 27 voxels it is a candidate of with one 64-bit LDS minimum
+//     key = distance bits << 32 | rank << 27 | source slot,   rank 0 = the voxel's own state, 1 + scan index otherwise,
+// which is the reference's "first minimum in scan order, own state first" (sequential.cpp:84-112) for the same reason as in
+// jfa_pass_dense.  Work is proportional to the seeds, not to the voxels; traffic is one read and one write of the id volume.
+template <class ID, int XR, int NT>
+__global__ void __launch_bounds__(NT)
+jfa_pass_seeds(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* __restrict__ out)
+{
+    constexpr uint32_t SLOTS = 64u * XR;                           // slot = ((plane * 4 + row) * 4 + segment) * XR + residue
+    constexpr unsigned long long kEmpty = 0x7F800000FFFFFFFFull;   // (+inf, no candidate)
+    __shared__ unsigned long long keys[SLOTS];
+    __shared__ uint32_t ids[SLOTS];
+    __shared__ uint16_t list[SLOTS];
+    __shared__ uint32_t cnt;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, N = f.n;
+    const uint32_t rx0 = blockIdx.x * XR, ry = blockIdx.y, rz = blockIdx.z;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    constexpr int PER = (int)(SLOTS / NT);                         // slots per thread, all requested before any is used
+    uint32_t mine[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t s = tid + (uint32_t)i * NT;
+        const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
+        mine[i] = ID::none();
+        if (rx0 + xr < k) mine[i] = in[((size_t)(rz + jp * k) * N + (ry + jr * k)) * N + (rx0 + xr + xs * k)];
+    }
+    uint32_t nmine = 0;                                            // seeds of this wave, lane 0 reserves list space once
+    unsigned long long ms[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t s = tid + (uint32_t)i * NT;
+        keys[s] = kEmpty;
+        ids[s] = mine[i];
+        ms[i] = __ballot(!ID::is_none(mine[i]));
+        nmine += (uint32_t)__popcll(ms[i]);
+    }
+    uint32_t base = 0;
+    if (lane == 0 && nmine) base = atomicAdd(&cnt, nmine);
+    base = (uint32_t)__shfl((int)base, 0);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (!ID::is_none(mine[i])) list[base + (uint32_t)__popcll(ms[i] & ((1ull << lane) - 1ull))] = (uint16_t)(tid + (uint32_t)i * NT);
+        base += (uint32_t)__popcll(ms[i]);
+    }
+    __syncthreads();
+    const uint32_t nseeds = cnt;
+    for (uint32_t e = tid; e < nseeds; e += NT) {
+        const uint32_t s = list[e];
+        const uint32_t id = ids[s];
+        const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
+        const float sx = axis_pos(f.ox, ID::xoff(id) >> 2, f.vs);
+        const float sy = axis_pos(f.oy, scr(ID::yoff(id) >> 2), f.vs);
+        const float sz = axis_pos(f.oz, scr(ID::zoff(id) >> 2), f.vs);
+        // squared differences to the up to three chain positions per axis this voxel is a neighbour of: the voxel itself (t = 0)
+        // and the ones k below / above it -- for the target v = u - t k the source u is the neighbour at +t
+        float dx2[3], dy2[3], dz2[3];
+#pragma unroll
+        for (int t = -1; t <= 1; ++t) {
+            const float dxv = sx - axis_pos(f.ox, rx0 + xr + (xs - t) * k, f.vs);
+            const float dyv = sy - axis_pos(f.oy, ry + (jr - t) * k, f.vs);
+            const float dzv = sz - axis_pos(f.oz, rz + (jp - t) * k, f.vs);
+            dx2[t + 1] = dxv * dxv; dy2[t + 1] = dyv * dyv; dz2[t + 1] = dzv * dzv;
+        }
+#pragma unroll
+        for (int c = -1; c <= 1; ++c) {
+            if (jp - c > 3u) continue;                             // unsigned: also rejects -1
+#pragma unroll
+            for (int b = -1; b <= 1; ++b) {
+                if (jr - b > 3u) continue;
+#pragma unroll
+                for (int a = -1; a <= 1; ++a) {
+                    if (xs - a > 3u) continue;
+                    const float d = (dx2[a + 1] + dy2[b + 1]) + dz2[c + 1];
+                    const bool own = a == 0 && b == 0 && c == 0;
+                    if (!own && !(d < INFINITY)) continue;         // sequential.cpp:106 never takes such a candidate
+                    const uint32_t rank = own ? 0u : (uint32_t)((c + 1) * 9 + (b + 1) * 3 + (a + 1) + 1);
+                    const uint32_t t = (((jp - c) * 4u + (jr - b)) * 4u + (xs - a)) * XR + xr;
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (rank << 27) | s;
+                    __hip_atomic_fetch_min(&keys[t], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long won[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) won[i] = keys[tid + (uint32_t)i * NT];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t s = tid + (uint32_t)i * NT;
+        const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
+        if (rx0 + xr >= k) continue;
+        const uint32_t id = won[i] == kEmpty ? ID::none() : ids[(uint32_t)won[i] & 0x07FFFFFFu];
+        out[((size_t)(rz + jp * k) * N + (ry + jr * k)) * N + (rx0 + xr + xs * k)] = id;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ final
 // One lane = 4 voxels.  sequential.cpp:55-60,106-109 + apps/cli/main.cpp:200 give the sign rule.
 __device__ __forceinline__ void load4(const uint32_t* base, size_t quad, uint32_t (&o)[4])
@@ -1459,6 +1563,16 @@ static uint32_t tail_split(const vp_ctx* ctx, uint32_t tiles, uint32_t wgPerCu)
     return std::min(tiles / 2u, slots * 4u / 3u);
 }
 
+// The seed-scatter kernel serves the pass with k = n/4 of a whole grid with 32-bit ids (the chains must be closed: 4 k = n).
+#ifndef VP_JFA_SEEDS_DEFAULT
+#define VP_JFA_SEEDS_DEFAULT 1
+#endif
+static bool seeds_applies(const Frame& f, uint32_t k, bool fin)
+{
+    static const int enabled = env_int("VP_JFA_SEEDS", VP_JFA_SEEDS_DEFAULT);
+    return enabled && !fin && !wide(f) && k * 4u == f.n && f.z0 == 0 && f.z1 == f.n && k <= 65535u;
+}
+
 template <class ID>
 static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
 {
@@ -1510,6 +1624,17 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
         else
             hipLaunchKernelGGL(jfa_pass_direct<Id10>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
                                (const uint32_t*)d_minus, (const uint32_t*)d_plus, (uint32_t*)d_out);
+    } else if (f.n >= 256 && seeds_applies(f, k, d_sdf != nullptr)) {
+        // tile = 4 x 4 x 4 chain positions x 32 residues = 2,048 voxels (28 KB of LDS), 512 threads = 4 voxels each.  Measured
+        // (profiles/r02/ab28.txt, ab29.txt): 16 x 256 -14 %, 32 x 512 -16 % (n = 512) / -28 % (n = 1024) against
+        // jfa_pass_zstream<SKIP>; 2 or 8 voxels per thread, 64-byte and 256-byte segments are all slower than that
+#ifndef VP_SEEDS_XR
+#define VP_SEEDS_XR 32
+#define VP_SEEDS_NT 512
+#endif
+        const dim3 grid((k + VP_SEEDS_XR - 1) / VP_SEEDS_XR, k, k);  // 4 x 4 x 4 chain positions x XR residues per tile
+        if (f.n <= 512) hipLaunchKernelGGL((jfa_pass_seeds<Id9, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
+        else            hipLaunchKernelGGL((jfa_pass_seeds<Id10, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
     } else if (f.n >= 256 && dense_applies(f, k, d_in, d_minus, d_plus, d_sdf != nullptr)) {
         if (f.n <= 512) VP_TRY(launch_dense<Id9>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
         else            VP_TRY(launch_dense<Id10>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
