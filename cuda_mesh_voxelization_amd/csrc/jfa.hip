@@ -1268,12 +1268,13 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
 // jfa_pass_dense.  Work is proportional to the seeds, not to the voxels; traffic is one read and one write of the id volume.
 template <class ID, int XR, int NT>
 __global__ void __launch_bounds__(NT)
-jfa_pass_seeds(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* __restrict__ out)
+jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typename ID::T* __restrict__ out)
 {
+    using T = typename ID::T;
     constexpr uint32_t SLOTS = 64u * XR;                           // slot = ((plane * 4 + row) * 4 + segment) * XR + residue
     constexpr unsigned long long kEmpty = 0x7F800000FFFFFFFFull;   // (+inf, no candidate)
     __shared__ unsigned long long keys[SLOTS];
-    __shared__ uint32_t ids[SLOTS];
+    __shared__ T ids[SLOTS];
     __shared__ uint16_t list[SLOTS];
     __shared__ uint32_t cnt;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, N = f.n;
@@ -1281,7 +1282,7 @@ jfa_pass_seeds(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
     if (tid == 0) cnt = 0;
     __syncthreads();
     constexpr int PER = (int)(SLOTS / NT);                         // slots per thread, all requested before any is used
-    uint32_t mine[PER];
+    T mine[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const uint32_t s = tid + (uint32_t)i * NT;
@@ -1311,7 +1312,7 @@ jfa_pass_seeds(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
     const uint32_t nseeds = cnt;
     for (uint32_t e = tid; e < nseeds; e += NT) {
         const uint32_t s = list[e];
-        const uint32_t id = ids[s];
+        const T id = ids[s];
         const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
         const float sx = axis_pos(f.ox, ID::xoff(id) >> 2, f.vs);
         const float sy = axis_pos(f.oy, scr(ID::yoff(id) >> 2), f.vs);
@@ -1355,7 +1356,7 @@ jfa_pass_seeds(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
         const uint32_t s = tid + (uint32_t)i * NT;
         const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
         if (rx0 + xr >= k) continue;
-        const uint32_t id = won[i] == kEmpty ? ID::none() : ids[(uint32_t)won[i] & 0x07FFFFFFu];
+        const T id = won[i] == kEmpty ? ID::none() : ids[(uint32_t)won[i] & 0x07FFFFFFu];
         out[((size_t)(rz + jp * k) * N + (ry + jr * k)) * N + (rx0 + xr + xs * k)] = id;
     }
 }
@@ -1563,14 +1564,14 @@ static uint32_t tail_split(const vp_ctx* ctx, uint32_t tiles, uint32_t wgPerCu)
     return std::min(tiles / 2u, slots * 4u / 3u);
 }
 
-// The seed-scatter kernel serves the pass with k = n/4 of a whole grid with 32-bit ids (the chains must be closed: 4 k = n).
+// The seed-scatter kernel serves the pass with k = n/4 of a whole grid (the chains must be closed: 4 k = n), either id width.
 #ifndef VP_JFA_SEEDS_DEFAULT
 #define VP_JFA_SEEDS_DEFAULT 1
 #endif
 static bool seeds_applies(const Frame& f, uint32_t k, bool fin)
 {
     static const int enabled = env_int("VP_JFA_SEEDS", VP_JFA_SEEDS_DEFAULT);
-    return enabled && !fin && !wide(f) && k * 4u == f.n && f.z0 == 0 && f.z1 == f.n && k <= 65535u;
+    return enabled && !fin && k * 4u == f.n && f.z0 == 0 && f.z1 == f.n && k <= 65535u;
 }
 
 template <class ID>
@@ -1633,8 +1634,9 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
 #define VP_SEEDS_NT 512
 #endif
         const dim3 grid((k + VP_SEEDS_XR - 1) / VP_SEEDS_XR, k, k);  // 4 x 4 x 4 chain positions x XR residues per tile
-        if (f.n <= 512) hipLaunchKernelGGL((jfa_pass_seeds<Id9, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
-        else            hipLaunchKernelGGL((jfa_pass_seeds<Id10, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
+        if (wide(f))         hipLaunchKernelGGL((jfa_pass_seeds<Id64, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint2*)d_in, (uint2*)d_out);
+        else if (f.n <= 512) hipLaunchKernelGGL((jfa_pass_seeds<Id9, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
+        else                 hipLaunchKernelGGL((jfa_pass_seeds<Id10, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
     } else if (f.n >= 256 && dense_applies(f, k, d_in, d_minus, d_plus, d_sdf != nullptr)) {
         if (f.n <= 512) VP_TRY(launch_dense<Id9>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
         else            VP_TRY(launch_dense<Id10>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
