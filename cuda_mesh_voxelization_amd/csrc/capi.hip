@@ -366,7 +366,10 @@ int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fi
     char* a = (char*)d_work;
     char* b = a + volBytes;
     uint32_t k = f->n / 2;                                         // jfa/sequential.cpp:72
-    if (jfa_can_start_from_mask(fr, algo) && k > 1) {
+    if (jfa_can_fuse_first_two(fr, algo)) {
+        VP_TRY(launch_jfa_first_two(ctx, fr, (const uint32_t*)(b + volBytes), a));    // passes n/2 and n/4 straight from the border mask
+        k /= 4;
+    } else if (jfa_can_start_from_mask(fr, algo) && k > 1) {
         VP_TRY(launch_jfa_first_pass(ctx, fr, (const uint32_t*)(b + volBytes), a));   // straight from the border mask
         k /= 2;
     }

@@ -1256,6 +1256,51 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
     }
 }
 
+// ------------------------------------------------------------------------------------------ seed scatter: one proposal round
+// The seed at (sx, sy, sz), held by the voxel of slot s of a closed 4-chain tile (slot = ((plane * 4 + row) * 4 + segment) * XR +
+// residue), proposes itself to the voxels STEP chain positions away along each axis, s itself included (rank 0).
+//     key = distance bits << 32 | rank << 27 | s,   rank = 1 + scan index of s as seen from the target (sequential.cpp:84-112)
+// The minimum is commutative, so the loops run (row, column, plane): dx^2 + dy^2 is formed once per row and column.
+// The minimum is commutative, so the loops run (row, column, plane): dx^2 + dy^2 is formed once per row and column.  (Spreading
+// the 27 proposals of a seed over nine threads was measured: -3 % at n = 1024, +5 .. 14 % at n = 512, profiles/r02/ab34.txt.)
+template <int XR, int STEP>
+__device__ __forceinline__ void propose(unsigned long long* keys, uint32_t s, float sx, float sy, float sz, const Frame& f,
+                                        uint32_t rx0, uint32_t ry, uint32_t rz, uint32_t k)
+{
+    const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
+    float dx2[3], dy2[3], dz2[3];
+    bool va[3], vb[3], vc[3];
+#pragma unroll
+    for (int t = -1; t <= 1; ++t) {                                // target = s - t STEP positions: s is its neighbour at +t
+        va[t + 1] = xs - t * STEP <= 3u; vb[t + 1] = jr - t * STEP <= 3u; vc[t + 1] = jp - t * STEP <= 3u;   // unsigned: also rejects < 0
+        const float dxv = sx - axis_pos(f.ox, rx0 + xr + (xs - t * STEP) * k, f.vs);
+        const float dyv = sy - axis_pos(f.oy, ry + (jr - t * STEP) * k, f.vs);
+        const float dzv = sz - axis_pos(f.oz, rz + (jp - t * STEP) * k, f.vs);
+        dx2[t + 1] = dxv * dxv; dy2[t + 1] = dyv * dyv; dz2[t + 1] = dzv * dzv;
+    }
+#pragma unroll
+    for (int b = -1; b <= 1; ++b) {
+        if (!vb[b + 1]) continue;
+#pragma unroll
+        for (int a = -1; a <= 1; ++a) {
+            if (!va[a + 1]) continue;
+            const float pre = dx2[a + 1] + dy2[b + 1];
+            // lowest plane first: the three planes are then constant non-negative offsets from one index
+            const uint32_t t0 = s - (uint32_t)(b * STEP) * (4u * XR) - (uint32_t)(a * STEP) * XR - (uint32_t)STEP * (16u * XR);
+#pragma unroll
+            for (int c = -1; c <= 1; ++c) {
+                if (!vc[c + 1]) continue;
+                const float d = pre + dz2[c + 1];
+                const bool own = a == 0 && b == 0 && c == 0;
+                if (!own && !(d < INFINITY)) continue;             // sequential.cpp:106 never takes such a candidate
+                const uint32_t rank = own ? 0u : (uint32_t)((c + 1) * 9 + (b + 1) * 3 + (a + 1) + 1);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | ((rank << 27) | s);
+                __hip_atomic_fetch_min(&keys[t0 + (uint32_t)((1 - c) * STEP) * (16u * XR)], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ seed scatter (k = n/4)
 // The pass with k = n/4 sees a state in which few voxels hold a seed yet (5 % on the headline mesh; tools/seed_occupancy.py),
 // but three quarters of the 64-voxel row segments hold at least one, so wave-uniform skipping barely helps the gather form:
@@ -1282,13 +1327,23 @@ jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     if (tid == 0) cnt = 0;
     __syncthreads();
     constexpr int PER = (int)(SLOTS / NT);                         // slots per thread, all requested before any is used
+    // slot tid + i NT = row-plane (rpb + i G) x column `col`: a thread keeps its x, and the row-plane of an iteration is the same
+    // for the whole wave (4 XR >= 64 slots per row-plane), so row addresses are scalar work
+    constexpr uint32_t RPW = 4u * XR;
+    constexpr uint32_t G = NT / RPW;
+    static_assert(NT % RPW == 0 && RPW % 64u == 0, "a wave must stay inside one row-plane");
+    const uint32_t col = tid % RPW, myx = rx0 + col % XR + (col / XR) * k;
+    const bool xin = rx0 + col % XR < k;
+    const uint32_t rpb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / RPW));
+    auto row_of = [&](int i) {                                     // voxel index of x = 0 of the row-plane of iteration i
+        const uint32_t rp = rpb + (uint32_t)i * G;
+        return ((size_t)(rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N;
+    };
     T mine[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const uint32_t s = tid + (uint32_t)i * NT;
-        const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
         mine[i] = ID::none();
-        if (rx0 + xr < k) mine[i] = in[((size_t)(rz + jp * k) * N + (ry + jr * k)) * N + (rx0 + xr + xs * k)];
+        if (xin) mine[i] = in[row_of(i) + myx];
     }
     uint32_t nmine = 0;                                            // seeds of this wave, lane 0 reserves list space once
     unsigned long long ms[PER];
@@ -1313,39 +1368,8 @@ jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     for (uint32_t e = tid; e < nseeds; e += NT) {
         const uint32_t s = list[e];
         const T id = ids[s];
-        const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
-        const float sx = axis_pos(f.ox, ID::xoff(id) >> 2, f.vs);
-        const float sy = axis_pos(f.oy, scr(ID::yoff(id) >> 2), f.vs);
-        const float sz = axis_pos(f.oz, scr(ID::zoff(id) >> 2), f.vs);
-        // squared differences to the up to three chain positions per axis this voxel is a neighbour of: the voxel itself (t = 0)
-        // and the ones k below / above it -- for the target v = u - t k the source u is the neighbour at +t
-        float dx2[3], dy2[3], dz2[3];
-#pragma unroll
-        for (int t = -1; t <= 1; ++t) {
-            const float dxv = sx - axis_pos(f.ox, rx0 + xr + (xs - t) * k, f.vs);
-            const float dyv = sy - axis_pos(f.oy, ry + (jr - t) * k, f.vs);
-            const float dzv = sz - axis_pos(f.oz, rz + (jp - t) * k, f.vs);
-            dx2[t + 1] = dxv * dxv; dy2[t + 1] = dyv * dyv; dz2[t + 1] = dzv * dzv;
-        }
-#pragma unroll
-        for (int c = -1; c <= 1; ++c) {
-            if (jp - c > 3u) continue;                             // unsigned: also rejects -1
-#pragma unroll
-            for (int b = -1; b <= 1; ++b) {
-                if (jr - b > 3u) continue;
-#pragma unroll
-                for (int a = -1; a <= 1; ++a) {
-                    if (xs - a > 3u) continue;
-                    const float d = (dx2[a + 1] + dy2[b + 1]) + dz2[c + 1];
-                    const bool own = a == 0 && b == 0 && c == 0;
-                    if (!own && !(d < INFINITY)) continue;         // sequential.cpp:106 never takes such a candidate
-                    const uint32_t rank = own ? 0u : (uint32_t)((c + 1) * 9 + (b + 1) * 3 + (a + 1) + 1);
-                    const uint32_t t = (((jp - c) * 4u + (jr - b)) * 4u + (xs - a)) * XR + xr;
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (rank << 27) | s;
-                    __hip_atomic_fetch_min(&keys[t], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
+        propose<XR, 1>(keys, s, axis_pos(f.ox, ID::xoff(id) >> 2, f.vs), axis_pos(f.oy, scr(ID::yoff(id) >> 2), f.vs),
+                       axis_pos(f.oz, scr(ID::zoff(id) >> 2), f.vs), f, rx0, ry, rz, k);
     }
     __syncthreads();
     unsigned long long won[PER];
@@ -1353,11 +1377,108 @@ jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     for (int i = 0; i < PER; ++i) won[i] = keys[tid + (uint32_t)i * NT];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const uint32_t s = tid + (uint32_t)i * NT;
-        const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
-        if (rx0 + xr >= k) continue;
+        if (!xin) continue;
         const T id = won[i] == kEmpty ? ID::none() : ids[(uint32_t)won[i] & 0x07FFFFFFu];
-        out[((size_t)(rz + jp * k) * N + (ry + jr * k)) * N + (rx0 + xr + xs * k)] = id;
+        out[row_of(i) + myx] = id;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ first two passes from the mask
+// Passes k = n/2 and k = n/4 in one kernel, straight from the border bitmask.  Both steps are steps along the closed 4-chains of
+// jfa_pass_seeds (+-n/2 = two chain positions, +-n/4 = one), so the state after the first pass of a tile's 64 x XR voxels depends
+// on the border bits of those same voxels only: nothing but 64 x XR bits is read, the first pass never touches HBM at all, and the
+// id volume is written once.  Stage A scatters the border voxels (0.7 % on the headline mesh) two positions along each axis, which
+// leaves every voxel with the slot of its pass-1 seed (or none); stage B scatters the voxels that have one (5 %) one position
+// along each axis with that seed's coordinates.  Keys and ranks as in jfa_pass_seeds; a seed's coordinates are those of its slot.
+template <class ID, int XR, int NT>
+__global__ void __launch_bounds__(NT)
+jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out)
+{
+    using T = typename ID::T;
+    constexpr uint32_t SLOTS = 64u * XR;                           // slot = ((plane * 4 + row) * 4 + segment) * XR + residue
+    constexpr int PER = (int)(SLOTS / NT);
+    constexpr unsigned long long kEmpty = 0x7F800000FFFFFFFFull;
+    constexpr uint16_t kNoSeed = 0xFFFFu;
+    static_assert(SLOTS < 0xFFFFu && SLOTS % NT == 0, "tile");
+    __shared__ unsigned long long keys[SLOTS];
+    __shared__ uint16_t seedOf[SLOTS];                             // after stage A: slot of the voxel's pass-1 seed
+    __shared__ T idOf[SLOTS];                                      // packed id of the voxel of a slot (what a seed at that slot is called)
+    __shared__ uint16_t list[SLOTS];
+    __shared__ uint32_t cnt[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, N = f.n, k = N / 4u;
+    const uint32_t rx0 = blockIdx.x * XR, ry = blockIdx.y, rz = blockIdx.z;
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
+    auto coords = [&](uint32_t s, uint32_t& x, uint32_t& y, uint32_t& z) {
+        x = rx0 + s % XR + ((s / XR) & 3u) * k; y = ry + ((s / (4u * XR)) & 3u) * k; z = rz + (s / (16u * XR)) * k;
+    };
+    // wave-cooperative append of the slots whose flag is set (one reservation per wave)
+    auto append = [&](const bool (&flag)[PER], uint32_t& counter) {
+        unsigned long long ms[PER];
+        uint32_t n = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { ms[i] = __ballot(flag[i]); n += (uint32_t)__popcll(ms[i]); }
+        uint32_t base = 0;
+        if (lane == 0 && n) base = atomicAdd(&counter, n);
+        base = (uint32_t)__shfl((int)base, 0);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (flag[i]) list[base + (uint32_t)__popcll(ms[i] & ((1ull << lane) - 1ull))] = (uint16_t)(tid + (uint32_t)i * NT);
+            base += (uint32_t)__popcll(ms[i]);
+        }
+    };
+    // every entry of the list proposes the seed that sits at slot q (its coordinates are those of q) from slot s
+    auto scatter = [&](uint32_t nlist, auto seed_slot, auto step) {
+        constexpr int STEP = decltype(step)::value;
+        for (uint32_t e = tid; e < nlist; e += NT) {
+            const uint32_t s = list[e];
+            uint32_t qx, qy, qz;
+            coords(seed_slot(s), qx, qy, qz);
+            propose<XR, STEP>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k);
+        }
+    };
+
+    // slot tid + i NT = row-plane (rpb + i G) x column `col` (see jfa_pass_seeds): row addresses are scalar work
+    constexpr uint32_t RPW = 4u * XR;
+    constexpr uint32_t G = NT / RPW;
+    static_assert(NT % RPW == 0 && RPW % 64u == 0, "a wave must stay inside one row-plane");
+    const uint32_t col = tid % RPW, myx = rx0 + col % XR + (col / XR) * k;
+    const bool xin = rx0 + col % XR < k;
+    const uint32_t rpb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / RPW));
+    // ---- stage A: border voxels -> pass with k = n/2
+    bool flag[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t s = tid + (uint32_t)i * NT;
+        const uint32_t rp = rpb + (uint32_t)i * G, y = ry + (rp & 3u) * k, z = rz + (rp >> 2) * k;
+        flag[i] = xin && ((border[((size_t)z * N + y) * f.w + (myx >> 5)] >> (myx & 31u)) & 1u);
+        keys[s] = kEmpty;
+        idOf[s] = ID::pack(myx, y, z);
+    }
+    append(flag, cnt[0]);
+    __syncthreads();
+    scatter(cnt[0], [](uint32_t s) { return s; }, std::integral_constant<int, 2>{});
+    __syncthreads();
+    // ---- stage B: voxels that have a seed now -> pass with k = n/4
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t s = tid + (uint32_t)i * NT;
+        const unsigned long long key = keys[s];
+        flag[i] = key != kEmpty;
+        seedOf[s] = flag[i] ? (uint16_t)((uint32_t)key & 0x07FFFFFFu) : kNoSeed;
+        keys[s] = kEmpty;                                          // own slots only: nobody else touches them before the barrier
+    }
+    append(flag, cnt[1]);
+    __syncthreads();
+    scatter(cnt[1], [&](uint32_t s) { return (uint32_t)seedOf[s]; }, std::integral_constant<int, 1>{});
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (!xin) continue;
+        const unsigned long long key = keys[tid + (uint32_t)i * NT];
+        const T id = key == kEmpty ? ID::none() : idOf[seedOf[(uint32_t)key & 0x07FFFFFFu]];
+        const uint32_t rp = rpb + (uint32_t)i * G;
+        out[((size_t)(rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx] = id;
     }
 }
 
@@ -1441,7 +1562,40 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, c
     return launch_jfa_pass_ex(ctx, f, k, d_in, d_minus, d_plus, d_out, algo, nullptr, 0.0f, nullptr);
 }
 
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 bool jfa_can_start_from_mask(const Frame& f, int algo) { return algo == VP_ALGO_TILED && f.n >= 256 && f.n % 128 == 0; }
+
+// Passes k = n/2 and k = n/4 of a whole grid from its border mask in one launch (jfa_first_two); timed as the first pass.
+#ifndef VP_JFA_FIRST_TWO_DEFAULT
+#define VP_JFA_FIRST_TWO_DEFAULT 1
+#endif
+bool jfa_can_fuse_first_two(const Frame& f, int algo)
+{
+    static const int enabled = env_int("VP_JFA_FIRST_TWO", VP_JFA_FIRST_TWO_DEFAULT);
+    return enabled && jfa_can_start_from_mask(f, algo) && f.z0 == 0 && f.z1 == f.n && f.n / 8 >= 1;
+}
+
+int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out)
+{
+    ProfScope p(ctx, VP_K_JFA_FIRST);
+    const uint32_t k = f.n / 4;
+    // tile = 4 x 4 x 4 chain positions x XR residues.  Measured (profiles/r02/ab33.txt): 16 residues x 256 threads is the best
+    // shape at n = 512 (0.404 ms against 0.183 + 0.307 for the two separate kernels; 32 x 512: 0.436), 32 x 512 at n = 1024
+    // (2.94 ms against 1.39 + 2.12; 16 x 256: 3.41).  The kernel is bound by the latency of its stages, not by bytes or VALU.
+    const bool small = f.n <= 512;
+    const uint32_t xr = small ? 16u : 32u;
+    const dim3 grid((k + xr - 1) / xr, k, k);
+    if (wide(f))    hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out);
+    else if (small) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out);
+    else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out);
+    VP_HIP(hipGetLastError());
+    return 0;
+}
 
 // First pass from the whole-grid border mask (see jfa_first_pass).
 int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out)
@@ -1521,11 +1675,6 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 
 // Dense tile kernel (jfa_pass_dense): 32-bit ids, dense passes (and, as build options, the wide passes and the fused last
 // pass), id buffers contiguous.
-static int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 #ifndef VP_JFA_DENSE_FINAL
 #define VP_JFA_DENSE_FINAL 1      // the fused last pass runs here too: 0.397 -> 0.368 ms at n = 512, 3.62 -> 3.42 ms at n = 1024 against

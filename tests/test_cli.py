@@ -155,7 +155,7 @@ def test_cli_export_meshes(cli, tmp_path):
 @pytest.mark.gpu
 def test_cli_runs_the_benchmarked_kernel_sequence(cli, engine, tmp_path):
     """JFA::Compute<TILED> (what `vpcli -t 2 -s` calls) runs the SAME launch sequence as vp_jfa, which bench.py times:
-    border mask, first pass from the mask, sparse / dense tile passes, fused last pass -- same kernels, same launch
+    border mask, the first two passes from the mask in one launch, dense tile passes, fused last pass -- same kernels, same launch
     counts, device time within 5 % (read from vp_prof in both processes)."""
     import math
     import torch
@@ -172,7 +172,7 @@ def test_cli_runs_the_benchmarked_kernel_sequence(cli, engine, tmp_path):
         elif line.startswith("[TiledJFA]:"):
             runs.append(cur); cur = {}
     assert len(runs) == 4
-    want = {"surface": 1, "jfa_first": 1, "jfa_sparse": 1, "jfa_dense": 6, "jfa_last": 1}
+    want = {"surface": 1, "jfa_first": 1, "jfa_dense": 6, "jfa_last": 1}       # jfa_first = passes n/2 and n/4 in one launch
     for r in runs:
         assert {k: c for k, (_, c) in r.items()} == want, r
     cli_ms = min(sum(ms for ms, _ in r.values()) for r in runs[1:])
