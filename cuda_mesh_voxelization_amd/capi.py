@@ -23,7 +23,7 @@ SYMBOLS = [
     "vp_malloc", "vp_free", "vp_memset", "vp_memcpy_d2d", "vp_ctx_workspace", "vp_ctx_release", "vp_upload", "vp_download",
     "vp_grid_words", "vp_grid_voxels",
     "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa", "vp_jfa_start", "vp_jfa_run", "vp_jfa_init", "vp_jfa_pass",
-    "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass",
+    "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass", "vp_jfa_can_fuse_first_two", "vp_jfa_first_two",
     "vp_surface", "vp_extract_count", "vp_extract", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_select", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
 ]
@@ -111,6 +111,8 @@ def lib():
         "vp_jfa_last_pass": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int]),
         "vp_jfa_can_start_from_mask": (ctypes.c_int, [fp, ctypes.c_int]),
         "vp_jfa_first_pass": (ctypes.c_int, [_vp, fp, _vp, _vp]),
+        "vp_jfa_can_fuse_first_two": (ctypes.c_int, [fp, ctypes.c_int]),
+        "vp_jfa_first_two": (ctypes.c_int, [_vp, fp, _vp, _vp]),
         "vp_surface": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
         "vp_extract_count": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
         "vp_extract": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_int, _vp, _vp, _vp, _sz]),
@@ -236,6 +238,13 @@ class Context:
 
     def jfa_can_start_from_mask(self, frame: Frame, algo: int = ALGO_TILED) -> bool:
         return bool(lib().vp_jfa_can_start_from_mask(ctypes.byref(frame), algo))
+
+    def jfa_can_fuse_first_two(self, frame: Frame, algo: int = ALGO_TILED) -> bool:
+        return bool(lib().vp_jfa_can_fuse_first_two(ctypes.byref(frame), algo))
+
+    def jfa_first_two(self, frame: Frame, d_border_grid: int, d_out: int):
+        """passes n/2 and n/4 of a whole grid in one launch from its border mask"""
+        check(lib().vp_jfa_first_two(self._h, ctypes.byref(frame), _vp(d_border_grid), _vp(d_out)))
 
     def jfa_first_pass(self, frame: Frame, d_border_grid: int, d_out: int):
         check(lib().vp_jfa_first_pass(self._h, ctypes.byref(frame), _vp(d_border_grid), _vp(d_out)))

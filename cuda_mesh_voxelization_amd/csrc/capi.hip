@@ -407,6 +407,22 @@ int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_g
     return launch_jfa_first_pass(ctx, fr, d_border_grid, d_out);
 }
 
+int vp_jfa_can_fuse_first_two(const vp_frame* f, int algo)
+{
+    return (f && check_frame(f, "vp_jfa_can_fuse_first_two", false) == 0 && jfa_can_fuse_first_two(make_frame(f), algo)) ? 1 : 0;
+}
+
+int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out)
+{
+    if (!ctx || !d_border_grid || !d_out) return set_error(VP_ERR_INVALID, "vp_jfa_first_two: null argument");
+    VP_TRY(bind_device(ctx));
+    VP_TRY(check_frame(f, "vp_jfa_first_two", false));
+    const Frame fr = make_frame(f);
+    if (!jfa_can_fuse_first_two(fr, VP_ALGO_TILED))
+        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_two: needs a whole-grid frame with n >= 256 and n %% 128 == 0");
+    return launch_jfa_first_two(ctx, fr, d_border_grid, d_out);
+}
+
 int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const void* d_minus, const void* d_plus,
                      void* d_scratch, const uint32_t* d_words, float fill_unset, float* d_sdf, int algo)
 {

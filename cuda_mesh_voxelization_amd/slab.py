@@ -86,6 +86,12 @@ class HipSlabBackend:
     def surface(self, frame, words, border):
         self.ctx.surface(frame, words.data_ptr(), None, None, border.data_ptr())
 
+    def can_fuse_first_two(self, frame, algo):
+        return self.ctx.jfa_can_fuse_first_two(frame, algo)
+
+    def jfa_first_two_global(self, frame, border_full, dst_full):
+        self.ctx.jfa_first_two(frame, border_full.data_ptr(), dst_full.data_ptr())
+
     def jfa_first_pass_global(self, region, border_full, dst_full):
         self.ctx.jfa_first_pass(region, border_full.data_ptr(),
                                 dst_full.data_ptr() + region.z0 * region.n * region.n * self.ctx.jfa_id_bytes(region))
@@ -290,7 +296,8 @@ class GhostSlabPipeline:
         n, passes = self.global_frame.n, len(self.regions)
         return {"pipeline": "ghost", "slab_planes": self.z1 - self.z0, "regions": [[k, b0, b1] for k, b0, b1 in self.regions],
                 "plane_passes_this_rank": int(self.planes_computed), "plane_passes_one_gpu": n * passes,
-                "work_ceiling_speedup": round(n * passes / self.planes_computed, 3), "bytes_exchanged": 0}
+                "work_ceiling_speedup": round(n * passes / self.planes_computed, 3), "bytes_exchanged": 0,
+                "first_two_passes_fused_over_whole_grid": bool(getattr(self, "fused_first_two", False))}
 
     def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
         out = self.words if out is None else out
@@ -313,7 +320,18 @@ class GhostSlabPipeline:
             self.be.surface(self.global_frame, self.words, self.border)
         else:
             self.be.jfa_init(self.global_frame, self.words, None, None, a)
+        # The first two passes (k = n/2, n/4) as ONE launch over the whole grid (vp_jfa_first_two) where the second pass would cover
+        # most of the grid anyway: 0.40 ms at n = 512 against 0.18 for the first pass + 0.36 x the covered fraction for the second.
+        skip = 0
+        if (mask_start and last >= 2 and hasattr(self.be, "can_fuse_first_two") and self.be.can_fuse_first_two(self.global_frame, algo)
+                and (self.regions[1][2] - self.regions[1][1]) * 100 >= 65 * self.global_frame.n):
+            self.be.jfa_first_two_global(self.global_frame, self.border, b)
+            a, b = b, a
+            skip = 2
+            self.fused_first_two = True
         for i, (k, b0, b1) in enumerate(self.regions):
+            if i < skip:
+                continue
             region = self.global_frame.slab(b0, b1)
             if i == 0 and mask_start:
                 self.be.jfa_first_pass_global(region, self.border, b)

@@ -163,6 +163,11 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
  * identical to vp_jfa_init + vp_jfa_pass(k = n/2). */
 int vp_jfa_can_start_from_mask(const vp_frame* f, int algo);
 int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out);
+/* The passes k = n/2 AND k = n/4 of a WHOLE grid in one launch from its border bitmask (vp_jfa uses it internally): identical
+ * to vp_jfa_first_pass + vp_jfa_pass(k = n/4), with the first pass never written to memory.  Whole-grid frames only
+ * (z0 = 0, z1 = n); a slab driver whose second pass covers most of the grid anyway may run it instead of the two region passes. */
+int vp_jfa_can_fuse_first_two(const vp_frame* f, int algo);
+int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out);
 
 /* "Surface" output (README.md:9): the border-voxel mask that JFA seeds
  * from (jfa/sequential.cpp:24-64), as a bitmask with the grid's layout. */

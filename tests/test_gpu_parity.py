@@ -574,6 +574,13 @@ def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
             engine.ctx.jfa_first_pass(fr, border.data_ptr(), a.data_ptr())
             engine.sync()
             assert torch.equal(a, b), (n, kind, "first pass from the mask", int((a != b).sum().item()))
+        if k == n // 4 and engine.ctx.jfa_can_fuse_first_two(fr, ALGO_TILED):
+            # ... and what vp_jfa runs since: both passes in one launch from the mask (vp_jfa_first_two)
+            border = torch.empty(fr.words, dtype=torch.int32, device=engine.device)
+            engine.ctx.surface(fr, g.data_ptr(), None, None, border.data_ptr())
+            engine.ctx.jfa_first_two(fr, border.data_ptr(), a.data_ptr())
+            engine.sync()
+            assert torch.equal(a, b), (n, kind, "passes n/2 + n/4 from the mask", int((a != b).sum().item()))
         cur, a = a, cur
         k //= 2
 
