@@ -14,6 +14,8 @@
 //     -e, --export           export phases as OBJ into out/ (created if missing): per-mesh grids, the CSG result,
 //                            sdf-coloured cubes and point cloud -- file names as in the reference
 //     -d, --dump PREFIX      (extension) write PREFIX.grid.u32 and PREFIX.sdf.f32 raw little-endian dumps
+//     -g, --gpus G           (extension) cut the grid into G Z-slabs, one per device 0 .. G-1 (the reference pins device 0,
+//                            apps/cli/main.cpp:22-23); --multi ghost|halo picks the JFA variant (vphip.h, vp_multi_jfa)
 //     -h, --help
 #include <cmath>
 #include <cstdint>
@@ -36,6 +38,7 @@
 #include "mesh/mesh_io.h"
 #include "proc_utils.h"
 #include "vox/vox.h"
+#include "vp_runtime.h"
 
 using gridType = uint32_t;
 
@@ -52,6 +55,8 @@ struct Options {
     unsigned blockSize = 32;
     unsigned iterations = 1;
     std::string dump;
+    unsigned gpus = 1;
+    std::string multi = "ghost";
     bool help = false;
 };
 
@@ -64,9 +69,15 @@ const char* kUsage =
     "  -p, --operation arg   CSG Operations (1 = union, 2 = inter, 3 = diff) (default: 0)\n"
     "  -e, --export          Exports the phases\n"
     "  -s, --sdf             Active SDF calculation on output file\n"
-    "  -b, --block-size arg  Number of thread in block to process tiled voxelization (default: 32)\n"
+    "  -b, --block-size arg  Number of thread in block to process tiled voxelization (default: 32); accepted and checked\n"
+    "                        (multiple of 16) for compatibility, WITHOUT effect: the tile kernels of this build have fixed\n"
+    "                        shapes (one wave per 8 x 8 columns)\n"
     "  -m, --benckmark arg   Number of iteration in benckmark mode (if not present benckmark are off) (default: 1)\n"
     "  -d, --dump arg        Write raw dumps <arg>.grid.u32 / <arg>.sdf.f32 (extension)\n"
+    "  -g, --gpus arg        GPU types: cut the grid into <arg> Z-slabs, one per device 0 .. <arg>-1 (extension; default: 1);\n"
+    "                        <arg> must divide the side into slabs of a multiple of 8 planes\n"
+    "      --multi arg       JFA on several devices: ghost = recomputed ghost planes, no exchange between passes (default);\n"
+    "                        halo = halo planes copied device to device before every pass\n"
     "  -h, --help            Print usage\n";
 
 // Minimal getopt-style parser: -x V, -xV, --long V, --long=V, boolean switches, positionals.
@@ -74,7 +85,7 @@ Options Parse(int argc, char** argv)
 {
     static const std::map<std::string, char> longNames = {
         {"filenames", 'i'}, {"num-voxels", 'n'}, {"type", 't'}, {"output", 'o'}, {"operation", 'p'}, {"export", 'e'},
-        {"sdf", 's'}, {"block-size", 'b'}, {"benckmark", 'm'}, {"benchmark", 'm'}, {"dump", 'd'}, {"help", 'h'}};
+        {"sdf", 's'}, {"block-size", 'b'}, {"benckmark", 'm'}, {"benchmark", 'm'}, {"dump", 'd'}, {"gpus", 'g'}, {"multi", 'M'}, {"help", 'h'}};
     Options o;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -114,6 +125,8 @@ Options Parse(int argc, char** argv)
             case 'b': o.blockSize = static_cast<unsigned>(std::stoul(value)); break;
             case 'm': o.iterations = static_cast<unsigned>(std::stoul(value)); break;
             case 'd': o.dump = value; break;
+            case 'g': o.gpus = static_cast<unsigned>(std::stoul(value)); break;
+            case 'M': o.multi = value; break;
             default: cpuAssert(false, std::string("Unknown option -") + key + "\n");
         }
     }
@@ -164,6 +177,18 @@ int main(int argc, char** argv)
     const bool BENCHMARK = opt.iterations > 1;
     const bool EXPORT = !BENCHMARK && opt.doExport;
     const bool GPU = TYPE == Types::NAIVE || TYPE == Types::TILED;      // exports: the walk over the grid runs on the device too
+    cpuAssert(opt.gpus >= 1 && opt.gpus <= 64, "Number of GPUs must be 1..64");
+    cpuAssert(opt.multi == "ghost" || opt.multi == "halo", "--multi must be ghost or halo");
+    if (GPU && opt.gpus > 1) {
+        // Z-slabs over devices 0 .. G-1.  VPLIB_SHARE_GPU=1 (test rigs with fewer devices than slabs): the slabs share the devices
+        // there are -- same code path, several contexts per device.
+        std::vector<int> devices(opt.gpus);
+        int present = 0;
+        const char* share = std::getenv("VPLIB_SHARE_GPU");
+        if (share && std::strcmp(share, "1") == 0) present = vplib::DeviceCount();
+        for (unsigned i = 0; i < opt.gpus; ++i) devices[i] = present > 0 ? static_cast<int>(i % static_cast<unsigned>(present)) : static_cast<int>(i);
+        vplib::SetDevices(devices, opt.multi == "ghost");
+    }
 
     std::vector<Mesh> meshes(opt.filenames.size());
     std::vector<HostVoxelsGrid<gridType>> grids(opt.filenames.size());

@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvphip.so")
 CLI = os.path.join(PKG, "vpcli")
 
-HIP_SOURCES = ["capi.hip", "vox.hip", "csg.hip", "jfa.hip", "extract.hip"]
+HIP_SOURCES = ["capi.hip", "vox.hip", "csg.hip", "jfa.hip", "extract.hip", "multi.hip"]
 # -ffp-contract=off is part of the parity contract: an FMA changes the bitmask / sdf bits.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
              "-Wall", "-Wno-unused-function"]

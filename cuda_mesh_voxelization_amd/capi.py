@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("VPHIP_LIB") or os.path.join(PKG, "libvphip.so")   # V
 ALGO_NAIVE, ALGO_TILED = 1, 2
 OP_VOID, OP_UNION, OP_INTERSECTION, OP_DIFFERENCE = 0, 1, 2, 3
 EXTRACT_SET, EXTRACT_EXPOSED = 0, 1
+MULTI_HALO, MULTI_GHOST = 0, 1
 
 KERNELS = ["vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
            "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract"]
@@ -19,13 +20,15 @@ JFA_PASS_KEYS = ("jfa_pass", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last")
 
 # every symbol include/vphip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_stream", "vp_ctx_sync", "vp_last_error", "vp_abi_version",
+    "vp_device_count", "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_stream", "vp_ctx_sync", "vp_last_error", "vp_abi_version",
     "vp_malloc", "vp_free", "vp_memset", "vp_memcpy_d2d", "vp_ctx_workspace", "vp_ctx_release", "vp_upload", "vp_download",
     "vp_grid_words", "vp_grid_voxels",
     "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa", "vp_jfa_start", "vp_jfa_run", "vp_jfa_init", "vp_jfa_pass",
     "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass", "vp_jfa_can_fuse_first_two", "vp_jfa_first_two",
     "vp_surface", "vp_extract_count", "vp_extract", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_select", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
+    "vp_multi_create", "vp_multi_destroy", "vp_multi_count", "vp_multi_ctx", "vp_multi_sync", "vp_multi_set_mesh", "vp_multi_voxelize",
+    "vp_multi_set_grid", "vp_multi_get_grid", "vp_multi_csg", "vp_multi_jfa", "vp_multi_get_sdf", "vp_multi_bytes_moved",
 ]
 
 
@@ -82,6 +85,7 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     fp = ctypes.POINTER(Frame)
     sig = {
+        "vp_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
         "vp_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
         "vp_ctx_destroy": (ctypes.c_int, [_vp]),
         "vp_ctx_set_stream": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
@@ -124,6 +128,19 @@ def lib():
         "vp_prof_reset": (ctypes.c_int, [_vp]),
         "vp_prof_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
         "vp_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
+        "vp_multi_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(_vp)]),
+        "vp_multi_destroy": (ctypes.c_int, [_vp]),
+        "vp_multi_count": (ctypes.c_int, [_vp]),
+        "vp_multi_ctx": (_vp, [_vp, ctypes.c_int]),
+        "vp_multi_sync": (ctypes.c_int, [_vp]),
+        "vp_multi_set_mesh": (ctypes.c_int, [_vp, _vp, _sz, _vp, _sz]),
+        "vp_multi_voxelize": (ctypes.c_int, [_vp, fp, ctypes.c_int]),
+        "vp_multi_set_grid": (ctypes.c_int, [_vp, fp, _vp]),
+        "vp_multi_get_grid": (ctypes.c_int, [_vp, _vp]),
+        "vp_multi_csg": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+        "vp_multi_jfa": (ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_int, ctypes.c_int]),
+        "vp_multi_get_sdf": (ctypes.c_int, [_vp, _vp]),
+        "vp_multi_bytes_moved": (ctypes.c_uint64, [_vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the symbol is not exported
@@ -296,3 +313,71 @@ class Context:
             if n.value:
                 out[name] = {"ms": ms.value, "launches": int(n.value)}
         return out
+
+
+class Multi:
+    """vp_multi: one process, several devices (or several contexts on one device), Z-slabs.  Host arrays are numpy."""
+
+    def __init__(self, devices):
+        import numpy as np
+        self._np = np
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = _vp()
+        check(lib().vp_multi_create(devs, len(devices), ctypes.byref(self._h)))
+        self.frame = None
+
+    def close(self):
+        if self._h:
+            lib().vp_multi_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def count(self):
+        return lib().vp_multi_count(self._h)
+
+    def set_mesh(self, xyz, tri):
+        np = self._np
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        tri = np.ascontiguousarray(tri, dtype=np.uint32)
+        check(lib().vp_multi_set_mesh(self._h, xyz.ctypes.data, xyz.shape[0], tri.ctypes.data, tri.shape[0]))
+
+    def voxelize(self, frame: Frame, algo=ALGO_TILED):
+        self.frame = frame
+        check(lib().vp_multi_voxelize(self._h, ctypes.byref(frame), algo))
+
+    def set_grid(self, frame: Frame, words):
+        np = self._np
+        self.frame = frame
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        assert words.size == frame.words
+        check(lib().vp_multi_set_grid(self._h, ctypes.byref(frame), words.ctypes.data))
+
+    def get_grid(self):
+        out = self._np.empty(self.frame.words, dtype=self._np.uint32)
+        check(lib().vp_multi_get_grid(self._h, out.ctypes.data))
+        return out
+
+    def csg(self, other, op):
+        other = self._np.ascontiguousarray(other, dtype=self._np.uint32)
+        check(lib().vp_multi_csg(self._h, other.ctypes.data, op))
+
+    def jfa(self, fill=float("-inf"), algo=ALGO_TILED, mode=MULTI_HALO):
+        check(lib().vp_multi_jfa(self._h, fill, algo, mode))
+
+    def get_sdf(self):
+        out = self._np.empty(self.frame.voxels, dtype=self._np.float32)
+        check(lib().vp_multi_get_sdf(self._h, out.ctypes.data))
+        return out
+
+    def sync(self):
+        check(lib().vp_multi_sync(self._h))
+
+    @property
+    def bytes_moved(self):
+        return int(lib().vp_multi_bytes_moved(self._h))

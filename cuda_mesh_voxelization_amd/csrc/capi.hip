@@ -105,6 +105,13 @@ static int bind_device(vp_ctx* ctx)
     return 0;
 }
 
+// vp_extract must follow a vp_extract_count of the same grid CONTENTS; the record of that count is dropped as soon as the
+// buffer it was taken from is written through this ABI or handed out again as a workspace slot.
+static void grid_written(vp_ctx* ctx, const void* d_ptr)
+{
+    if (d_ptr && d_ptr == (const void*)ctx->ext_words) ctx->ext_words = nullptr;
+}
+
 static const char* kNames[VP_K_COUNT] = {
     "vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
     "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract"
@@ -119,6 +126,14 @@ extern "C" {
 int vp_abi_version(void) { return VP_ABI_VERSION; }
 
 const char* vp_last_error(void) { return g_err; }
+
+int vp_device_count(int* out)
+{
+    if (!out) return set_error(VP_ERR_INVALID, "vp_device_count: null out");
+    *out = 0;
+    VP_HIP(hipGetDeviceCount(out));
+    return 0;
+}
 
 int vp_ctx_create(int device, vp_ctx** out)
 {
@@ -187,6 +202,8 @@ int vp_free(vp_ctx* ctx, void* d_ptr)
 {
     if (!ctx) return set_error(VP_ERR_INVALID, "vp_free: null ctx");
     VP_TRY(bind_device(ctx));
+    grid_written(ctx, d_ptr);
+    if (d_ptr == ctx->jfa_started.work) ctx->jfa_started.valid = false;
     if (d_ptr) { VP_HIP(hipStreamSynchronize(ctx->stream)); VP_HIP(hipFree(d_ptr)); }
     return 0;
 }
@@ -195,6 +212,7 @@ int vp_memcpy_d2d(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes)
 {
     if (!ctx || ((!d_dst || !d_src) && bytes)) return set_error(VP_ERR_INVALID, "vp_memcpy_d2d: null argument");
     VP_TRY(bind_device(ctx));
+    grid_written(ctx, d_dst);
     if (bytes) VP_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
@@ -205,6 +223,7 @@ int vp_ctx_workspace(vp_ctx* ctx, int slot, size_t bytes, void** d_out)
     VP_TRY(bind_device(ctx));
     VP_TRY(reserve(ctx, ctx->slots[slot], bytes ? bytes : 1));
     *d_out = ctx->slots[slot].ptr;
+    grid_written(ctx, *d_out);                                     // whoever asks for the slot is about to fill it
     return 0;
 }
 
@@ -215,6 +234,8 @@ int vp_ctx_release(vp_ctx* ctx)
     VP_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < VP_WORKSPACE_SLOTS; ++i) release(ctx->slots[i]);
     release(ctx->jfa_work);
+    ctx->jfa_started.valid = false;
+    ctx->ext_words = nullptr;
     return 0;
 }
 
@@ -222,6 +243,7 @@ int vp_memset(vp_ctx* ctx, void* d_ptr, int byte_value, size_t bytes)
 {
     if (!ctx || (!d_ptr && bytes)) return set_error(VP_ERR_INVALID, "vp_memset: null argument");
     VP_TRY(bind_device(ctx));
+    grid_written(ctx, d_ptr);
     if (bytes) VP_HIP(hipMemsetAsync(d_ptr, byte_value, bytes, ctx->stream));
     return 0;
 }
@@ -230,6 +252,7 @@ int vp_upload(vp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes)
 {
     if (!ctx || ((!d_dst || !h_src) && bytes)) return set_error(VP_ERR_INVALID, "vp_upload: null argument");
     VP_TRY(bind_device(ctx));
+    grid_written(ctx, d_dst);
     if (bytes) {
         VP_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
         VP_HIP(hipStreamSynchronize(ctx->stream));
@@ -260,6 +283,7 @@ int vp_voxelize(vp_ctx* ctx, const vp_frame* f, uint32_t* d_words, const float* 
     if (ntris && (!d_xyz || !d_tri || !nverts)) return set_error(VP_ERR_INVALID, "vp_voxelize: null mesh arrays");
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_voxelize: algo %d", algo);
     if (ntris > 0xFFFFFFFFull / 3) return set_error(VP_ERR_UNSUPPORTED, "vp_voxelize: too many triangles");
+    grid_written(ctx, d_words);
     return launch_voxelize(ctx, make_frame(f), d_words, d_xyz, nverts, d_tri, ntris, algo, accumulate ? 1 : 0);
 }
 
@@ -268,6 +292,7 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
     if (!ctx || ((!d_a || !d_b) && nwords)) return set_error(VP_ERR_INVALID, "vp_csg: null argument");
     VP_TRY(bind_device(ctx));
     if (op < VP_OP_VOID || op > VP_OP_DIFFERENCE) return set_error(VP_ERR_INVALID, "vp_csg: unknown op %d", op);
+    grid_written(ctx, d_a);
     return launch_csg(ctx, d_a, d_b, nwords, op);
 }
 
@@ -336,7 +361,9 @@ static int jfa_check(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, vo
     VP_TRY(check_frame(f, who, true));
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "%s: algo %d", who, algo);
     if (!d_work) {                                                 // context-owned workspace (grow-only, reused by later calls)
+        const void* before = ctx->jfa_work.ptr;
         VP_TRY(reserve(ctx, ctx->jfa_work, vp_jfa_workspace_bytes(f)));
+        if (ctx->jfa_work.ptr != before) ctx->jfa_started.valid = false;   // regrown: what a vp_jfa_start left there is gone
         d_work = ctx->jfa_work.ptr;
     } else if (work_bytes < vp_jfa_workspace_bytes(f)) {
         return set_error(VP_ERR_INVALID, "%s: workspace too small", who);
@@ -350,9 +377,12 @@ int vp_jfa_start(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void* 
     const Frame fr = make_frame(f);
     const size_t volBytes = vp_grid_voxels(f) * vp_jfa_id_bytes(f);
     char* a = (char*)d_work;
-    if (jfa_can_start_from_mask(fr, algo) && f->n / 2 > 1)
-        return launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, nullptr, (uint32_t*)(a + 2 * volBytes));   // border mask only
-    return launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, a, nullptr);
+    const bool mask = jfa_can_start_from_mask(fr, algo) && f->n / 2 > 1;
+    ctx->jfa_started.valid = false;
+    if (mask) VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, nullptr, (uint32_t*)(a + 2 * volBytes)));   // border mask only
+    else      VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, a, nullptr));
+    ctx->jfa_started = {true, mask, f->n, algo, d_work, d_words};
+    return 0;
 }
 
 int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset, float* d_sdf,
@@ -366,6 +396,13 @@ int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fi
     char* a = (char*)d_work;
     char* b = a + volBytes;
     uint32_t k = f->n / 2;                                         // jfa/sequential.cpp:72
+    // The workspace must hold what THIS sequence starts from: the record of the matching vp_jfa_start (same grid, frame size,
+    // algo and workspace).  One start serves one run: the passes overwrite the volumes.
+    const bool wantMask = jfa_can_start_from_mask(fr, algo) && k > 1;
+    const vp_ctx::JfaStarted st = ctx->jfa_started;
+    ctx->jfa_started.valid = false;
+    if (!st.valid || st.n != f->n || st.algo != algo || st.work != d_work || st.words != d_words || st.mask != wantMask)
+        return set_error(VP_ERR_INVALID, "vp_jfa_run: call vp_jfa_start with the same grid, frame, algo and workspace first");
     if (jfa_can_fuse_first_two(fr, algo)) {
         VP_TRY(launch_jfa_first_two(ctx, fr, (const uint32_t*)(b + volBytes), a));    // passes n/2 and n/4 straight from the border mask
         k /= 4;

@@ -187,6 +187,63 @@ jfa_init(Frame f, const uint32_t* __restrict__ words, const uint32_t* __restrict
     }
 }
 
+// Border mask alone (vp_surface, the "::Initialization" half of vp_jfa), rows of a power-of-two number of words >= 4.
+// A lane owns one word column (xw, y) and MARCHES along z over `zc` planes.  Per plane it forms
+//     H(z) = AND over the rows y-1, y, y+1 of (left & word & right)            -- the 3 x 3 in-plane part of the 26-neighbourhood
+// from three word loads (the left / right words come from the neighbouring lanes: v_mov_b32_dpp wave_shr / wave_shl, a VALU
+// move instead of the ds_bpermute of __shfl), keeps the H of three consecutive planes in registers, and
+//     border(z) = word(z) & ~(H(z-1) & H(z) & H(z+1))                            (sequential.cpp:28-55).
+// 3 (zc + 2) / zc word loads and 6 lane moves per output word where jfa_init needs 9 and 18, and zc times fewer, longer
+// workgroups (jfa_init at n = 1024: 131,072 workgroups of 256 words, 0.23 ms for 2 x 128 MiB = 1.1 TB/s).
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }   // lane i <- lane i-1
+__device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }   // lane i <- lane i+1
+
+__global__ void __launch_bounds__(256)
+jfa_border_march(Frame f, const uint32_t* __restrict__ words, const uint32_t* __restrict__ below,
+                 const uint32_t* __restrict__ above, uint32_t* __restrict__ border_words, uint32_t zc)
+{
+    const int W = (int)f.w, N = (int)f.n;
+    const uint32_t wi = blockIdx.x * 256u + threadIdx.x;           // word index inside a plane (n w is a multiple of 256)
+    const int xw = (int)(wi & (uint32_t)(W - 1));
+    const int y = (int)(wi / (uint32_t)W);
+    const int zfirst = (int)f.z0 + (int)(blockIdx.y * zc);
+    const int zlast = min(zfirst + (int)zc, (int)f.z1);           // exclusive
+    const size_t planeWords = (size_t)N * W;
+    const bool xlo = xw == 0, xhi = xw == W - 1;
+    // in-plane part of plane zg; `centre` receives the lane's own word
+    auto inplane = [&](int zg, uint32_t& centre) -> uint32_t {
+        uint32_t r[3];
+        if (zg < 0 || zg >= N) { centre = 0u; return 0u; }         // outside the grid counts as unset (sequential.cpp:46-51); wave-uniform
+        const uint32_t* pl = zg < (int)f.z0 ? (zg == (int)f.z0 - 1 ? below : nullptr)
+                           : zg >= (int)f.z1 ? (zg == (int)f.z1 ? above : nullptr)
+                           : words + (size_t)(zg - (int)f.z0) * planeWords;
+        if (pl == nullptr) { centre = 0u; return 0u; }              // a halo plane the caller did not give: as outside
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            r[dy + 1] = (yy >= 0 && yy < N) ? pl[(size_t)yy * W + xw] : 0u;
+        }
+        centre = r[1];
+        uint32_t h = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            uint32_t p = lane_prev(r[j]), n = lane_next(r[j]);
+            if (xlo) p = 0u;
+            if (xhi) n = 0u;
+            h &= ((r[j] << 1) | (p >> 31)) & r[j] & ((r[j] >> 1) | (n << 31));
+        }
+        return h;
+    };
+    uint32_t cPrev, cCur, cNext;
+    uint32_t hPrev = inplane(zfirst - 1, cPrev);
+    uint32_t hCur = inplane(zfirst, cCur);
+    for (int zg = zfirst; zg < zlast; ++zg) {
+        const uint32_t hNext = inplane(zg + 1, cNext);
+        border_words[(size_t)(zg - (int)f.z0) * planeWords + wi] = cCur & ~(hPrev & hCur & hNext);
+        hPrev = hCur; hCur = hNext; cCur = cNext;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ pass
 // Plane of global z `zg` among the three id buffers of a slab (see vphip.h, vp_jfa_pass).
 template <class T>
@@ -913,22 +970,35 @@ __device__ __forceinline__ void lds_span(const char* base, uint32_t off, int lo,
 #define VP_FINAL_GLOBAL_MASK 2      // 0: LDS, 1: global, 2: global with the 4-KB tables only
 #endif
 template <class ID> constexpr bool final_mask_global() { return VP_FINAL_GLOBAL_MASK == 1 || (VP_FINAL_GLOBAL_MASK == 2 && ID::kTab > 512); }
+// 8-byte ids (n <= 2048, round 3): the same kernel with
+//   * ranks relative to the tile: (index of the source row among the tile's (CH + 2) x (RY + 2) source rows) << 11 | x, + 1 -- the byte
+//     offset of a source voxel no longer fits 32 bits (the volume is 64 GiB); a 60-entry LDS table turns the row index of the winner
+//     back into its row number for the gather;
+//   * 8-KB tables: PX and the squared y differences per output row (TY) as before, but ONE table of seed z POSITIONS instead of CH
+//     tables of squared z differences -- (sz - pz)^2 is formed per id and output plane (2 VALU each) -- so that the footprint is
+//     48 KB and three 512-thread workgroups share a CU; "none" (all ones: its fields are real coordinates at n = 2048) gets an
+//     infinite seed x by an explicit test, once per id.
+template <class ID> constexpr bool dense_wide() { return std::is_same<ID, Id64>::value; }
 template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP>
-__global__ void __launch_bounds__(NT, (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (ID::kTab == 512 || NT == 512) ? 6 : 4)
-jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-               const uint32_t* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf,
+__global__ void __launch_bounds__(NT, dense_wide<ID>() ? 4 : RY > 4 ? 4 : (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (ID::kTab == 512 || NT == 512) ? 6 : 4)
+jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typename ID::T* __restrict__ out,
+               const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf,
                uint32_t tilesY, uint32_t tiles, uint32_t splitTiles)
 {
-    using T = uint32_t;
+    using T = typename ID::T;
+    constexpr bool WIDE = dense_wide<ID>();
+    constexpr uint32_t IDB = (uint32_t)sizeof(T);
     constexpr int TAB = ID::kTab;
-    constexpr int PXT = TAB + 1;                                   // slot TAB = the x index of "none" = +inf
+    constexpr int PXT = WIDE ? TAB : TAB + 1;                      // 32-bit ids: slot TAB = the x index of "none" = +inf
     constexpr int EY = 1, EZ = 1;                                  // floats per table entry (wider entries: measured slower)
     constexpr int NR = RY + 2;
     constexpr int NI = NR * 3;
+    constexpr int CHT = WIDE ? 1 : CH;                             // z tables: squared differences per output plane / one table of positions
     using B = typename std::conditional<FINAL, float, double>::type;
     __shared__ float PX[PXT];
     __shared__ __attribute__((aligned(16))) float TY[RY / EY][TAB][EY];
-    __shared__ __attribute__((aligned(16))) float TZ[CH / EZ][TAB][EZ];
+    __shared__ __attribute__((aligned(16))) float TZ[CHT / EZ][TAB][EZ];
+    __shared__ uint32_t RB[WIDE ? (CH + 2) * NR : 1];              // WIDE: row number (inside the id buffer) of every source row of the tile
     constexpr bool GM = final_mask_global<ID>();
     __shared__ uint32_t WM[(FINAL && !GM) ? RY * CH * (TAB / 32) : 1];
 
@@ -974,13 +1044,24 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
             const float sy = axis_pos(f.oy, i, f.vs), sz = axis_pos(f.oz, i, f.vs);
 #pragma unroll
             for (int j = 0; j < RY; ++j) { const float d = sy - py[j]; TY[j / EY][si][j % EY] = d * d; }
+            if (WIDE) TZ[0][si][0] = sz;
+            else {
 #pragma unroll
-            for (int j = 0; j < CH; ++j) { const float d = sz - pz[j]; TZ[j / EZ][si][j % EZ] = d * d; }
+                for (int j = 0; j < CHT; ++j) { const float d = sz - pz[j]; TZ[j / EZ][si][j % EZ] = d * d; }
+            }
         } else {                                                   // slots no real id refers to ("none" does: TAB - 1); finite: inf + it = inf
 #pragma unroll
             for (int j = 0; j < RY; ++j) TY[j / EY][i][j % EY] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < CH; ++j) TZ[j / EZ][i][j % EZ] = 0.0f;
+            for (int j = 0; j < CHT; ++j) TZ[j / EZ][i][j % EZ] = 0.0f;
+        }
+    }
+    if (WIDE) {
+        // row numbers of the tile's source rows: entry pj * NR + rr = plane zbase + (pj - 1) k, row ybase + (rr - 1) k (0 where outside)
+        for (uint32_t i = tid; i < (uint32_t)((CH + 2) * NR); i += NT) {
+            const int zg = zbase + ((int)(i / NR) - 1) * K, yy = ybase + ((int)(i % NR) - 1) * K;
+            const bool ok = zg >= (int)f.z0 - K && zg < (int)f.z1 + K && zg >= 0 && zg < N && yy >= 0 && yy < N;
+            RB[i] = ok ? (uint32_t)((zg - (int)f.z0) * N + yy) : 0u;   // negative for the minus halo planes of a slab: read back as int
         }
     }
     if (FINAL && !GM) {
@@ -995,16 +1076,16 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
     const char* tx = reinterpret_cast<const char*>(PX);
     const char* ty = reinterpret_cast<const char*>(TY);
     const char* tz = reinterpret_cast<const char*>(TZ);
-    const uint32_t rowBytes = (uint32_t)N * 4u;
+    const uint32_t rowBytes = (uint32_t)N * IDB;
     const size_t planeBytes = (size_t)N * rowBytes;
     int yout = 1, nout = 1;
 #pragma unroll
     for (int j = 1; j < RY; ++j) yout += (ybase + j * K < N) ? 1 : 0;
 #pragma unroll
     for (int j = 1; j < CH; ++j) nout += (zbase + j * K < (int)f.z1) ? 1 : 0;
-    const uint32_t kb = k * 4u;
-    // Ranks and the gather are relative to the first source plane of the tile that lies in the grid (zlo below): at most
-    // the whole volume, 4 GiB at n = 1024, so byte offset + 1 <= 2^32 - 3 fits the low word.
+    const uint32_t kb = k * IDB;
+    // 32-bit ids: ranks and the gather are relative to the first source plane of the tile that lies in the grid (zlo below): at
+    // most the whole volume, 4 GiB at n = 1024, so byte offset + 1 <= 2^32 - 3 fits the low word.  8-byte ids: see the header.
 
     const int zbase0 = zbase, lbase0 = lbase, ybase0 = ybase;
     const uint32_t xiters = ((uint32_t)N + NT - 1) / NT, xper = (xiters + xparts - 1) / xparts * NT;
@@ -1027,7 +1108,9 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
         }
         const float px = PX[x];
         const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
-        const uint32_t xo = x * 4u, xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;   // a column outside the grid reads the centre column
+        const uint32_t xo = x * IDB, xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;   // a column outside the grid reads the centre column
+        // WIDE: rank of a candidate = (source row index << 11 | x of the column it was read from) + 1
+        const uint32_t xr[3] = {(hasM ? x - k : x) + 1u, x + 1u, (hasP ? x + k : x) + 1u};
 
         // SKIP (wide passes, k >= n/4: half of the neighbour rows / planes / columns lie outside the grid): a source row that
         // does not exist is neither loaded nor evaluated (wave-uniform branch), and neither is a column x-k / x+k that no lane
@@ -1061,14 +1144,21 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
         struct Dec { float sx; float dy2[RY]; float dz2[CH]; };
         auto lookup = [&](int P, int rr, T id, Dec& d) {
             const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
-            d.sx = lds_f32(tx + ID::xoff(id));                              // "none": slot TAB = +inf
+            d.sx = lds_f32(tx + ID::xoff(id));                              // 32-bit ids: "none" reads slot TAB = +inf
+            if constexpr (WIDE) d.sx = ID::is_none(id) ? INFINITY : d.sx;   // (inf - px)^2 = inf: "none" loses every '<'
             const uint32_t yo = ID::yoff(id), zo = ID::zoff(id);
 #if defined(VP_ABL_NOLDS)
             for (int a = 0; a < RY; ++a) d.dy2[a] = __uint_as_float(yo + a);
             for (int o = 0; o < CH; ++o) d.dz2[o] = __uint_as_float(zo + o);
 #else
             lds_span<RY, EY, TAB>(ty, yo, alo, ahi, d.dy2);
-            lds_span<CH, EZ, TAB>(tz, zo, olo, ohi, d.dz2);
+            if constexpr (WIDE) {
+                const float sz = lds_f32(tz + zo);                          // seed z position; the squares per output plane are formed here
+#pragma unroll
+                for (int o = olo; o <= ohi; ++o) { const float dzv = sz - pz[o]; d.dz2[o] = dzv * dzv; }
+            } else {
+                lds_span<CH, EZ, TAB>(tz, zo, olo, ohi, d.dz2);
+            }
 #endif
         };
 #ifndef VP_FINAL_MIN3
@@ -1080,7 +1170,7 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
             const float dxv = d.sx - px;
             const float dx2 = dxv * dxv;
             u32x2 cand;
-            if (!FINAL) cand.x = prank + ro[rr] + (c == 0 ? xmo : c == 1 ? xo : xpo);
+            if (!FINAL) cand.x = WIDE ? (uint32_t)(((P + 1) * NR + rr) << 11) + xr[c] : prank + ro[rr] + (c == 0 ? xmo : c == 1 ? xo : xpo);
 #pragma unroll
             for (int a = alo; a <= ahi; ++a) {
                 const float pre = dx2 + d.dy2[a];
@@ -1108,11 +1198,12 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
             }
         };
 #ifndef VP_DENSE_PIPE
-#define VP_DENSE_PIPE (ID::kTab == 512)      // measured (tools/ab_step.py): -1.3 % at n = 512, +0.8 % at n = 1024
+#define VP_DENSE_PIPE (ID::kTab == 512 || (FINAL && !WIDE))      // measured (tools/ab_step.py): -1.3 % at n = 512, +0.8 % at n = 1024 (dense); FINAL at n = 1024: see DEPTH
 #endif
         auto scatter = [&](int P, T (&w)[NI]) {
             // rank of the ids of this plane: byte offset of the row inside the gather window + 1 (wave-uniform) + the column offset
-            const uint32_t prank = (uint32_t)((zbase + P * K - zlo) * (ptrdiff_t)planeBytes) + 1u;
+            // (WIDE: (source row index << 11) + x + 1, the row part added per row in steps() through the unrolled constant below)
+            const uint32_t prank = WIDE ? 0u : (uint32_t)((zbase + P * K - zlo) * (ptrdiff_t)planeBytes) + 1u;
             const int olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
             const bool curOk = P <= nout && zbase + P * K >= 0 && zbase + P * K < N;      // SKIP: does this source plane exist
             Plane next{nullptr, false};
@@ -1121,14 +1212,21 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
                 // Software pipeline over the 18 ids of the plane: the table lookups of id j + 1 are issued BEFORE the candidate
                 // steps of id j (the scheduling barriers keep the compiler from sinking them back to their first use), so a wave
                 // waits for LDS data a whole id of VALU work after asking for it instead of immediately.
-                Dec d[2];
-                lookup(P, 0, w[0], d[0]);
+#ifndef VP_DENSE_PIPE_DEPTH
+                // ids looked up ahead of the one being evaluated.  Two ahead (profiles/r03/ab_pipe_*.txt): fused last pass at n = 1024
+                // 3.23 -> 3.05 ms (-6 %), at n = 512 +-0; dense passes +1 % (n = 512) and +24 % (n = 1024: 7 more VGPRs cost a workgroup per CU)
+#define VP_DENSE_PIPE_DEPTH ((FINAL && ID::kTab == 1024) ? 2 : 1)
+#endif
+                constexpr int DEPTH = VP_DENSE_PIPE_DEPTH;
+                Dec d[DEPTH + 1];
+#pragma unroll
+                for (int j = 0; j < DEPTH && j < NI; ++j) lookup(P, j / 3, w[j], d[j]);
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     const int rr = j / 3, c = j % 3;
-                    if (j + 1 < NI) lookup(P, (j + 1) / 3, w[j + 1], d[(j + 1) & 1]);
+                    if (j + DEPTH < NI) lookup(P, (j + DEPTH) / 3, w[j + DEPTH], d[(j + DEPTH) % (DEPTH + 1)]);
                     __builtin_amdgcn_sched_barrier(0);
-                    steps(P, rr, c, d[j & 1], prank);
+                    steps(P, rr, c, d[j % (DEPTH + 1)], prank);
                     if (c == 2) {
                         const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1);
 #pragma unroll
@@ -1209,7 +1307,7 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
                         if (a >= yout) continue;
                         const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (P - 1) * K) * N + (ybase + a * K);
                         const bool set = ((GM ? mw[a] : WM[(a * CH + (P - 1)) * (TAB / 32) + (x >> 5)]) >> (x & 31)) & 1u;
-                        row_store(set ? best[a][P - 1] : copysignf(best[a][P - 1], fill), row_resource(sdf + rowIdx * N, rowBytes), xo);
+                        row_store(set ? best[a][P - 1] : copysignf(best[a][P - 1], fill), row_resource(sdf + rowIdx * N, (uint32_t)N * 4u), x * 4u);
                     }
                 }
             } else {
@@ -1227,13 +1325,20 @@ jfa_pass_dense(Frame f, uint32_t k, const uint32_t* __restrict__ in, uint32_t* _
                     for (int a = 0; a < RY; ++a) {
                         if (a >= yout) continue;
                         const uint32_t lo = __builtin_bit_cast(u32x2, best[a][P - 1]).x;
-                        const uint32_t ownOff = orank + ro[a + 1] + xo;
-                        const uint32_t off = lo ? lo - 1u : ownOff;
+                        if constexpr (WIDE) {
+                            // rank - 1 = source row index << 11 | x; the own voxel (rank 0) sits in row (P, a + 1) of the tile's source rows
+                            const uint32_t r = lo ? lo - 1u : (uint32_t)((P * NR + a + 1) << 11) + x;
+                            const ptrdiff_t row = (ptrdiff_t)(int)RB[r >> 11];
+                            pend[a] = in[row * N + (ptrdiff_t)(r & 2047u)];
+                        } else {
+                            const uint32_t ownOff = orank + ro[a + 1] + xo;
+                            const uint32_t off = lo ? lo - 1u : ownOff;
 #if defined(VP_ABL_NOGATHER)
-                        pend[a] = off;
+                            pend[a] = T(off);
 #else
-                        pend[a] = *reinterpret_cast<const T*>(gbase + off);
+                            pend[a] = *reinterpret_cast<const T*>(gbase + off);
 #endif
+                        }
                     }
                 }
             }
@@ -1390,6 +1495,10 @@ jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 // id volume is written once.  Stage A scatters the border voxels (0.7 % on the headline mesh) two positions along each axis, which
 // leaves every voxel with the slot of its pass-1 seed (or none); stage B scatters the voxels that have one (5 %) one position
 // along each axis with that seed's coordinates.  Keys and ranks as in jfa_pass_seeds; a seed's coordinates are those of its slot.
+// Measured and dropped (round 3, profiles/r03/ab_step_512.txt): a PERSISTENT form of this kernel -- 8 workgroups per CU walking the
+// tile sequence, the next tile's mask words requested a tile ahead -- ran 0.493 ms against 0.404 (n = 512) and 3.44 against 2.92
+// (n = 1024).  The launch already keeps 7.5 of 8 wave slots per SIMD occupied (SQ_WAVE_CYCLES is in quad-cycles), so there was no
+// dispatch gap to close, and workgroups that start together walk their five stages in step and meet at the LDS.
 template <class ID, int XR, int NT>
 __global__ void __launch_bounds__(NT)
 jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out)
@@ -1537,12 +1646,28 @@ inline bool wide(const Frame& f) { return f.n > 1024; }           // 64-bit ids
 size_t jfa_id_bytes(const Frame& f) { return wide(f) ? 8 : 4; }
 
 // ---------------------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* below,
                     const uint32_t* above, void* d_ids, uint32_t* d_border_words)
 {
     const size_t nwords = (size_t)f.n * f.n * (f.z1 - f.z0) / 32;
     const unsigned blocks = (unsigned)(nwords / 256);             // nwords is a multiple of 256
     ProfScope p(ctx, d_ids ? VP_K_JFA_INIT : VP_K_SURFACE);
+    static const int march = env_int("VP_BORDER_MARCH", 1);       // dev switch: 0 = jfa_init for the mask as well
+    if (!d_ids && d_border_words && march && f.w >= 4 && (f.w & (f.w - 1)) == 0) {
+        // border mask alone: lanes march along z (jfa_border_march); chunks of zc planes, short enough to fill the chip
+        const uint32_t inPlane = f.n * f.w / 256u, nz = f.z1 - f.z0;
+        uint32_t zc = 32;
+        while (zc > 4 && inPlane * ((nz + zc - 1) / zc) < 8u * (uint32_t)ctx->cus) zc /= 2;
+        hipLaunchKernelGGL(jfa_border_march, dim3(inPlane, (nz + zc - 1) / zc), dim3(256), 0, ctx->stream, f, d_words, below, above, d_border_words, zc);
+        VP_HIP(hipGetLastError());
+        return 0;
+    }
 #define VP_INIT(ID, I, M) hipLaunchKernelGGL((jfa_init<ID, I, M>), dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, below, above, \
                                              (typename ID::T*)d_ids, d_border_words)
     if (wide(f)) {
@@ -1560,12 +1685,6 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, c
                     const void* d_plus, void* d_out, int algo)
 {
     return launch_jfa_pass_ex(ctx, f, k, d_in, d_minus, d_plus, d_out, algo, nullptr, 0.0f, nullptr);
-}
-
-static int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
 }
 
 bool jfa_can_start_from_mask(const Frame& f, int algo) { return algo == VP_ALGO_TILED && f.n >= 256 && f.n % 128 == 0; }
@@ -1691,8 +1810,9 @@ static bool dense_applies(const Frame& f, uint32_t k, const void* d_in, const vo
 {
     if (fin && !VP_JFA_DENSE_FINAL) return false;
     static const int enabled = env_int("VP_JFA_DENSE", VP_JFA_DENSE_DEFAULT);         // dev switch: 0 = round-1 kernel for every pass
-    if (!enabled || wide(f) || (k * 4 >= f.n && !VP_JFA_DENSE_WIDEK)) return false;
-    const size_t plane = (size_t)f.n * f.n * 4;
+    static const int wideOn = env_int("VP_JFA_DENSE_WIDE", 1);                          // dev switch: 0 = round-1 kernel for 8-byte ids
+    if (!enabled || (wide(f) && !wideOn) || (k * 4 >= f.n && !VP_JFA_DENSE_WIDEK)) return false;
+    const size_t plane = (size_t)f.n * f.n * jfa_id_bytes(f);
     const char* in = (const char*)d_in;
     if (f.z0 > 0 && (const char*)d_minus + (size_t)k * plane != in) return false;      // the three id buffers must be one volume
     const uint32_t pbase = std::max(f.z1, f.z0 + k);
@@ -1728,26 +1848,32 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 {
     const uint32_t nz = f.z1 - f.z0;
     VP_TRY(ensure_none_rows(ctx));
-    const uint32_t* none_row = none_row_of<ID>(ctx);
+    using T = typename ID::T;
+    const T* none_row = none_row_of<ID>(ctx);
     const bool fin = d_sdf != nullptr;
     const bool wideK = k * 4 >= f.n;                               // half of the neighbour rows / planes are outside the grid: SKIP variant
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k;
     const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
     // Tile 4 rows x 8 planes when the plane chains divide by 8, else 4 x 4.  2-KB tables (n <= 512): 256 threads, 26 KB of LDS,
     // six workgroups per CU.  4-KB tables: the 4 x 8 tile takes 52 KB, shared by the 8 waves of a 512-thread workgroup (three per CU).
+#ifndef VP_DENSE_RY
+#define VP_DENSE_RY 4             // output rows per tile (dev: 8 = 4.7 decoded ids per voxel instead of 5.6, 109 VGPRs, four waves per SIMD)
+#endif
 #define VP_LAUNCH_DENSE(CH, NT, F, S)                                                                                              \
     do {                                                                                                                           \
-        const uint32_t ty_ = nresY * ((ylen + 3) / 4), t_ = ty_ * nres * ((zlen + CH - 1) / CH);                                   \
+        const uint32_t ty_ = nresY * ((ylen + VP_DENSE_RY - 1) / VP_DENSE_RY), t_ = ty_ * nres * ((zlen + CH - 1) / CH);           \
         /* a row of <= NT voxels has no halves */                                                                                  \
-        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, ID::kTab == 512 ? ((F) && !final_mask_global<ID>() ? 5u : 6u) : NT == 512 ? ((F) && !final_mask_global<ID>() ? 2u : 3u) : 4u) : 0u;                      \
-        hipLaunchKernelGGL((jfa_pass_dense<ID, 4, CH, NT, F, true, S>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,            \
-                           (const uint32_t*)d_in, (uint32_t*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                 \
+        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, dense_wide<ID>() ? 2u : ID::kTab == 512 ? ((F) && !final_mask_global<ID>() ? 5u : 6u) : NT == 512 ? ((F) && !final_mask_global<ID>() ? 2u : 3u) : 4u) : 0u;                      \
+        hipLaunchKernelGGL((jfa_pass_dense<ID, VP_DENSE_RY, CH, NT, F, true, S>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,            \
+                           (const T*)d_in, (T*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                               \
     } while (0)
 #define VP_DENSE_F(CH, NT) do { if (fin) VP_LAUNCH_DENSE(CH, NT, (VP_JFA_DENSE_FINAL != 0), false);                                \
                                 else if (wideK) VP_LAUNCH_DENSE(CH, NT, false, (VP_JFA_DENSE_WIDEK != 0));                          \
                                 else VP_LAUNCH_DENSE(CH, NT, false, false); } while (0)
     const bool deep = zlen % 8 == 0;
-    if constexpr (ID::kTab == 512) { if (deep) VP_DENSE_F(8, 256); else VP_DENSE_F(4, 256); }
+    // 8-byte ids: 8-KB tables (PX + 4 x TY + one z position table = 48 KB), 512 threads
+    if constexpr (dense_wide<ID>()) { if (deep) VP_DENSE_F(8, 512); else VP_DENSE_F(4, 512); }
+    else if constexpr (ID::kTab == 512) { if (deep) VP_DENSE_F(8, 256); else VP_DENSE_F(4, 256); }
     else                           { if (deep) VP_DENSE_F(8, 512); else VP_DENSE_F(4, 256); }
 #undef VP_DENSE_F
 #undef VP_LAUNCH_DENSE
@@ -1787,8 +1913,9 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
         else if (f.n <= 512) hipLaunchKernelGGL((jfa_pass_seeds<Id9, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
         else                 hipLaunchKernelGGL((jfa_pass_seeds<Id10, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
     } else if (f.n >= 256 && dense_applies(f, k, d_in, d_minus, d_plus, d_sdf != nullptr)) {
-        if (f.n <= 512) VP_TRY(launch_dense<Id9>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
-        else            VP_TRY(launch_dense<Id10>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        if (wide(f))         VP_TRY(launch_dense<Id64>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        else if (f.n <= 512) VP_TRY(launch_dense<Id9>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        else                 VP_TRY(launch_dense<Id10>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
     } else if (f.n >= 256) {
         if (wide(f)) VP_TRY(launch_chain<Id64>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
         else if (f.n <= 512) VP_TRY(launch_chain<Id9>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));

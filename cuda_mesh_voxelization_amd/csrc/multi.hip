@@ -1,0 +1,456 @@
+// multi.hip -- vp_multi_*: one process driving several GPUs of a node, the grid cut into Z-slabs (include/vphip.h).
+//
+// The reference is single-GPU: apps/cli/main.cpp:22-23 pins device 0 and every Compute() uses it.  This file is what replaces
+// that line when more than one device is given: one vp_ctx (stream + workspace) per device, rank r owns the planes
+// [r n/G, (r+1) n/G) of every buffer, and the stages are the C-ABI stages of a slab frame (vp_frame.z0 / z1):
+//
+//   voxelize   every (y, z) column is independent (vox/sequential.cpp:40-57): each device rasterises the mesh into its slab.
+//   CSG        word-wise: each device combines its slabs.
+//   JFA        VP_MULTI_HALO   init needs one bitmask plane from each Z-neighbour; the pass with step k needs the id planes
+//                              [z0-k, min(z0, z1-k)) and [max(z1, z0+k), z1+k) from whoever owns them.  They are moved with
+//                              hipMemcpyPeerAsync on the RECEIVER's stream behind an event of the sender's stream, and every
+//                              stream waits for the copies that read its buffers before it overwrites them two passes later:
+//                              the whole JFA is enqueued without a host synchronisation.  Halos of the narrow passes
+//                              (k <= nz/2) land directly below / above the slab inside one allocation, so those passes see
+//                              one contiguous volume (the dense tile kernel applies).
+//                  VP_MULTI_GHOST  no exchange between passes: the bitmask slabs are all-gathered once (n^3/8 bytes), every
+//                              device runs pass i on its slab widened by the reach of the later passes and the regions shrink
+//                              to the bare slab at k = 1.  Costs two full id volumes per device.
+//
+// Every stage is a pure function of the previous buffers, so the concatenated slabs are bit-identical to the single-device
+// result for any number of devices -- including several contexts on ONE device, which is how the tests run it.
+// Host code only; compiled with the kernels because it uses the context internals (stream, device).
+#include "vp_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+using namespace vp;
+
+namespace {
+
+struct Rank {
+    vp_ctx* ctx = nullptr;
+    int device = 0;
+    uint32_t z0 = 0, z1 = 0;
+    // resident buffers (grow-only)
+    Buffer mesh_xyz, mesh_tri;
+    Buffer words;                              // bitmask of the slab (halo) / of the whole grid (ghost, after the all-gather)
+    Buffer other;                              // second operand of a CSG
+    Buffer below, above;                       // bitmask planes z0-1 / z1
+    Buffer ids[2];                             // halo: [H | nz | H] planes each; ghost: whole volumes
+    Buffer minus, plus;                        // halo: whole slabs of distant ranks (wide passes)
+    Buffer border;                             // ghost: border mask of the whole grid
+    Buffer sdf;                                // slab
+    hipEvent_t ready = nullptr;                // "my buffers hold what the peers may read"
+    hipEvent_t copied = nullptr;               // "the copies INTO my buffers of this step are done"
+};
+
+}  // namespace
+
+struct vp_multi {
+    std::vector<Rank> ranks;
+    vp_frame frame{};                          // global frame of the resident grid
+    bool have_grid = false, have_sdf = false;
+    size_t nverts = 0, ntris = 0;
+    uint64_t bytes_moved = 0;                  // device-to-device bytes of the last vp_multi_jfa
+    int last_mode = -1;
+};
+
+namespace {
+
+int bind(const Rank& r)
+{
+    VP_HIP(hipSetDevice(r.device));
+    return 0;
+}
+
+int grow(Rank& r, Buffer& b, size_t bytes)
+{
+    VP_TRY(bind(r));
+    return reserve(r.ctx, b, bytes ? bytes : 1);
+}
+
+vp_frame slab_frame(const vp_frame& g, uint32_t z0, uint32_t z1)
+{
+    vp_frame f = g;
+    f.z0 = z0; f.z1 = z1;
+    return f;
+}
+
+int check_split(const vp_multi* m, const vp_frame* f, const char* who)
+{
+    if (!m || !f) return set_error(VP_ERR_INVALID, "%s: null argument", who);
+    const uint32_t g = (uint32_t)m->ranks.size();
+    if (f->n < 32 || f->n > 2048 || f->n % 32 != 0) return set_error(VP_ERR_UNSUPPORTED, "%s: n=%u unsupported (need 32 <= n <= 2048, n %% 32 == 0)", who, f->n);
+    if (f->z0 != 0 || f->z1 != f->n) return set_error(VP_ERR_INVALID, "%s: whole-grid frame required", who);
+    if (f->n % g != 0 || (f->n / g) % 8 != 0)
+        return set_error(VP_ERR_INVALID, "%s: n=%u cannot be cut into %u Z-slabs of a multiple of 8 planes", who, f->n, g);
+    return 0;
+}
+
+void assign_slabs(vp_multi* m, const vp_frame* f)
+{
+    const uint32_t g = (uint32_t)m->ranks.size(), nz = f->n / g;
+    for (uint32_t r = 0; r < g; ++r) { m->ranks[r].z0 = r * nz; m->ranks[r].z1 = (r + 1) * nz; }
+    m->frame = *f;
+}
+
+// dst's stream waits for src's `ready` event, then copies.  (hipMemcpyPeerAsync between two contexts of one device is an
+// ordinary device-to-device copy.)
+int peer_copy(vp_multi* m, Rank& dst, void* d_dst, const Rank& src, const void* d_src, size_t bytes)
+{
+    if (!bytes) return 0;
+    VP_TRY(bind(dst));
+    VP_HIP(hipStreamWaitEvent(dst.ctx->stream, src.ready, 0));
+    if (dst.device == src.device) VP_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dst.ctx->stream));
+    else VP_HIP(hipMemcpyPeerAsync(d_dst, dst.device, d_src, src.device, bytes, dst.ctx->stream));
+    m->bytes_moved += bytes;
+    return 0;
+}
+
+int mark_ready(Rank& r)
+{
+    VP_TRY(bind(r));
+    VP_HIP(hipEventRecord(r.ready, r.ctx->stream));
+    return 0;
+}
+
+// After the copies of a step: every receiver records `copied`; every stream waits for all of them before it goes on (its next
+// kernels may overwrite what a peer has just read -- the ping-pong volume written by the pass after this one).
+int fence_copies(vp_multi* m)
+{
+    for (Rank& r : m->ranks) { VP_TRY(bind(r)); VP_HIP(hipEventRecord(r.copied, r.ctx->stream)); }
+    for (Rank& r : m->ranks) {
+        VP_TRY(bind(r));
+        for (Rank& o : m->ranks) if (&o != &r) VP_HIP(hipStreamWaitEvent(r.ctx->stream, o.copied, 0));
+    }
+    return 0;
+}
+
+// Every rank keeps its slab at its GLOBAL position inside a buffer of the whole grid (n^3/8 bytes, small next to the id
+// volumes): the halo mode uses the slab alone, the ghost mode fills in the rest.
+char* slab_words(const vp_multi* m, const Rank& r)
+{
+    return (char*)r.words.ptr + (size_t)r.z0 * ((size_t)m->frame.n * m->frame.n / 8);
+}
+
+struct HaloMove { uint32_t src, dst; bool minusSide; uint32_t g0, g1; };
+
+// For step k: dst needs the global planes [g0, g1) owned by src for its minus / plus buffer (one entry per owner).
+std::vector<HaloMove> halo_plan(uint32_t n, uint32_t world, uint32_t k)
+{
+    const uint32_t nz = n / world;
+    std::vector<HaloMove> plan;
+    for (uint32_t dst = 0; dst < world; ++dst) {
+        const int64_t z0 = (int64_t)dst * nz, z1 = z0 + nz;
+        const int64_t lo[2] = {std::max<int64_t>(z0 - k, 0), std::max<int64_t>(z1, z0 + k)};
+        const int64_t hi[2] = {std::min<int64_t>(z0, z1 - (int64_t)k), std::min<int64_t>(z1 + k, n)};
+        for (int side = 0; side < 2; ++side)
+            for (int64_t g = lo[side]; g < hi[side];) {
+                const uint32_t src = (uint32_t)(g / nz);
+                const int64_t e = std::min<int64_t>(hi[side], (int64_t)(src + 1) * nz);
+                plan.push_back({src, dst, side == 0, (uint32_t)g, (uint32_t)e});
+                g = e;
+            }
+    }
+    return plan;
+}
+
+struct Region { uint32_t k, b0, b1; };
+
+// Planes each pass must produce on a rank so that no exchange is needed: the slab widened by the sum of the later steps,
+// rounded outwards to the 8-plane tile and clipped to the grid.
+std::vector<Region> ghost_regions(uint32_t n, uint32_t z0, uint32_t z1)
+{
+    std::vector<uint32_t> ks;
+    for (uint32_t k = n / 2; k >= 1; k /= 2) ks.push_back(k);
+    std::vector<Region> out;
+    for (size_t i = 0; i < ks.size(); ++i) {
+        uint32_t g = 0;
+        for (size_t j = i + 1; j < ks.size(); ++j) g += ks[j];
+        const uint32_t b0 = z0 > g ? (z0 - g) / 8 * 8 : 0;
+        const uint32_t b1 = std::min(n, (z1 + g + 7) / 8 * 8);
+        out.push_back({ks[i], b0, b1});
+    }
+    return out;
+}
+
+int jfa_halo(vp_multi* m, float fill, int algo)
+{
+    const vp_frame& G = m->frame;
+    const uint32_t n = G.n, world = (uint32_t)m->ranks.size(), nz = n / world;
+    const size_t S = vp_jfa_id_bytes(&G), planeIds = (size_t)n * n * S, planeWords = (size_t)n * n / 8;   // bytes
+    const uint32_t H = world > 1 ? nz / 2 : 0;
+    for (Rank& r : m->ranks) {
+        for (Buffer& b : r.ids) VP_TRY(grow(r, b, (size_t)(nz + 2 * H) * planeIds));
+        VP_TRY(grow(r, r.sdf, (size_t)nz * n * n * 4));
+        if (world > 1) {
+            VP_TRY(grow(r, r.minus, (size_t)nz * planeIds)); VP_TRY(grow(r, r.plus, (size_t)nz * planeIds));
+            VP_TRY(grow(r, r.below, planeWords)); VP_TRY(grow(r, r.above, planeWords));
+        }
+    }
+    // bitmask planes for the 26-neighbourhood of the seeding (jfa/sequential.cpp:24-64)
+    for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
+    for (uint32_t r = 0; r < world; ++r) {
+        Rank& me = m->ranks[r];
+        if (r > 0) VP_TRY(peer_copy(m, me, me.below.ptr, m->ranks[r - 1], slab_words(m, m->ranks[r - 1]) + (size_t)(nz - 1) * planeWords, planeWords));
+        if (r + 1 < world) VP_TRY(peer_copy(m, me, me.above.ptr, m->ranks[r + 1], slab_words(m, m->ranks[r + 1]), planeWords));
+    }
+    if (world > 1) VP_TRY(fence_copies(m));
+    int cur = 0;
+    auto slab_ids = [&](Rank& r, int which) { return (char*)r.ids[which].ptr + (size_t)H * planeIds; };
+    for (uint32_t r = 0; r < world; ++r) {
+        Rank& me = m->ranks[r];
+        const vp_frame f = slab_frame(G, me.z0, me.z1);
+        VP_TRY(vp_jfa_init(me.ctx, &f, (const uint32_t*)slab_words(m, me), r > 0 ? (const uint32_t*)me.below.ptr : nullptr,
+                           r + 1 < world ? (const uint32_t*)me.above.ptr : nullptr, slab_ids(me, cur)));
+    }
+    for (uint32_t k = n / 2; k >= 1; k /= 2) {
+        const bool narrow = k <= H;
+        if (world > 1) {
+            for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
+            for (const HaloMove& h : halo_plan(n, world, k)) {
+                if (h.src == h.dst) continue;
+                Rank& dst = m->ranks[h.dst];
+                const Rank& src = m->ranks[h.src];
+                // where plane g of the receiver's minus / plus buffer lives (include/vphip.h, vp_jfa_pass)
+                const int64_t base = h.minusSide ? (int64_t)dst.z0 - k : std::max<int64_t>(dst.z1, (int64_t)dst.z0 + k);
+                char* buf = narrow ? (h.minusSide ? slab_ids(dst, cur) - (size_t)k * planeIds : slab_ids(dst, cur) + (size_t)nz * planeIds)
+                                   : (char*)(h.minusSide ? dst.minus.ptr : dst.plus.ptr);
+                VP_TRY(peer_copy(m, dst, buf + (size_t)(h.g0 - base) * planeIds, src,
+                                 (const char*)m->ranks[h.src].ids[cur].ptr + (size_t)(H + h.g0 - src.z0) * planeIds, (size_t)(h.g1 - h.g0) * planeIds));
+            }
+            VP_TRY(fence_copies(m));
+        }
+        for (uint32_t r = 0; r < world; ++r) {
+            Rank& me = m->ranks[r];
+            const vp_frame f = slab_frame(G, me.z0, me.z1);
+            const void* in = slab_ids(me, cur);
+            const void *mi = nullptr, *pl = nullptr;
+            if (world > 1) {
+                mi = narrow ? (const void*)((const char*)in - (size_t)k * planeIds) : me.minus.ptr;
+                pl = narrow ? (const void*)((const char*)in + (size_t)nz * planeIds) : me.plus.ptr;
+            }
+            if (k == 1) VP_TRY(vp_jfa_last_pass(me.ctx, &f, in, mi, pl, slab_ids(me, cur ^ 1), (const uint32_t*)slab_words(m, me), fill, (float*)me.sdf.ptr, algo));
+            else        VP_TRY(vp_jfa_pass(me.ctx, &f, k, in, mi, pl, slab_ids(me, cur ^ 1), algo));
+        }
+        cur ^= 1;
+    }
+    return 0;
+}
+
+int jfa_ghost(vp_multi* m, float fill, int algo)
+{
+    const vp_frame& G = m->frame;
+    const uint32_t n = G.n, world = (uint32_t)m->ranks.size(), nz = n / world;
+    const size_t S = vp_jfa_id_bytes(&G), planeIds = (size_t)n * n * S, planeWords = (size_t)n * n / 8;
+    const size_t slabWords = (size_t)nz * planeWords;
+    // all-gather of the bitmask slabs: every device ends up with the whole grid (its own slab stays where it is: plane z0)
+    for (Rank& r : m->ranks) {
+        VP_TRY(grow(r, r.border, (size_t)n * planeWords));
+        for (Buffer& b : r.ids) VP_TRY(grow(r, b, (size_t)n * planeIds));
+        VP_TRY(grow(r, r.sdf, (size_t)nz * n * n * 4));
+    }
+    // words buffers of the ghost mode hold the whole grid with the rank's own slab at its global position (see vp_multi_set_grid /
+    // vp_multi_voxelize, which place it there when the mode is known; here the slabs of the peers are filled in)
+    for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
+    for (uint32_t r = 0; r < world; ++r)
+        for (uint32_t o = 0; o < world; ++o)
+            if (o != r) VP_TRY(peer_copy(m, m->ranks[r], (char*)m->ranks[r].words.ptr + (size_t)o * slabWords, m->ranks[o],
+                                         (const char*)m->ranks[o].words.ptr + (size_t)o * slabWords, slabWords));
+    if (world > 1) VP_TRY(fence_copies(m));
+    for (uint32_t r = 0; r < world; ++r) {
+        Rank& me = m->ranks[r];
+        const std::vector<Region> regs = ghost_regions(n, me.z0, me.z1);
+        const size_t last = regs.size() - 1;
+        char* a = (char*)me.ids[0].ptr;
+        char* b = (char*)me.ids[1].ptr;
+        const uint32_t* words = (const uint32_t*)me.words.ptr;
+        const bool maskStart = last > 0 && vp_jfa_can_start_from_mask(&G, algo);
+        if (maskStart) VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
+        else           VP_TRY(vp_jfa_init(me.ctx, &G, words, nullptr, nullptr, a));
+        size_t skip = 0;
+        // the first two passes as ONE whole-grid launch where the second pass would cover most of the grid anyway
+        if (maskStart && last >= 2 && vp_jfa_can_fuse_first_two(&G, algo) && (uint64_t)(regs[1].b1 - regs[1].b0) * 100 >= 65ull * n) {
+            VP_TRY(vp_jfa_first_two(me.ctx, &G, (const uint32_t*)me.border.ptr, b));
+            std::swap(a, b);
+            skip = 2;
+        }
+        for (size_t i = skip; i < regs.size(); ++i) {
+            const Region& g = regs[i];
+            const vp_frame f = slab_frame(G, g.b0, g.b1);
+            // whole volumes addressed by global plane: minus starts k planes below the region, plus at max(b1, b0 + k)
+            const char* in = a + (size_t)g.b0 * planeIds;
+            const char* mi = a + ((ptrdiff_t)g.b0 - (ptrdiff_t)g.k) * (ptrdiff_t)planeIds;
+            const char* pl = a + (size_t)std::max(g.b1, g.b0 + g.k) * planeIds;
+            char* out = b + (size_t)g.b0 * planeIds;
+            if (i == 0 && maskStart) {
+                VP_TRY(vp_jfa_first_pass(me.ctx, &f, (const uint32_t*)me.border.ptr, out));
+            } else if (i == last) {
+                VP_TRY(vp_jfa_last_pass(me.ctx, &f, in, mi, pl, out, words + (size_t)g.b0 * (planeWords / 4), fill, (float*)me.sdf.ptr, algo));
+                break;
+            } else {
+                VP_TRY(vp_jfa_pass(me.ctx, &f, g.k, in, mi, pl, out, algo));
+            }
+            std::swap(a, b);
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vp_multi_create(const int* devices, int ndev, vp_multi** out)
+{
+    if (!out || !devices || ndev < 1 || ndev > 64) return set_error(VP_ERR_INVALID, "vp_multi_create: bad argument");
+    *out = nullptr;
+    vp_multi* m = new (std::nothrow) vp_multi();
+    if (!m) return set_error(VP_ERR_NOMEM, "vp_multi_create: out of host memory");
+    m->ranks.resize((size_t)ndev);
+    for (int i = 0; i < ndev; ++i) {
+        Rank& r = m->ranks[(size_t)i];
+        r.device = devices[i];
+        int rc = vp_ctx_create(devices[i], &r.ctx);
+        if (rc == 0 && hipEventCreateWithFlags(&r.ready, hipEventDisableTiming) != hipSuccess) rc = set_error(VP_ERR_NOMEM, "vp_multi_create: event");
+        if (rc == 0 && hipEventCreateWithFlags(&r.copied, hipEventDisableTiming) != hipSuccess) rc = set_error(VP_ERR_NOMEM, "vp_multi_create: event");
+        if (rc != 0) { vp_multi_destroy(m); return rc; }
+    }
+    // peer access between distinct devices (a failure only means the copies are staged by the runtime)
+    for (Rank& a : m->ranks)
+        for (Rank& b : m->ranks)
+            if (a.device != b.device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, a.device, b.device) == hipSuccess && can) {
+                    (void)hipSetDevice(a.device);
+                    (void)hipDeviceEnablePeerAccess(b.device, 0);   // hipErrorPeerAccessAlreadyEnabled is fine
+                    (void)hipGetLastError();
+                }
+            }
+    *out = m;
+    return 0;
+}
+
+int vp_multi_destroy(vp_multi* m)
+{
+    if (!m) return 0;
+    for (Rank& r : m->ranks) {
+        if (!r.ctx) continue;
+        (void)hipSetDevice(r.device);
+        (void)hipStreamSynchronize(r.ctx->stream);
+        Buffer* bufs[] = {&r.mesh_xyz, &r.mesh_tri, &r.words, &r.other, &r.below, &r.above, &r.ids[0], &r.ids[1], &r.minus, &r.plus, &r.border, &r.sdf};
+        for (Buffer* b : bufs) release(*b);
+        if (r.ready) (void)hipEventDestroy(r.ready);
+        if (r.copied) (void)hipEventDestroy(r.copied);
+        vp_ctx_destroy(r.ctx);
+    }
+    delete m;
+    return 0;
+}
+
+int vp_multi_count(const vp_multi* m) { return m ? (int)m->ranks.size() : 0; }
+
+vp_ctx* vp_multi_ctx(vp_multi* m, int rank) { return (m && rank >= 0 && rank < (int)m->ranks.size()) ? m->ranks[(size_t)rank].ctx : nullptr; }
+
+int vp_multi_sync(vp_multi* m)
+{
+    if (!m) return set_error(VP_ERR_INVALID, "vp_multi_sync: null argument");
+    for (Rank& r : m->ranks) { VP_TRY(bind(r)); VP_HIP(hipStreamSynchronize(r.ctx->stream)); }
+    return 0;
+}
+
+int vp_multi_set_mesh(vp_multi* m, const float* h_xyz, size_t nverts, const uint32_t* h_tri, size_t ntris)
+{
+    if (!m || ((!h_xyz || !h_tri) && ntris)) return set_error(VP_ERR_INVALID, "vp_multi_set_mesh: null argument");
+    for (Rank& r : m->ranks) {
+        VP_TRY(grow(r, r.mesh_xyz, nverts * 12)); VP_TRY(grow(r, r.mesh_tri, ntris * 12));
+        if (nverts) VP_HIP(hipMemcpyAsync(r.mesh_xyz.ptr, h_xyz, nverts * 12, hipMemcpyHostToDevice, r.ctx->stream));
+        if (ntris) VP_HIP(hipMemcpyAsync(r.mesh_tri.ptr, h_tri, ntris * 12, hipMemcpyHostToDevice, r.ctx->stream));
+    }
+    m->nverts = nverts; m->ntris = ntris;
+    return vp_multi_sync(m);                                       // the host arrays may go away
+}
+
+int vp_multi_voxelize(vp_multi* m, const vp_frame* f, int algo)
+{
+    VP_TRY(check_split(m, f, "vp_multi_voxelize"));
+    assign_slabs(m, f);
+    for (Rank& r : m->ranks) {
+        VP_TRY(grow(r, r.words, vp_grid_words(f) * 4));
+        const vp_frame sf = slab_frame(*f, r.z0, r.z1);
+        VP_TRY(vp_voxelize(r.ctx, &sf, (uint32_t*)slab_words(m, r), (const float*)r.mesh_xyz.ptr, m->nverts, (const uint32_t*)r.mesh_tri.ptr, m->ntris, algo, 0));
+    }
+    m->have_grid = true; m->have_sdf = false;
+    return 0;
+}
+
+int vp_multi_set_grid(vp_multi* m, const vp_frame* f, const uint32_t* h_words)
+{
+    VP_TRY(check_split(m, f, "vp_multi_set_grid"));
+    if (!h_words) return set_error(VP_ERR_INVALID, "vp_multi_set_grid: null argument");
+    assign_slabs(m, f);
+    const size_t planeWords = (size_t)f->n * f->n / 8;
+    for (Rank& r : m->ranks) {
+        VP_TRY(grow(r, r.words, vp_grid_words(f) * 4));
+        VP_HIP(hipMemcpyAsync(slab_words(m, r), (const char*)h_words + (size_t)r.z0 * planeWords, (size_t)(r.z1 - r.z0) * planeWords, hipMemcpyHostToDevice, r.ctx->stream));
+    }
+    m->have_grid = true; m->have_sdf = false;
+    return vp_multi_sync(m);
+}
+
+int vp_multi_get_grid(vp_multi* m, uint32_t* h_words)
+{
+    if (!m || !h_words || !m->have_grid) return set_error(VP_ERR_INVALID, "vp_multi_get_grid: no resident grid");
+    const size_t planeWords = (size_t)m->frame.n * m->frame.n / 8;
+    for (Rank& r : m->ranks) {
+        VP_TRY(bind(r));
+        VP_HIP(hipMemcpyAsync((char*)h_words + (size_t)r.z0 * planeWords, slab_words(m, r), (size_t)(r.z1 - r.z0) * planeWords, hipMemcpyDeviceToHost, r.ctx->stream));
+    }
+    return vp_multi_sync(m);
+}
+
+int vp_multi_csg(vp_multi* m, const uint32_t* h_other, int op)
+{
+    if (!m || !h_other || !m->have_grid) return set_error(VP_ERR_INVALID, "vp_multi_csg: no resident grid");
+    const size_t planeWords = (size_t)m->frame.n * m->frame.n / 8;
+    for (Rank& r : m->ranks) {
+        const size_t bytes = (size_t)(r.z1 - r.z0) * planeWords;
+        VP_TRY(grow(r, r.other, bytes));
+        VP_HIP(hipMemcpyAsync(r.other.ptr, (const char*)h_other + (size_t)r.z0 * planeWords, bytes, hipMemcpyHostToDevice, r.ctx->stream));
+        VP_TRY(vp_csg(r.ctx, (uint32_t*)slab_words(m, r), (const uint32_t*)r.other.ptr, bytes / 4, op));
+    }
+    m->have_sdf = false;
+    return vp_multi_sync(m);
+}
+
+int vp_multi_jfa(vp_multi* m, float fill_unset, int algo, int mode)
+{
+    if (!m || !m->have_grid) return set_error(VP_ERR_INVALID, "vp_multi_jfa: no resident grid (vp_multi_voxelize / vp_multi_set_grid first)");
+    if (!std::isinf(fill_unset)) return set_error(VP_ERR_INVALID, "vp_multi_jfa: fill_unset must be +-infinity");
+    if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_multi_jfa: algo %d", algo);
+    if (mode != VP_MULTI_HALO && mode != VP_MULTI_GHOST) return set_error(VP_ERR_INVALID, "vp_multi_jfa: mode %d", mode);
+    m->bytes_moved = 0;
+    m->last_mode = mode;
+    if (mode == VP_MULTI_GHOST) VP_TRY(jfa_ghost(m, fill_unset, algo));
+    else VP_TRY(jfa_halo(m, fill_unset, algo));
+    m->have_sdf = true;
+    return 0;
+}
+
+int vp_multi_get_sdf(vp_multi* m, float* h_sdf)
+{
+    if (!m || !h_sdf || !m->have_sdf) return set_error(VP_ERR_INVALID, "vp_multi_get_sdf: no sdf (vp_multi_jfa first)");
+    const size_t plane = (size_t)m->frame.n * m->frame.n * 4;
+    for (Rank& r : m->ranks) {
+        VP_TRY(bind(r));
+        VP_HIP(hipMemcpyAsync((char*)h_sdf + (size_t)r.z0 * plane, r.sdf.ptr, (size_t)(r.z1 - r.z0) * plane, hipMemcpyDeviceToHost, r.ctx->stream));
+    }
+    return vp_multi_sync(m);
+}
+
+uint64_t vp_multi_bytes_moved(const vp_multi* m) { return m ? m->bytes_moved : 0; }
+
+}  // extern "C"

@@ -49,6 +49,16 @@ struct vp_ctx {
     // grow-only workspaces
     vp::Buffer rec, tile_cnt, tile_off, tile_cur, pairs, scratch, none_row;
     vp::Buffer jfa_work;                       // vp_jfa* with d_work = NULL: two id volumes + border mask
+    // what the last vp_jfa_start left in its workspace, so that vp_jfa_run can refuse anything else (a run on a workspace that
+    // holds init ids where it expects a border mask, or nothing at all, would produce an sdf from stale memory)
+    struct JfaStarted {
+        bool valid = false;
+        bool mask = false;                     // border mask behind the two id volumes (fast sequence) / init ids in the first volume
+        uint32_t n = 0;
+        int algo = 0;
+        const void* work = nullptr;
+        const uint32_t* words = nullptr;
+    } jfa_started;
     vp::Buffer slots[VP_WORKSPACE_SLOTS];      // vp_ctx_workspace
     // vp_extract_*: block counts / offsets of the last count call and what it was for
     vp::Buffer ext_cnt, ext_off;

@@ -5,6 +5,7 @@
 #define VPLIB_RUNTIME_H
 
 #include <string>
+#include <vector>
 
 #include "vphip.h"
 
@@ -12,6 +13,20 @@ namespace vplib {
 
 // Device used by Context(); call before the first GPU operation (default 0).
 void SetDevice(int device);
+
+// More than one device: every GPU Compute() (VOX / CSG / JFA, Types::NAIVE and Types::TILED) cuts the grid into Z-slabs, one
+// per entry of `devices`, through vp_multi_* (include/vphip.h) -- what stands where the reference pins device 0
+// (apps/cli/main.cpp:22-23).  `ghost` picks the JFA variant: true = recomputed ghost planes, no exchange between passes
+// (VP_MULTI_GHOST); false = halo planes copied device to device before every pass (VP_MULTI_HALO).  Results are bit-identical
+// to the single-device path.  A device may be named several times (several contexts on it).  Call before the first GPU operation.
+void SetDevices(const std::vector<int>& devices, bool ghost = true);
+
+// Devices visible to the process (0 when there is none or the runtime fails).
+int DeviceCount();
+
+// The slab driver, created on first call; nullptr while fewer than two devices are set.
+vp_multi* Multi();
+int MultiMode();
 
 // Creates the context on first call; prints the reference-style assert line and exits on failure.
 vp_ctx* Context();

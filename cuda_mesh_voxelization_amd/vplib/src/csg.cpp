@@ -34,6 +34,26 @@ void Host(bool parallel, uint32_t* a, const uint32_t* b, size_t n, int op)
 void Device(uint32_t* a, const uint32_t* b, size_t n, int op)
 {
     PROFILING_SCOPE("NaiveCSG");
+    if (vp_multi* multi = vplib::Multi()) {                         // several devices: word-wise on the Z-slabs
+        vp_frame f{};
+        f.n = 32;
+        while (static_cast<size_t>(f.n) * f.n * f.n / 32 < n) f.n += 32;   // the operation needs the side only to cut the slabs
+        f.voxel_size = 1.0f; f.z0 = 0; f.z1 = f.n;
+        cpuAssert(static_cast<size_t>(f.n) * f.n * f.n / 32 == n, "CSG on several devices needs a cubic grid with a side that is a multiple of 32");
+        {
+            PROFILING_SCOPE("NaiveCSG::Memory");
+            gpuAssert(vp_multi_set_grid(multi, &f, a));
+        }
+        {
+            PROFILING_SCOPE("NaiveCSG::Processing");
+            gpuAssert(vp_multi_csg(multi, b, op));                 // uploads the slabs of b, combines, synchronises
+        }
+        {
+            PROFILING_SCOPE("NaiveCSG::Memory");
+            gpuAssert(vp_multi_get_grid(multi, a));
+        }
+        return;
+    }
     vp_ctx* ctx = vplib::Context();
     void *da = nullptr, *db = nullptr;
     {

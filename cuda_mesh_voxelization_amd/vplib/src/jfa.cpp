@@ -118,7 +118,6 @@ void Device(int algo, const char* label, const uint32_t* words, size_t n, float 
     // timers (jfa/tiled.cu:265-334).  Device buffers are the context's cached workspace: no allocation in steady state.
     const std::string L(label);
     PROFILING_SCOPE(L);
-    vp_ctx* ctx = vplib::Context();
     vp_frame f{};
     f.n = static_cast<uint32_t>(n); f.voxel_size = vs;
     f.origin[0] = origin[0]; f.origin[1] = origin[1]; f.origin[2] = origin[2];
@@ -128,6 +127,23 @@ void Device(int algo, const char* label, const uint32_t* words, size_t n, float 
     float fill = -INFINITY;
     for (size_t i = 0; i < voxels; ++i)
         if (!((words[i >> 5] >> (i & 31)) & 1u)) { fill = sdf[i]; break; }
+    if (vp_multi* multi = vplib::Multi()) {                         // several devices: Z-slabs, halo copies or ghost planes
+        {
+            PROFILING_SCOPE(L + "::Memory");
+            gpuAssert(vp_multi_set_grid(multi, &f, words));
+        }
+        {
+            PROFILING_SCOPE(L + "::Processing");                    // seeding and passes are one enqueue here
+            gpuAssert(vp_multi_jfa(multi, fill, algo, vplib::MultiMode()));
+            gpuAssert(vp_multi_sync(multi));
+        }
+        {
+            PROFILING_SCOPE(L + "::Memory");
+            gpuAssert(vp_multi_get_sdf(multi, sdf));
+        }
+        return;
+    }
+    vp_ctx* ctx = vplib::Context();
     void *dWords = nullptr, *dSdf = nullptr;
     {
         PROFILING_SCOPE(L + "::Memory");

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <filesystem>
 #include <fstream>
 #include <vector>
@@ -85,9 +86,27 @@ bool load_cache(const std::string& filename, Mesh& mesh)
     CacheHeader h{};
     bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "VPMESH1", 8) == 0 && h.srcSize == size && h.srcMtime == mtime;
     if (ok) {
+        // the counts of a corrupt or foreign file must not reach resize(): the payload they announce has to be exactly what
+        // the file holds (overflow-safe: every count is bounded by the file size first), face indices come in threes
+        std::error_code ec;
+        const uint64_t fileSize = static_cast<uint64_t>(std::filesystem::file_size(filename + ".vpmesh", ec));
+        const uint64_t elem[5] = {sizeof(mesh.FacesCoords[0]), sizeof(mesh.FacesNormals[0]), sizeof(mesh.Coords[0]), sizeof(mesh.Normals[0]), sizeof(mesh.Colors[0])};
+        uint64_t payload = 0;
+        ok = !ec && fileSize >= sizeof(h);
+        for (int i = 0; ok && i < 5; ++i) {
+            ok = h.counts[i] <= (fileSize - sizeof(h)) / elem[i];
+            payload += h.counts[i] * elem[i];
+        }
+        ok = ok && payload == fileSize - sizeof(h) && h.counts[0] % 3 == 0;
+    }
+    if (ok) {
         mesh.Clear();
-        ok = read_vec(f, mesh.FacesCoords, h.counts[0]) && read_vec(f, mesh.FacesNormals, h.counts[1]) && read_vec(f, mesh.Coords, h.counts[2]) &&
-             read_vec(f, mesh.Normals, h.counts[3]) && read_vec(f, mesh.Colors, h.counts[4]) && std::fgetc(f) == EOF;
+        try {
+            ok = read_vec(f, mesh.FacesCoords, h.counts[0]) && read_vec(f, mesh.FacesNormals, h.counts[1]) && read_vec(f, mesh.Coords, h.counts[2]) &&
+                 read_vec(f, mesh.Normals, h.counts[3]) && read_vec(f, mesh.Colors, h.counts[4]) && std::fgetc(f) == EOF;
+        } catch (const std::exception&) {                           // bad_alloc / length_error: fall back to the parser
+            ok = false;
+        }
     }
     std::fclose(f);
     if (!ok) mesh.Clear();

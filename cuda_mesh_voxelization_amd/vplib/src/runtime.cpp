@@ -11,9 +11,38 @@ namespace vplib {
 namespace {
 int g_device = 0;
 vp_ctx* g_ctx = nullptr;
+std::vector<int> g_devices;
+bool g_ghost = true;
+vp_multi* g_multi = nullptr;
 }  // namespace
 
 void SetDevice(int device) { g_device = device; }
+
+void SetDevices(const std::vector<int>& devices, bool ghost)
+{
+    g_devices = devices;
+    g_ghost = ghost;
+    if (!devices.empty()) g_device = devices[0];                   // exports and single-device calls use the first one
+}
+
+vp_multi* Multi()
+{
+    if (g_devices.size() < 2) return nullptr;
+    if (!g_multi) {
+        gpuAssert(vp_multi_create(g_devices.data(), static_cast<int>(g_devices.size()), &g_multi));
+        static bool registered = false;
+        if (!registered) { std::atexit(Shutdown); registered = true; }
+    }
+    return g_multi;
+}
+
+int MultiMode() { return g_ghost ? VP_MULTI_GHOST : VP_MULTI_HALO; }
+
+int DeviceCount()
+{
+    int n = 0;
+    return vp_device_count(&n) == 0 ? n : 0;
+}
 
 vp_ctx* Context()
 {
@@ -36,6 +65,10 @@ void PrintDeviceTimes(const std::string& label)
 
 void Shutdown()
 {
+    if (g_multi) {
+        vp_multi_destroy(g_multi);
+        g_multi = nullptr;
+    }
     if (g_ctx) {
         vp_ctx_destroy(g_ctx);
         g_ctx = nullptr;

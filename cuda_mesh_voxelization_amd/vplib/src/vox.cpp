@@ -81,13 +81,29 @@ void Device(int algo, const char* label, uint32_t* words, size_t n, float vs, co
 {
     const std::string L(label);
     PROFILING_SCOPE(L + "(" + mesh.Name + ")");
-    vp_ctx* ctx = vplib::Context();
     vp_frame f{};
     f.n = static_cast<uint32_t>(n); f.voxel_size = vs;
     f.origin[0] = origin[0]; f.origin[1] = origin[1]; f.origin[2] = origin[2];
     f.z0 = 0; f.z1 = f.n;
     const size_t nverts = mesh.Coords.size(), ntris = mesh.TrianglesSize();
     const size_t gridBytes = vp_grid_words(&f) * 4;
+    if (vp_multi* multi = vplib::Multi()) {                         // several devices: every one rasterises its own Z-slab
+        {
+            PROFILING_SCOPE(L + "::Memory");
+            gpuAssert(vp_multi_set_mesh(multi, reinterpret_cast<const float*>(mesh.Coords.data()), nverts, mesh.FacesCoords.data(), ntris));
+        }
+        {
+            PROFILING_SCOPE(L + "::Processing");
+            gpuAssert(vp_multi_voxelize(multi, &f, algo));
+            gpuAssert(vp_multi_sync(multi));
+        }
+        {
+            PROFILING_SCOPE(L + "::Memory");
+            gpuAssert(vp_multi_get_grid(multi, words));
+        }
+        return;
+    }
+    vp_ctx* ctx = vplib::Context();
     void *dWords = nullptr, *dXyz = nullptr, *dTri = nullptr;
     {
         PROFILING_SCOPE(L + "::Memory");

@@ -61,6 +61,7 @@ typedef struct vp_ctx vp_ctx;
  * Replaces `cudaSetDevice(0)` + default stream + per-call cudaMalloc/cudaFree of the reference
  * (apps/cli/main.cpp:22-23, vplib/src/cuda_ptr.h:15-93).  The context owns a stream and a
  * grow-only workspace so that steady-state calls allocate nothing. */
+int vp_device_count(int* out);                                    /* devices visible to the process */
 int vp_ctx_create(int device, vp_ctx** out);
 int vp_ctx_destroy(vp_ctx* ctx);
 /* external != 0: enqueue on the caller's hipStream_t `hip_stream` (NULL = the device's null stream,
@@ -99,7 +100,11 @@ size_t vp_grid_voxels(const vp_frame* f);
  *   d_tri   ntris x 3 uint32  (Mesh::FacesCoords; ntris = indices/3 as in sequential.cpp:16)
  *   accumulate = 0: d_words is overwritten (GPU variants of the reference replace the grid,
  *                   vox/tiled.cu:572-575); 1: XOR into the existing words (sequential semantics).
- * Fully asynchronous: list sizes stay on the device (no read-back, no stream synchronisation). */
+ * Asynchronous in steady state: list sizes stay on the device (no read-back, no stream synchronisation).  The FIRST call, and
+ * any call that needs a larger internal buffer than the context has (grow-only), synchronises the stream and allocates:
+ * 80 B per triangle for the record list of large triangles (sized for the worst case, every triangle large: 0.86 GB for the
+ * 10.8 M-face mesh; only the records actually appended are touched), the tile work queue (>= 4 MiB, grows with what earlier
+ * calls needed) and the 8 x 8-column tile tables. */
 int vp_voxelize(vp_ctx* ctx, const vp_frame* f, uint32_t* d_words,
                 const float* d_xyz, size_t nverts, const uint32_t* d_tri, size_t ntris,
                 int algo, int accumulate);
@@ -131,7 +136,10 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
            float* d_sdf, void* d_work, size_t work_bytes, int algo);
 /* vp_jfa in the two parts the reference times separately ("::Initialization" = seeding, jfa/tiled.cu:265-290;
  * "::Processing" = the passes, jfa/tiled.cu:292-334): vp_jfa == vp_jfa_start + vp_jfa_run on the same workspace.
- * This is the sequence JFA::Compute<NAIVE|TILED> and the CLI run -- the same kernels the benchmark times. */
+ * This is the sequence JFA::Compute<NAIVE|TILED> and the CLI run -- the same kernels the benchmark times.
+ * The context records what vp_jfa_start left in the workspace (grid pointer, n, algo, workspace, border mask or init ids);
+ * vp_jfa_run returns VP_ERR_INVALID unless exactly that start preceded it -- one start serves one run, and the record is
+ * dropped when the workspace is released, regrown or freed. */
 int vp_jfa_start(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void* d_work, size_t work_bytes, int algo);
 int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
                float* d_sdf, void* d_work, size_t work_bytes, int algo);
@@ -184,11 +192,49 @@ int vp_surface(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words,
  *   record = linear voxel index x + n (y + n z) in bits 0..39 | face mask << 40 (bit = axis * 2 + side; X, Y, Z; 0 = minus)
  * vp_extract_count runs the counting pass and returns the number of records (blocking); vp_extract then writes up to
  * `capacity` records (and, when d_sdf and d_values are given, the sdf value of each voxel) -- it must follow a count call for
- * the same grid and mode. */
+ * the same grid and mode, else VP_ERR_INVALID.  "Same grid" means same contents: the count is forgotten as soon as d_words is
+ * written through this ABI (vp_voxelize, vp_csg, vp_upload, vp_memset, vp_memcpy_d2d), freed, or handed out again by
+ * vp_ctx_workspace; a caller that writes the buffer with its own kernels must count again itself. */
 enum { VP_EXTRACT_SET = 0, VP_EXTRACT_EXPOSED = 1 };
 int vp_extract_count(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode, uint64_t* h_count);
 int vp_extract(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode, const float* d_sdf,
                uint64_t* d_records, float* d_values, size_t capacity);
+
+/* ---- several GPUs of one node: Z-slabs -------------------------------------------------------
+ * Replaces the reference's hard-wired device 0 (apps/cli/main.cpp:22-23) when more than one device is given: ONE process,
+ * one context per device, rank r owns the planes [r n/G, (r+1) n/G) of the grid, the sdf and the JFA state; G must divide n
+ * into slabs of a multiple of 8 planes.  The stages are the slab forms of the calls above (vp_frame.z0 / z1):
+ *   voxelize / CSG   no exchange (columns and words are independent)
+ *   JFA              VP_MULTI_HALO : bitmask planes z0-1 / z1 before the seeding and the id planes [z0-k, min(z0, z1-k)),
+ *                                    [max(z1, z0+k), z1+k) before the pass with step k travel device to device
+ *                                    (hipMemcpyPeerAsync behind stream events; no host synchronisation inside the JFA)
+ *                    VP_MULTI_GHOST: the bitmask slabs are all-gathered once (n^3/8 bytes) and every device recomputes the
+ *                                    ghost planes its later passes reach: no exchange between passes, two full id volumes
+ *                                    per device
+ * Results are bit-identical to the single-device calls for any G.  `devices` may name one device several times (several
+ * contexts on it): that is how the parity tests run on a one-GPU box.  Grid, sdf and mesh stay resident on the devices
+ * between calls; host arrays are whole-grid arrays in the reference's layout. */
+typedef struct vp_multi vp_multi;
+enum { VP_MULTI_HALO = 0, VP_MULTI_GHOST = 1 };
+int vp_multi_create(const int* devices, int ndev, vp_multi** out);
+int vp_multi_destroy(vp_multi* m);
+int vp_multi_count(const vp_multi* m);
+vp_ctx* vp_multi_ctx(vp_multi* m, int rank);                      /* the context of a rank (timers, stream) */
+int vp_multi_sync(vp_multi* m);
+/* broadcast of the mesh to every device (blocking) -- Mesh::Coords / Mesh::FacesCoords as in vp_voxelize */
+int vp_multi_set_mesh(vp_multi* m, const float* h_xyz, size_t nverts, const uint32_t* h_tri, size_t ntris);
+/* every device rasterises the resident mesh into its slab of a fresh grid with frame f (async) */
+int vp_multi_voxelize(vp_multi* m, const vp_frame* f, int algo);
+/* scatter a host grid into the slabs / gather the slabs (blocking) */
+int vp_multi_set_grid(vp_multi* m, const vp_frame* f, const uint32_t* h_words);
+int vp_multi_get_grid(vp_multi* m, uint32_t* h_words);
+/* resident grid = resident grid op h_other (CSG::Compute's "result in the first grid", csg/naive.cu:62); blocking */
+int vp_multi_csg(vp_multi* m, const uint32_t* h_other, int op);
+/* JFA of the resident grid into the resident slab sdfs (async); vp_multi_get_sdf gathers them (blocking) */
+int vp_multi_jfa(vp_multi* m, float fill_unset, int algo, int mode);
+int vp_multi_get_sdf(vp_multi* m, float* h_sdf);
+/* device-to-device bytes the last vp_multi_jfa enqueued (halo planes / the bitmask all-gather) */
+uint64_t vp_multi_bytes_moved(const vp_multi* m);
 
 /* ---- host-in / host-out conveniences (the reference's Compute() calling convention) -------
  * Upload, run, download, synchronise -- what every reference Compute<NAIVE|TILED> does

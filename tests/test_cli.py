@@ -251,6 +251,16 @@ def test_cli_mesh_cache(cli, tmp_path):
     with open(obj + ".vpmesh", "r+b") as f:                                                # truncate: malformed cache is ignored
         f.truncate(100)
     assert np.array_equal(grid(env, "corrupt"), O.voxelize(xyz, tri, 64, vs, origin))
+    # a cache with a VALID header (magic, size and mtime stamp of the source) whose counts are absurd must be ignored as well,
+    # not reach vector::resize (length_error / bad_alloc used to abort the CLI)
+    assert os.path.exists(obj + ".vpmesh")                                                  # rewritten by the run above
+    with open(obj + ".vpmesh", "r+b") as f:
+        head = bytearray(f.read(24 + 40))
+        head[24:32] = (2 ** 62).to_bytes(8, "little")                                      # counts[0]
+        head[40:48] = (2 ** 40 + 1).to_bytes(8, "little")                                  # counts[2]
+        f.seek(0)
+        f.write(head)
+    assert np.array_equal(grid(env, "absurd"), O.voxelize(xyz, tri, 64, vs, origin))
 
 
 @pytest.mark.gpu
@@ -262,3 +272,29 @@ def test_cli_gpu_types_reject_unsupported_sizes_loudly(cli, tmp_path):
     p = subprocess.run([cli, M.asset("d20.obj"), "-n", "100", "-t", "0"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0
     assert "multiple of 32" in subprocess.run([cli, "-h"], capture_output=True, text=True).stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g,multi", [(2, "halo"), (4, "halo"), (4, "ghost")])
+def test_cli_gpus_flag_matches_golden(cli, golden_rows, tmp_path, g, multi):
+    """`vpcli -g G` (the multi-GPU extension of the CLI; the reference pins device 0, apps/cli/main.cpp:22-23): the
+    grid is cut into G Z-slabs behind the same VOX / CSG / JFA::Compute calls (vplib::SetDevices -> vp_multi_*).  On a one-GPU box
+    VPLIB_SHARE_GPU=1 puts the slabs' contexts on the devices there are; results are the reference's golden rows all the same."""
+    env = dict(os.environ, VPLIB_SHARE_GPU="1")
+    for meshes, n, op in ((["bunny.obj"], 64, 0), (["bimba.obj", "bunny.obj"], 128, 1)):
+        args = [M.asset(m) for m in meshes] + ["-n", str(n), "-t", "2", "-s", "-g", str(g), "--multi", multi] + (["-p", str(op)] if op else [])
+        prefix = str(tmp_path / ("g%d%s%d" % (g, multi, n)))
+        p = subprocess.run([cli] + args + ["-d", prefix], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        _check_row(prefix, _row(golden_rows, meshes, n, op))
+        labels = {m.group("label") for m in map(LINE.match, p.stdout.splitlines()) if m}
+        assert {"TiledVox::Processing", "TiledJFA::Processing", "TiledJFA::Memory"} <= labels   # same timer grammar
+    # a slab count that does not cut the grid into multiples of 8 planes is refused with the reference-style assert line
+    p = subprocess.run([cli, M.asset("d20.obj"), "-n", "96", "-t", "2", "-g", "5"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode != 0 and "cannot be cut" in p.stdout
+    # without the test-rig switch the devices 0 .. G-1 must exist
+    if g == 4:
+        import torch
+        if torch.cuda.device_count() < 4:
+            p = subprocess.run([cli, M.asset("d20.obj"), "-n", "64", "-t", "2", "-g", "4"], capture_output=True, text=True, timeout=120)
+            assert p.returncode != 0 and "not present" in p.stdout

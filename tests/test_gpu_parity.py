@@ -166,6 +166,42 @@ def test_jfa_start_run_equals_jfa(engine):
             assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
 
 
+def test_jfa_run_needs_its_own_start(engine):
+    """vp_jfa_run reads what vp_jfa_start left in the workspace (a border mask or init ids, depending on frame and algo): the
+    context records it and anything else is refused instead of producing an sdf from stale memory."""
+    xyz, tri = M.import_mesh(M.asset("bunny.obj"))
+    ctx = engine.ctx
+    frames = {}
+    for n in (64, 256):
+        origin, vs = M.frame([xyz], n)
+        frames[n] = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    g = {n: engine.voxelize(f, dx, dt) for n, f in frames.items()}
+    out = torch.empty(frames[256].voxels, dtype=torch.float32, device=engine.device)
+    nb = ctx.jfa_workspace_bytes(frames[256])
+    work = torch.empty(nb, dtype=torch.uint8, device=engine.device)
+    run = lambda n, algo, w=work: ctx.jfa_run(frames[n], g[n].data_ptr(), -math.inf, out.data_ptr(), w.data_ptr(), nb, algo)
+    start = lambda n, algo, w=work: ctx.jfa_start(frames[n], g[n].data_ptr(), w.data_ptr(), nb, algo)
+    ref = engine.jfa(frames[256], g[256]).clone()                     # vp_jfa leaves no usable record behind
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(256, ALGO_TILED)
+    start(256, ALGO_NAIVE)                                             # init ids ...
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(256, ALGO_TILED)                                           # ... where the tiled sequence expects the border mask
+    start(256, ALGO_TILED)
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(64, ALGO_TILED)                                            # another frame
+    start(256, ALGO_TILED)
+    other = torch.empty(nb, dtype=torch.uint8, device=engine.device)
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(256, ALGO_TILED, other)                                    # another workspace
+    start(256, ALGO_TILED)
+    run(256, ALGO_TILED)
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(256, ALGO_TILED)                                           # one start serves one run
+
+
 @pytest.mark.parametrize("op", [1, 2, 3, 0])
 def test_csg_matches_oracle(engine, op):
     rng = np.random.default_rng(op)
@@ -341,6 +377,15 @@ def test_headline_size_properties(engine):
     s_t = engine.jfa(fr, g_t, algo=ALGO_TILED).clone()
     s_n = engine.jfa(fr, g_t, algo=ALGO_NAIVE)
     assert torch.equal(s_t.view(torch.int32), s_n.view(torch.int32))
+    # ... and the sdf of exactly this workload against the ORACLE, bit for bit (a few seconds on the GPU box's host cores),
+    # plus the hashes recorded from the oracle run in the build container (tests/golden/own_oracle_runs.json)
+    exp_s = O.jfa(exp, 512, vs, origin)
+    _assert_sdf_equal(s_t.cpu().numpy(), exp_s)
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "own_oracle_runs.json")) as f:
+        (row,) = [r for r in json.load(f)["rows"] if r["n"] == 512]
+    assert [O.popcount(wt), O.fnv(wt)] == row["grid"]
+    assert O.fnv(s_t.cpu().numpy()) == row["sdf"]["fnv"] and int((exp_s == 0).sum()) == row["sdf"]["zeros"]
     border = engine.surface(fr, g_t)
     s = s_t.cpu().numpy()
     bbits = np.unpackbits(engine.words_to_numpy(border).view(np.uint8), bitorder="little").astype(bool)
@@ -525,6 +570,13 @@ def test_extract_records_match_numpy(engine):
             got = rec.cpu().numpy().view(np.uint64)[:cnt]
             assert np.array_equal(got, exp), (n, mode)
             assert np.array_equal(val.cpu().numpy()[:cnt], (exp & np.uint64((1 << 40) - 1)).astype(np.float32))
+            # the count belongs to the grid CONTENTS: once the buffer is written through the ABI, vp_extract wants a new count
+            if cnt > 10 and mode == EXTRACT_SET:
+                keep = g.clone()
+                engine.csg(g, keep, 1)                                 # g |= g: same bits, but written
+                with pytest.raises(capi.VPError, match="vp_extract_count"):
+                    engine.ctx.extract(fr, g.data_ptr(), mode, None, rec.data_ptr(), None, cnt)
+                assert engine.ctx.extract_count(fr, g.data_ptr(), mode) == cnt
             # a capacity smaller than the count truncates, never writes past it
             if cnt > 10:
                 rec.fill_(-1)

@@ -1,0 +1,114 @@
+"""vp_multi_* -- the C++ Z-slab driver behind the C ABI (csrc/multi.hip; what replaces the reference's hard-wired device 0,
+apps/cli/main.cpp:22-23).  A one-GPU box runs it with several contexts on device 0: the slab frames, halo copies, stream events
+and ghost regions are the ones a multi-device node runs, only the copies stay on the device.  Bar: concatenated slabs
+bit-identical to the single-context result (and, at the small sizes, to the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from cuda_mesh_voxelization_amd import capi, mesh as M
+from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, MULTI_GHOST, MULTI_HALO, Frame
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(engine, fr, xyz, tri, algo=ALGO_TILED):
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    g = engine.voxelize(fr, dx, dt, algo=algo)
+    s = engine.jfa(fr, g, algo=algo)
+    engine.sync()
+    return engine.words_to_numpy(g).copy(), s.cpu().numpy()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("name,n", [("bunny.obj", 64), ("bunny.obj", 256)])
+def test_multi_matches_single_and_oracle(engine, name, n, world):
+    xyz, tri = M.import_mesh(M.asset(name))
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    exp_w = O.voxelize(xyz, tri, n, vs, origin)
+    exp_s = O.jfa(exp_w, n, vs, origin)
+    m = capi.Multi([0] * world)
+    try:
+        assert m.count == world
+        m.set_mesh(xyz, tri)
+        for algo in (ALGO_TILED, ALGO_NAIVE):
+            m.voxelize(fr, algo)
+            assert np.array_equal(m.get_grid(), exp_w)
+            for mode in (MULTI_HALO, MULTI_GHOST):
+                m.jfa(algo=algo, mode=mode)
+                got = m.get_sdf()
+                assert np.array_equal(got.view(np.uint32), exp_s.view(np.uint32)), (algo, mode)
+                # halo: planes really moved (bitmask planes + id planes of every pass); ghost: only the bitmask all-gather
+                if mode == MULTI_GHOST:
+                    assert m.bytes_moved == world * (world - 1) * (fr.words // world) * 4
+                else:
+                    assert m.bytes_moved > 2 * (world - 1) * n * n * 4
+    finally:
+        m.close()
+
+
+def test_multi_csg_and_set_grid(engine):
+    """config 3's flow on slabs: two meshes in one frame, union accumulated into the resident grid, then the sdf."""
+    a = M.import_mesh(M.asset("bimba.obj"))
+    b = M.import_mesh(M.asset("bunny.obj"))
+    n, world = 128, 4
+    origin, vs = M.frame([a[0], b[0]], n)
+    fr = Frame.make(n, vs, origin)
+    wa, wb = O.voxelize(a[0], a[1], n, vs, origin), O.voxelize(b[0], b[1], n, vs, origin)
+    m = capi.Multi([0] * world)
+    try:
+        for op in (1, 2, 3):
+            m.set_mesh(*a)
+            m.voxelize(fr)
+            m.csg(wb, op)
+            exp = wa.copy()
+            O.csg(exp, wb, op)
+            assert np.array_equal(m.get_grid(), exp), op
+            m.jfa(mode=MULTI_HALO)
+            assert np.array_equal(m.get_sdf().view(np.uint32), O.jfa(exp, n, vs, origin).view(np.uint32)), op
+        # a host grid scattered into the slabs gives the same sdf as the one voxelized in place
+        m.set_grid(fr, exp)
+        m.jfa(mode=MULTI_GHOST)
+        assert np.array_equal(m.get_sdf().view(np.uint32), O.jfa(exp, n, vs, origin).view(np.uint32))
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("world,mode", [(2, MULTI_HALO), (4, MULTI_HALO), (8, MULTI_HALO), (4, MULTI_GHOST), (8, MULTI_GHOST)])
+def test_multi_headline_size_equals_single(engine, world, mode):
+    """n = 512 on the benchmark mesh: narrow passes land next to the slab (dense tile kernel), wide ones in the whole-slab
+    buffers; ghost regions at 4 and 8 ranks take the fused first two passes or the two region passes respectively."""
+    xyz, tri = M.bunny(24)
+    n = 512
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    ref_w, ref_s = _single(engine, fr, xyz, tri)
+    m = capi.Multi([0] * world)
+    try:
+        m.set_mesh(xyz, tri)
+        m.voxelize(fr)
+        assert np.array_equal(m.get_grid(), ref_w)
+        m.jfa(mode=mode)
+        assert np.array_equal(m.get_sdf().view(np.uint32), ref_s.view(np.uint32))
+    finally:
+        m.close()
+        torch.cuda.empty_cache()
+
+
+def test_multi_rejects_bad_splits_and_order(engine):
+    fr = Frame.make(96, 1.0, (0, 0, 0))
+    m = capi.Multi([0, 0, 0, 0, 0])
+    try:
+        with pytest.raises(capi.VPError, match="cannot be cut"):
+            m.set_grid(fr, np.zeros(fr.words, np.uint32))
+        m.frame = fr
+        with pytest.raises(capi.VPError, match="no resident grid"):
+            m.jfa()
+        with pytest.raises(capi.VPError, match="no sdf"):
+            m.get_sdf()
+    finally:
+        m.close()
+    with pytest.raises(capi.VPError, match="not present"):
+        capi.Multi([0, 99])

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p tools/exp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude "$@" \
-    cuda_mesh_voxelization_amd/csrc/{capi,vox,csg,jfa,extract}.hip -o tools/exp/libvphip_$name.so
+    cuda_mesh_voxelization_amd/csrc/{capi,vox,csg,jfa,extract,multi}.hip -o tools/exp/libvphip_$name.so
 echo tools/exp/libvphip_$name.so
