@@ -971,7 +971,7 @@ __device__ __forceinline__ void lds_span(const char* base, uint32_t off, int lo,
 #endif
 template <class ID> constexpr bool final_mask_global() { return VP_FINAL_GLOBAL_MASK == 1 || (VP_FINAL_GLOBAL_MASK == 2 && ID::kTab > 512); }
 // 8-byte ids (n <= 2048, round 3): the same kernel with
-//   * ranks relative to the tile: (index of the source row among the tile's (CH + 2) x (RY + 2) source rows) << 11 | x, + 1 -- the byte
+//   * ranks relative to the tile: (index of the source row among the tile's (CH + 2) x (RY + 2) source rows) << 14 | byte offset in the row, + 1 -- the byte
 //     offset of a source voxel no longer fits 32 bits (the volume is 64 GiB); a 60-entry LDS table turns the row index of the winner
 //     back into its row number for the gather;
 //   * 8-KB tables: PX and the squared y differences per output row (TY) as before, but ONE table of seed z POSITIONS instead of CH
@@ -980,7 +980,10 @@ template <class ID> constexpr bool final_mask_global() { return VP_FINAL_GLOBAL_
 //     infinite seed x by an explicit test, once per id.
 template <class ID> constexpr bool dense_wide() { return std::is_same<ID, Id64>::value; }
 template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP>
-__global__ void __launch_bounds__(NT, dense_wide<ID>() ? 4 : RY > 4 ? 4 : (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (ID::kTab == 512 || NT == 512) ? 6 : 4)
+#ifndef VP_DENSE_WIDE_WAVES
+#define VP_DENSE_WIDE_WAVES 4
+#endif
+__global__ void __launch_bounds__(NT, dense_wide<ID>() ? (NT == 256 ? VP_DENSE_WIDE_WAVES : 4) : RY > 4 ? 4 : (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (ID::kTab == 512 || NT == 512) ? 6 : 4)
 jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typename ID::T* __restrict__ out,
                const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf,
                uint32_t tilesY, uint32_t tiles, uint32_t splitTiles)
@@ -994,9 +997,14 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     constexpr int NR = RY + 2;
     constexpr int NI = NR * 3;
     constexpr int CHT = WIDE ? 1 : CH;                             // z tables: squared differences per output plane / one table of positions
+#ifndef VP_DENSE_WIDE_YPOS
+#define VP_DENSE_WIDE_YPOS 0      // 1: 8-byte ids with a y table of positions too (24 KB of LDS, 256 threads, four workgroups per CU) instead of
+#endif                            // RY tables of squared differences (48 KB, 512 threads, two workgroups): measured 52.7 against 51.2 ms per pass
+    constexpr bool YPOS = WIDE && VP_DENSE_WIDE_YPOS;
+    constexpr int RYT = YPOS ? 1 : RY;
     using B = typename std::conditional<FINAL, float, double>::type;
     __shared__ float PX[PXT];
-    __shared__ __attribute__((aligned(16))) float TY[RY / EY][TAB][EY];
+    __shared__ __attribute__((aligned(16))) float TY[RYT / EY][TAB][EY];
     __shared__ __attribute__((aligned(16))) float TZ[CHT / EZ][TAB][EZ];
     __shared__ uint32_t RB[WIDE ? (CH + 2) * NR : 1];              // WIDE: row number (inside the id buffer) of every source row of the tile
     constexpr bool GM = final_mask_global<ID>();
@@ -1026,9 +1034,24 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     }
     if (VP_DENSE_XCD && total % 8u == 0u) lin = (lin % 8u) * (total / 8u) + lin / 8u;
     if (rev) lin = total - 1u - lin;
-    const uint32_t bx = lin % tilesY, by = lin / tilesY;
-    const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
     const int nres = min(K, nzl);
+#ifndef VP_DENSE_ORDER
+#define VP_DENSE_ORDER 0
+#endif
+    // Tile order.  0: y residue fastest -- consecutive tiles are adjacent rows of the volume and share nothing.  1: the tiles of
+    // one (y residue, z residue) pair -- the only tiles that share halo rows and planes -- are consecutive, chunk along y fastest,
+    // so that the rows two neighbours both read are requested at about the same time (measured: profiles/r03/ab_order_*.txt).
+    uint32_t bx, by;
+    if (VP_DENSE_ORDER == 1) {
+        const uint32_t ncy = tilesY / (uint32_t)nresY, tilesZ = total / tilesY, ncz = tilesZ / (uint32_t)nres;
+        const uint32_t cy = lin % ncy; uint32_t t = lin / ncy;
+        const uint32_t cz = t % ncz; t /= ncz;
+        bx = t % (uint32_t)nresY + cy * (uint32_t)nresY;
+        by = t / (uint32_t)nresY + cz * (uint32_t)nres;
+    } else {
+        bx = lin % tilesY; by = lin / tilesY;
+    }
+    const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
     const int lbase = (int)(by % nres) + (int)(by / nres) * CH * K;
     if (ybase >= N || lbase >= nzl) return;
     const int zbase = lbase + (int)f.z0;
@@ -1042,8 +1065,11 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         if (i < (uint32_t)N) {
             const uint32_t si = scr(i);
             const float sy = axis_pos(f.oy, i, f.vs), sz = axis_pos(f.oz, i, f.vs);
+            if (YPOS) TY[0][si][0] = sy;
+            else {
 #pragma unroll
-            for (int j = 0; j < RY; ++j) { const float d = sy - py[j]; TY[j / EY][si][j % EY] = d * d; }
+                for (int j = 0; j < RYT; ++j) { const float d = sy - py[j]; TY[j / EY][si][j % EY] = d * d; }
+            }
             if (WIDE) TZ[0][si][0] = sz;
             else {
 #pragma unroll
@@ -1051,7 +1077,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             }
         } else {                                                   // slots no real id refers to ("none" does: TAB - 1); finite: inf + it = inf
 #pragma unroll
-            for (int j = 0; j < RY; ++j) TY[j / EY][i][j % EY] = 0.0f;
+            for (int j = 0; j < RYT; ++j) TY[j / EY][i][j % EY] = 0.0f;
 #pragma unroll
             for (int j = 0; j < CHT; ++j) TZ[j / EZ][i][j % EZ] = 0.0f;
         }
@@ -1109,8 +1135,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         const float px = PX[x];
         const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
         const uint32_t xo = x * IDB, xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;   // a column outside the grid reads the centre column
-        // WIDE: rank of a candidate = (source row index << 11 | x of the column it was read from) + 1
-        const uint32_t xr[3] = {(hasM ? x - k : x) + 1u, x + 1u, (hasP ? x + k : x) + 1u};
+        // WIDE: rank of a candidate = (source row index << 14 | byte offset of the column it was read from) + 1
 
         // SKIP (wide passes, k >= n/4: half of the neighbour rows / planes / columns lie outside the grid): a source row that
         // does not exist is neither loaded nor evaluated (wave-uniform branch), and neither is a column x-k / x+k that no lane
@@ -1151,7 +1176,13 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             for (int a = 0; a < RY; ++a) d.dy2[a] = __uint_as_float(yo + a);
             for (int o = 0; o < CH; ++o) d.dz2[o] = __uint_as_float(zo + o);
 #else
-            lds_span<RY, EY, TAB>(ty, yo, alo, ahi, d.dy2);
+            if constexpr (YPOS) {
+                const float sy = lds_f32(ty + yo);
+#pragma unroll
+                for (int a = alo; a <= ahi; ++a) { const float dyv = sy - py[a]; d.dy2[a] = dyv * dyv; }
+            } else {
+                lds_span<RY, EY, TAB>(ty, yo, alo, ahi, d.dy2);
+            }
             if constexpr (WIDE) {
                 const float sz = lds_f32(tz + zo);                          // seed z position; the squares per output plane are formed here
 #pragma unroll
@@ -1170,7 +1201,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             const float dxv = d.sx - px;
             const float dx2 = dxv * dxv;
             u32x2 cand;
-            if (!FINAL) cand.x = WIDE ? (uint32_t)(((P + 1) * NR + rr) << 11) + xr[c] : prank + ro[rr] + (c == 0 ? xmo : c == 1 ? xo : xpo);
+            if (!FINAL) cand.x = (WIDE ? (uint32_t)(((P + 1) * NR + rr) << 14) + 1u : prank + ro[rr]) + (c == 0 ? xmo : c == 1 ? xo : xpo);
 #pragma unroll
             for (int a = alo; a <= ahi; ++a) {
                 const float pre = dx2 + d.dy2[a];
@@ -1326,10 +1357,14 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                         if (a >= yout) continue;
                         const uint32_t lo = __builtin_bit_cast(u32x2, best[a][P - 1]).x;
                         if constexpr (WIDE) {
-                            // rank - 1 = source row index << 11 | x; the own voxel (rank 0) sits in row (P, a + 1) of the tile's source rows
-                            const uint32_t r = lo ? lo - 1u : (uint32_t)((P * NR + a + 1) << 11) + x;
-                            const ptrdiff_t row = (ptrdiff_t)(int)RB[r >> 11];
-                            pend[a] = in[row * N + (ptrdiff_t)(r & 2047u)];
+                            // rank - 1 = source row index << 14 | byte offset in the row; the own voxel (rank 0) sits in row (P, a + 1) of the tile's source rows
+                            const uint32_t r = lo ? lo - 1u : (uint32_t)((P * NR + a + 1) << 14) + xo;
+                            const ptrdiff_t row = (ptrdiff_t)(int)RB[r >> 14];
+#if defined(VP_ABL_NOGATHER)
+                            pend[a] = ID::pack(r & 2047u, (uint32_t)row & 2047u, 0u);
+#else
+                            pend[a] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(in) + row * (ptrdiff_t)rowBytes + (ptrdiff_t)(r & 16383u));
+#endif
                         } else {
                             const uint32_t ownOff = orank + ro[a + 1] + xo;
                             const uint32_t off = lo ? lo - 1u : ownOff;
@@ -1810,8 +1845,13 @@ static bool dense_applies(const Frame& f, uint32_t k, const void* d_in, const vo
 {
     if (fin && !VP_JFA_DENSE_FINAL) return false;
     static const int enabled = env_int("VP_JFA_DENSE", VP_JFA_DENSE_DEFAULT);         // dev switch: 0 = round-1 kernel for every pass
-    static const int wideOn = env_int("VP_JFA_DENSE_WIDE", 1);                          // dev switch: 0 = round-1 kernel for 8-byte ids
-    if (!enabled || (wide(f) && !wideOn) || (k * 4 >= f.n && !VP_JFA_DENSE_WIDEK)) return false;
+    // 8-byte ids (n > 1024): the fused last pass runs here (38.4 -> 37.7 ms at n = 2048); the id passes stay on jfa_pass_zstream
+    // (46.5 ms against 51.2 here, profiles/r03/n2048_dense_wide.txt): the winner gather -- one 8-byte load per voxel from rows the tile
+    // read one to three planes earlier -- misses the L2 at this size (16-KB rows; 43.1 ms with the gather ablated).
+    // VP_JFA_DENSE_WIDE=1 routes them here all the same (dev), =0 keeps even the last pass on the round-1 kernel.
+    static const int wideMode = env_int("VP_JFA_DENSE_WIDE", 2);
+    if (wide(f) && (wideMode == 0 || (wideMode == 2 && !fin))) return false;
+    if (!enabled || (k * 4 >= f.n && !VP_JFA_DENSE_WIDEK)) return false;
     const size_t plane = (size_t)f.n * f.n * jfa_id_bytes(f);
     const char* in = (const char*)d_in;
     if (f.z0 > 0 && (const char*)d_minus + (size_t)k * plane != in) return false;      // the three id buffers must be one volume
@@ -1856,6 +1896,9 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
     // Tile 4 rows x 8 planes when the plane chains divide by 8, else 4 x 4.  2-KB tables (n <= 512): 256 threads, 26 KB of LDS,
     // six workgroups per CU.  4-KB tables: the 4 x 8 tile takes 52 KB, shared by the 8 waves of a 512-thread workgroup (three per CU).
+#ifndef VP_DENSE_WIDE_NT
+#define VP_DENSE_WIDE_NT 512      // threads per workgroup with 8-byte ids (256 with -DVP_DENSE_WIDE_YPOS=1)
+#endif
 #ifndef VP_DENSE_RY
 #define VP_DENSE_RY 4             // output rows per tile (dev: 8 = 4.7 decoded ids per voxel instead of 5.6, 109 VGPRs, four waves per SIMD)
 #endif
@@ -1863,7 +1906,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     do {                                                                                                                           \
         const uint32_t ty_ = nresY * ((ylen + VP_DENSE_RY - 1) / VP_DENSE_RY), t_ = ty_ * nres * ((zlen + CH - 1) / CH);           \
         /* a row of <= NT voxels has no halves */                                                                                  \
-        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, dense_wide<ID>() ? 2u : ID::kTab == 512 ? ((F) && !final_mask_global<ID>() ? 5u : 6u) : NT == 512 ? ((F) && !final_mask_global<ID>() ? 2u : 3u) : 4u) : 0u;                      \
+        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, dense_wide<ID>() ? (NT == 256 ? 5u : 2u) : ID::kTab == 512 ? ((F) && !final_mask_global<ID>() ? 5u : 6u) : NT == 512 ? ((F) && !final_mask_global<ID>() ? 2u : 3u) : 4u) : 0u;                      \
         hipLaunchKernelGGL((jfa_pass_dense<ID, VP_DENSE_RY, CH, NT, F, true, S>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,            \
                            (const T*)d_in, (T*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                               \
     } while (0)
@@ -1872,7 +1915,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
                                 else VP_LAUNCH_DENSE(CH, NT, false, false); } while (0)
     const bool deep = zlen % 8 == 0;
     // 8-byte ids: 8-KB tables (PX + 4 x TY + one z position table = 48 KB), 512 threads
-    if constexpr (dense_wide<ID>()) { if (deep) VP_DENSE_F(8, 512); else VP_DENSE_F(4, 512); }
+    if constexpr (dense_wide<ID>()) { if (deep) VP_DENSE_F(8, VP_DENSE_WIDE_NT); else VP_DENSE_F(4, VP_DENSE_WIDE_NT); }
     else if constexpr (ID::kTab == 512) { if (deep) VP_DENSE_F(8, 256); else VP_DENSE_F(4, 256); }
     else                           { if (deep) VP_DENSE_F(8, 512); else VP_DENSE_F(4, 256); }
 #undef VP_DENSE_F

@@ -586,7 +586,7 @@ def test_extract_records_match_numpy(engine):
                 assert np.array_equal(r2[:10].view(np.uint64), exp[:10]) and (r2[10:] == -1).all()
 
 
-@pytest.mark.parametrize("n,kind", [(512, "noise"), (512, "sparse"), (512, "mesh"), (1024, "sparse"), (288, "noise")])
+@pytest.mark.parametrize("n,kind", [(512, "noise"), (512, "sparse"), (512, "mesh"), (1024, "sparse"), (288, "noise"), (1152, "noise")])
 def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
     """Pass by pass, on the SAME input state: the packed seed ids the tile kernels write (sparse, dense with the
     v_min_f64 pair update, every k; and the first pass in its from-the-border-mask form) equal those of the one-thread-per-voxel kernel, which walks the 27
@@ -608,8 +608,9 @@ def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
         else:
             words = (rng.random(nw) < 0.004).astype(np.uint32) << rng.integers(0, 32, nw).astype(np.uint32)
         g = engine.to_device(words, np.uint32)
-    assert engine.ctx.jfa_id_bytes(fr) == 4
-    cur = torch.empty(fr.voxels, dtype=torch.int32, device=engine.device)
+    idb = engine.ctx.jfa_id_bytes(fr)
+    assert idb == (8 if n > 1024 else 4)                              # n = 1152: 8-byte ids (tile-relative ranks in the dense kernel)
+    cur = torch.empty(fr.voxels, dtype=torch.int32 if idb == 4 else torch.int64, device=engine.device)
     engine.ctx.jfa_init(fr, g.data_ptr(), None, None, cur.data_ptr())
     a = torch.empty_like(cur)
     b = torch.empty_like(cur)
@@ -635,6 +636,9 @@ def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
             assert torch.equal(a, b), (n, kind, "passes n/2 + n/4 from the mask", int((a != b).sum().item()))
         cur, a = a, cur
         k //= 2
+    del cur, a, b
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
 
 
 def test_round1_tile_kernel_path_still_matches(engine):
