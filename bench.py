@@ -156,9 +156,11 @@ def main():
                          "abbreviation of its --nnodes / --nproc-per-node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-n1024", action="store_true", help="skip the extra n = 1024 JFA block of the default run")
-    ap.add_argument("--multi", choices=["ghost", "halo"], default="ghost",
+    ap.add_argument("--multi", choices=["ghost", "halo", "hybrid"], default="ghost",
                     help="N > 1: 'ghost' = Z-slabs with recomputed ghost planes, no data-path exchange (default: a plane costs ~1 us "
-                         "to recompute and ~20 us to move over xGMI); 'halo' = Z-slabs with RCCL point-to-point halo planes before every pass")
+                         "to recompute and ~20 us to move over xGMI); 'halo' = Z-slabs with RCCL point-to-point halo planes before every pass; "
+                         "'hybrid' = ghost planes for the wide passes (k > nz/2), halos of the adjacent ranks -- sent a pass ahead, under the "
+                         "interior planes -- for the narrow ones; id buffers hold only the planes a rank touches")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,8 +210,9 @@ def main():
         elapsed, live, table = run_single(eng, frame, d_xyz, d_tri, args.steps, args.warmup, ALGO_TILED)
         planes = n
     else:
-        from cuda_mesh_voxelization_amd.slab import make_pipeline
-        pipe = make_pipeline(args.multi, eng, frame, rank, world, dist)
+        from cuda_mesh_voxelization_amd.slab import HostStagedDist, make_pipeline
+        p2p = HostStagedDist(dist) if dist.get_backend() == "gloo" else dist        # gloo (the shared-GPU test rig) moves CPU tensors only
+        pipe = make_pipeline(args.multi, eng, frame, rank, world, p2p)
 
         def step():
             pipe.voxelize(d_xyz, d_tri, algo=ALGO_TILED)

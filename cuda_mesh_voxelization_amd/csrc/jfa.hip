@@ -1530,13 +1530,25 @@ jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 // id volume is written once.  Stage A scatters the border voxels (0.7 % on the headline mesh) two positions along each axis, which
 // leaves every voxel with the slot of its pass-1 seed (or none); stage B scatters the voxels that have one (5 %) one position
 // along each axis with that seed's coordinates.  Keys and ranks as in jfa_pass_seeds; a seed's coordinates are those of its slot.
+// dev (-DVP_FIRST_TWO_TIMING, tools/first_two_stages.py): s_memtime stamps of thread 0 at the stage boundaries of every tile
+#ifdef VP_FIRST_TWO_TIMING
+constexpr unsigned kFtSlots = 1u << 17;
+__device__ unsigned long long g_ft_slots[kFtSlots][16];          // one row per workgroup (modulo): plain stores, no atomics
+#define VP_FT_STAMP(i) unsigned long long ft_t##i = 0; if (threadIdx.x == 0) ft_t##i = __builtin_amdgcn_s_memtime()
+#define VP_FT_FLUSH(tile_) do { if (threadIdx.x == 0) { const unsigned long long t_[13] = {ft_t0, ft_t1, ft_t2, ft_t3, ft_t4, ft_t5, ft_t6, ft_t7, ft_t8, ft_t9, ft_t10, ft_t11, ft_t12}; \
+        const unsigned w_ = (tile_) % kFtSlots; \
+        for (int i_ = 1; i_ < 13; ++i_) g_ft_slots[w_][i_] = t_[i_] - t_[i_ - 1]; g_ft_slots[w_][0] = 1ull; } } while (0)
+#else
+#define VP_FT_STAMP(i) do {} while (0)
+#define VP_FT_FLUSH(tile_) do {} while (0)
+#endif
 // Measured and dropped (round 3, profiles/r03/ab_step_512.txt): a PERSISTENT form of this kernel -- 8 workgroups per CU walking the
 // tile sequence, the next tile's mask words requested a tile ahead -- ran 0.493 ms against 0.404 (n = 512) and 3.44 against 2.92
 // (n = 1024).  The launch already keeps 7.5 of 8 wave slots per SIMD occupied (SQ_WAVE_CYCLES is in quad-cycles), so there was no
 // dispatch gap to close, and workgroups that start together walk their five stages in step and meet at the LDS.
-template <class ID, int XR, int NT>
+template <class ID, int XR, int NT, int TPW>
 __global__ void __launch_bounds__(NT)
-jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out)
+jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out, uint32_t tilesX, uint32_t tiles)
 {
     using T = typename ID::T;
     constexpr uint32_t SLOTS = 64u * XR;                           // slot = ((plane * 4 + row) * 4 + segment) * XR + residue
@@ -1550,12 +1562,12 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
     __shared__ uint16_t list[SLOTS];
     __shared__ uint32_t cnt[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, N = f.n, k = N / 4u;
-    const uint32_t rx0 = blockIdx.x * XR, ry = blockIdx.y, rz = blockIdx.z;
-    if (tid < 2) cnt[tid] = 0;
-    __syncthreads();
-    auto coords = [&](uint32_t s, uint32_t& x, uint32_t& y, uint32_t& z) {
-        x = rx0 + s % XR + ((s / XR) & 3u) * k; y = ry + ((s / (4u * XR)) & 3u) * k; z = rz + (s / (16u * XR)) * k;
-    };
+    // slot tid + i NT = row-plane (rpb + i G) x column `col` (see jfa_pass_seeds): row addresses are scalar work
+    constexpr uint32_t RPW = 4u * XR;
+    constexpr uint32_t G = NT / RPW;
+    static_assert(NT % RPW == 0 && RPW % 64u == 0, "a wave must stay inside one row-plane");
+    const uint32_t col = tid % RPW;
+    const uint32_t rpb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / RPW));
     // wave-cooperative append of the slots whose flag is set (one reservation per wave)
     auto append = [&](const bool (&flag)[PER], uint32_t& counter) {
         unsigned long long ms[PER];
@@ -1571,58 +1583,99 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
             base += (uint32_t)__popcll(ms[i]);
         }
     };
-    // every entry of the list proposes the seed that sits at slot q (its coordinates are those of q) from slot s
-    auto scatter = [&](uint32_t nlist, auto seed_slot, auto step) {
-        constexpr int STEP = decltype(step)::value;
-        for (uint32_t e = tid; e < nlist; e += NT) {
-            const uint32_t s = list[e];
-            uint32_t qx, qy, qz;
-            coords(seed_slot(s), qx, qy, qz);
-            propose<XR, STEP>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k);
-        }
+    auto tile_origin = [&](uint32_t t, uint32_t& rx0, uint32_t& ry, uint32_t& rz) {
+        rx0 = (t % tilesX) * XR; const uint32_t q = t / tilesX; ry = q % k; rz = q / k;
     };
-
-    // slot tid + i NT = row-plane (rpb + i G) x column `col` (see jfa_pass_seeds): row addresses are scalar work
-    constexpr uint32_t RPW = 4u * XR;
-    constexpr uint32_t G = NT / RPW;
-    static_assert(NT % RPW == 0 && RPW % 64u == 0, "a wave must stay inside one row-plane");
-    const uint32_t col = tid % RPW, myx = rx0 + col % XR + (col / XR) * k;
-    const bool xin = rx0 + col % XR < k;
-    const uint32_t rpb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / RPW));
-    // ---- stage A: border voxels -> pass with k = n/2
-    bool flag[PER];
+    // A workgroup works through TPW consecutive tiles (default 1).  Their border words -- the only thing read from memory, and 37 % of
+    // a one-tile workgroup's life spent waiting for them (profiles/r03/first_two_stages_n512.txt) -- are ALL requested before the
+    // first tile is touched.  (Nothing is loaded inside the tile loop, so no wait in it ever covers the stores of the tile before:
+    // that is what made the persistent form of round 3 slower.)  More tiles per workgroup bought nothing, see VP_FIRST_TWO_TPW.
+    const uint32_t tile0 = (blockIdx.x) * TPW;
+    uint32_t mw[TPW][PER];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const uint32_t s = tid + (uint32_t)i * NT;
-        const uint32_t rp = rpb + (uint32_t)i * G, y = ry + (rp & 3u) * k, z = rz + (rp >> 2) * k;
-        flag[i] = xin && ((border[((size_t)z * N + y) * f.w + (myx >> 5)] >> (myx & 31u)) & 1u);
-        keys[s] = kEmpty;
-        idOf[s] = ID::pack(myx, y, z);
+    for (int u = 0; u < TPW; ++u) {
+        uint32_t rx0, ry, rz;
+        tile_origin(min(tile0 + u, tiles - 1u), rx0, ry, rz);
+        const uint32_t myx = rx0 + col % XR + (col / XR) * k;
+        const bool xin = rx0 + col % XR < k;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t rp = rpb + (uint32_t)i * G, y = ry + (rp & 3u) * k, z = rz + (rp >> 2) * k;
+            mw[u][i] = xin ? border[((size_t)z * N + y) * f.w + (myx >> 5)] : 0u;
+        }
     }
-    append(flag, cnt[0]);
-    __syncthreads();
-    scatter(cnt[0], [](uint32_t s) { return s; }, std::integral_constant<int, 2>{});
-    __syncthreads();
-    // ---- stage B: voxels that have a seed now -> pass with k = n/4
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const uint32_t s = tid + (uint32_t)i * NT;
-        const unsigned long long key = keys[s];
-        flag[i] = key != kEmpty;
-        seedOf[s] = flag[i] ? (uint16_t)((uint32_t)key & 0x07FFFFFFu) : kNoSeed;
-        keys[s] = kEmpty;                                          // own slots only: nobody else touches them before the barrier
-    }
-    append(flag, cnt[1]);
-    __syncthreads();
-    scatter(cnt[1], [&](uint32_t s) { return (uint32_t)seedOf[s]; }, std::integral_constant<int, 1>{});
-    __syncthreads();
+    for (int u = 0; u < TPW; ++u) {
+        const uint32_t tile = tile0 + u;
+        if (tile >= tiles) break;                                  // uniform
+        uint32_t rx0, ry, rz;
+        tile_origin(tile, rx0, ry, rz);
+        const uint32_t myx = rx0 + col % XR + (col / XR) * k;
+        const bool xin = rx0 + col % XR < k;
+        VP_FT_STAMP(0);
+        if (tid < 2) cnt[tid] = 0;
+        __syncthreads();                                           // also: the previous tile's output stage has read keys / seedOf / idOf
+        VP_FT_STAMP(1);
+        auto coords = [&](uint32_t s, uint32_t& x, uint32_t& y, uint32_t& z) {
+            x = rx0 + s % XR + ((s / XR) & 3u) * k; y = ry + ((s / (4u * XR)) & 3u) * k; z = rz + (s / (16u * XR)) * k;
+        };
+        // every entry of the list proposes the seed that sits at slot q (its coordinates are those of q) from slot s
+        auto scatter = [&](uint32_t nlist, auto seed_slot, auto step) {
+            constexpr int STEP = decltype(step)::value;
+            for (uint32_t e = tid; e < nlist; e += NT) {
+                const uint32_t s = list[e];
+                uint32_t qx, qy, qz;
+                coords(seed_slot(s), qx, qy, qz);
+                propose<XR, STEP>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k);
+            }
+        };
+        // ---- stage A: border voxels -> pass with k = n/2
+        bool flag[PER];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        if (!xin) continue;
-        const unsigned long long key = keys[tid + (uint32_t)i * NT];
-        const T id = key == kEmpty ? ID::none() : idOf[seedOf[(uint32_t)key & 0x07FFFFFFu]];
-        const uint32_t rp = rpb + (uint32_t)i * G;
-        out[((size_t)(rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx] = id;
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t s = tid + (uint32_t)i * NT;
+            const uint32_t rp = rpb + (uint32_t)i * G, y = ry + (rp & 3u) * k, z = rz + (rp >> 2) * k;
+            flag[i] = xin && ((mw[u][i] >> (myx & 31u)) & 1u);
+            keys[s] = kEmpty;
+            idOf[s] = ID::pack(myx, y, z);
+        }
+        VP_FT_STAMP(2);                                            // border words arrived (first tile of the workgroup), keys / ids written
+        append(flag, cnt[0]);
+        VP_FT_STAMP(3);
+        __syncthreads();
+        VP_FT_STAMP(4);
+        scatter(cnt[0], [](uint32_t s) { return s; }, std::integral_constant<int, 2>{});
+        VP_FT_STAMP(5);
+        __syncthreads();
+        VP_FT_STAMP(6);
+        // ---- stage B: voxels that have a seed now -> pass with k = n/4
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t s = tid + (uint32_t)i * NT;
+            const unsigned long long key = keys[s];
+            flag[i] = key != kEmpty;
+            seedOf[s] = flag[i] ? (uint16_t)((uint32_t)key & 0x07FFFFFFu) : kNoSeed;
+            keys[s] = kEmpty;                                      // own slots only: nobody else touches them before the barrier
+        }
+        VP_FT_STAMP(7);
+        append(flag, cnt[1]);
+        VP_FT_STAMP(8);
+        __syncthreads();
+        VP_FT_STAMP(9);
+        scatter(cnt[1], [&](uint32_t s) { return (uint32_t)seedOf[s]; }, std::integral_constant<int, 1>{});
+        VP_FT_STAMP(10);
+        __syncthreads();
+        VP_FT_STAMP(11);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (!xin) continue;
+            const unsigned long long key = keys[tid + (uint32_t)i * NT];
+            const T id = key == kEmpty ? ID::none() : idOf[seedOf[(uint32_t)key & 0x07FFFFFFu]];
+            const uint32_t rp = rpb + (uint32_t)i * G;
+            out[((size_t)(rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx] = id;
+        }
+        VP_FT_STAMP(12);
+        VP_FT_FLUSH(tile);
     }
 }
 
@@ -1734,19 +1787,25 @@ bool jfa_can_fuse_first_two(const Frame& f, int algo)
     return enabled && jfa_can_start_from_mask(f, algo) && f.z0 == 0 && f.z1 == f.n && f.n / 8 >= 1;
 }
 
+#ifndef VP_FIRST_TWO_TPW
+#define VP_FIRST_TWO_TPW 1        // tiles per workgroup.  Measured (profiles/r03/ab_tpw_*.txt): 1 / 2 / 4 / 8 tiles = 0.371 / 0.373 / 0.370 / 0.406 ms
+                                  // at n = 512, 2.78 / 2.81 / 2.74 / 3.23 at n = 1024 -- the other resident workgroups already cover the load
+                                  // latency; what did pay is the ONE-dimensional launch these forms share: 0.405 -> 0.371 ms, 2.92 -> 2.78
+#endif
 int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out)
 {
     ProfScope p(ctx, VP_K_JFA_FIRST);
     const uint32_t k = f.n / 4;
     // tile = 4 x 4 x 4 chain positions x XR residues.  Measured (profiles/r02/ab33.txt): 16 residues x 256 threads is the best
     // shape at n = 512 (0.404 ms against 0.183 + 0.307 for the two separate kernels; 32 x 512: 0.436), 32 x 512 at n = 1024
-    // (2.94 ms against 1.39 + 2.12; 16 x 256: 3.41).  The kernel is bound by the latency of its stages, not by bytes or VALU.
+    // (2.94 ms against 1.39 + 2.12; 16 x 256: 3.41).  A workgroup takes VP_FIRST_TWO_TPW consecutive tiles.
     const bool small = f.n <= 512;
     const uint32_t xr = small ? 16u : 32u;
-    const dim3 grid((k + xr - 1) / xr, k, k);
-    if (wide(f))    hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out);
-    else if (small) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out);
-    else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out);
+    const uint32_t tilesX = (k + xr - 1) / xr, tiles = tilesX * k * k;
+    const dim3 grid((tiles + VP_FIRST_TWO_TPW - 1) / VP_FIRST_TWO_TPW);
+    if (wide(f))    hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles);
+    else if (small) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles);
+    else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles);
     VP_HIP(hipGetLastError());
     return 0;
 }
@@ -1985,6 +2044,19 @@ int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const
     VP_HIP(hipGetLastError());
     return 0;
 }
+
+#ifdef VP_FIRST_TWO_TIMING
+extern "C" int vp_dev_first_two_times(unsigned long long* out16, int reset)
+{
+    static std::vector<unsigned long long> host((size_t)kFtSlots * 16);
+    if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_ft_slots), host.size() * 8) != hipSuccess) return 1;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    for (size_t w = 0; w < kFtSlots; ++w)
+        for (int i = 0; i < 16; ++i) out16[i] += host[w * 16 + i];
+    if (reset) { std::fill(host.begin(), host.end(), 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(g_ft_slots), host.data(), host.size() * 8) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 }  // namespace vp
 #endif  // VP_ISA_PROBE

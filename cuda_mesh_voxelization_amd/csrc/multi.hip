@@ -272,8 +272,9 @@ int jfa_ghost(vp_multi* m, float fill, int algo)
         if (maskStart) VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
         else           VP_TRY(vp_jfa_init(me.ctx, &G, words, nullptr, nullptr, a));
         size_t skip = 0;
-        // the first two passes as ONE whole-grid launch where the second pass would cover most of the grid anyway
-        if (maskStart && last >= 2 && vp_jfa_can_fuse_first_two(&G, algo) && (uint64_t)(regs[1].b1 - regs[1].b0) * 100 >= 65ull * n) {
+        // the first two passes as ONE whole-grid launch where the second pass would cover most of the grid anyway: break-even of the
+        // measured kernel times at 61 % of the grid (n = 512) and 73 % (n = 1024), as in slab.py: fused_first_two_threshold()
+        if (maskStart && last >= 2 && vp_jfa_can_fuse_first_two(&G, algo) && (uint64_t)(regs[1].b1 - regs[1].b0) * 100 >= (n <= 512 ? 65ull : 73ull) * n) {
             VP_TRY(vp_jfa_first_two(me.ctx, &G, (const uint32_t*)me.border.ptr, b));
             std::swap(a, b);
             skip = 2;

@@ -80,6 +80,24 @@ class HipSlabBackend:
         src, minus, plus, dst = self._global_ptrs(region, k, src_full, dst_full)
         self.ctx.jfa_pass(region, k, src, minus, plus, dst, algo)
 
+    # -- id buffers that hold the planes [lo, hi) only, addressed by global plane (HybridSlabPipeline) --------------
+    def _window_ptrs(self, region, k, src, dst, lo):
+        pb = region.n * region.n * self.ctx.jfa_id_bytes(region)
+        s, d = src.data_ptr() - lo * pb, dst.data_ptr() - lo * pb      # where plane 0 would be
+        return (s + region.z0 * pb, s + (region.z0 - k) * pb, s + max(region.z1, region.z0 + k) * pb, d + region.z0 * pb)
+
+    def jfa_pass_window(self, region, k, src, dst, lo, algo):
+        a, minus, plus, out = self._window_ptrs(region, k, src, dst, lo)
+        self.ctx.jfa_pass(region, k, a, minus, plus, out, algo)
+
+    def jfa_last_pass_window(self, region, src, scratch, lo, words_region, fill, sdf, algo):
+        a, minus, plus, out = self._window_ptrs(region, 1, src, scratch, lo)
+        self.ctx.jfa_last_pass(region, a, minus, plus, out, words_region.data_ptr(), fill, sdf.data_ptr(), algo)
+
+    def jfa_first_pass_window(self, region, border_full, dst, lo):
+        pb = region.n * region.n * self.ctx.jfa_id_bytes(region)
+        self.ctx.jfa_first_pass(region, border_full.data_ptr(), dst.data_ptr() + (region.z0 - lo) * pb)
+
     def can_start_from_mask(self, frame, algo):
         return self.ctx.jfa_can_start_from_mask(frame, algo)
 
@@ -99,6 +117,45 @@ class HipSlabBackend:
     def jfa_last_pass_global(self, region, src_full, scratch_full, words_region, fill, sdf, algo):
         src, minus, plus, scratch = self._global_ptrs(region, 1, src_full, scratch_full)
         self.ctx.jfa_last_pass(region, src, minus, plus, scratch, words_region.data_ptr(), fill, sdf.data_ptr(), algo)
+
+
+class HostStagedDist:
+    """Test rigs only (bench.py with VP_BENCH_SHARE_GPU=1: ranks share a GPU and rendezvous over gloo, whose send / recv take CPU
+    tensors): the point-to-point subset the pipelines use, staged through host memory.  On a real node the pipelines get
+    torch.distributed itself (backend "nccl" = RCCL) and device tensors travel directly."""
+    isend, irecv = "isend", "irecv"
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Req:
+        def __init__(self, reqs, tensor=None, host=None):
+            self.reqs, self.tensor, self.host = reqs, tensor, host
+
+        def wait(self):
+            for r in self.reqs:
+                r.wait()
+            if self.tensor is not None:
+                self.tensor.copy_(self.host)
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def batch_isend_irecv(self, ops):
+        out = []
+        for o in ops:
+            if o.op == "isend":
+                host = o.tensor.cpu()
+                out.append(self._Req([self.dist.isend(host, o.peer)], None, host))
+        for o in ops:
+            if o.op == "irecv":
+                host = torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
+                out.append(self._Req([self.dist.irecv(host, o.peer)], o.tensor, host))
+        return out
+
+    def barrier(self):
+        self.dist.barrier()
 
 
 def slab_range(n: int, rank: int, world: int):
@@ -262,6 +319,12 @@ def ghost_regions(n: int, rank: int, world: int):
     return out
 
 
+def fused_first_two_threshold(n: int) -> int:
+    """Per cent of the grid the second pass of a rank must cover before the whole-grid launch of the first two passes is the cheaper
+    way to run them (measured kernel times, see GhostSlabPipeline.jfa; the same rule lives in csrc/multi.hip)."""
+    return 65 if n <= 512 else 73
+
+
 class GhostSlabPipeline:
     """Z-slab strong scaling WITHOUT halo exchange.
 
@@ -321,10 +384,11 @@ class GhostSlabPipeline:
         else:
             self.be.jfa_init(self.global_frame, self.words, None, None, a)
         # The first two passes (k = n/2, n/4) as ONE launch over the whole grid (vp_jfa_first_two) where the second pass would cover
-        # most of the grid anyway: 0.40 ms at n = 512 against 0.18 for the first pass + 0.36 x the covered fraction for the second.
+        # most of the grid anyway: 0.40 ms at n = 512 against 0.18 for the first pass + 0.36 x the covered fraction for the second
+        # (break-even at 61 %), 2.94 ms at n = 1024 against 1.39 + 2.12 x the fraction (73 %): fused_first_two_threshold().
         skip = 0
         if (mask_start and last >= 2 and hasattr(self.be, "can_fuse_first_two") and self.be.can_fuse_first_two(self.global_frame, algo)
-                and (self.regions[1][2] - self.regions[1][1]) * 100 >= 65 * self.global_frame.n):
+                and (self.regions[1][2] - self.regions[1][1]) * 100 >= fused_first_two_threshold(self.global_frame.n) * self.global_frame.n):
             self.be.jfa_first_two_global(self.global_frame, self.border, b)
             a, b = b, a
             skip = 2
@@ -347,11 +411,177 @@ class GhostSlabPipeline:
 
 
 # =============================================================================================
+# Hybrid: ghost planes where planes are cheap to recompute and dear to move, halos where it is the other way round
+# =============================================================================================
+def hybrid_plan(n: int, rank: int, world: int):
+    """(wide, narrow): the passes with k > nz/2 as [(k, b0, b1)] -- run on the slab widened by the reach of the LATER WIDE passes
+    only (rounded to 8 planes, clipped) -- and the steps k <= nz/2, which run on the bare slab behind a halo of k planes from each
+    adjacent rank.  world == 1: every pass is 'wide' with the whole grid as its region."""
+    z0, z1 = slab_range(n, rank, world)
+    H = (z1 - z0) // 2 if world > 1 else 0
+    ks = []
+    k = n // 2
+    while k >= 1:
+        ks.append(k)
+        k //= 2
+    wide_ks = [k for k in ks if k > H]
+    wide = []
+    for i, k in enumerate(wide_ks):
+        g = sum(wide_ks[i + 1:])
+        wide.append((k, max(0, (z0 - g) // 8 * 8), min(n, -((-(z1 + g)) // 8) * 8)))
+    return wide, [k for k in ks if k <= H]
+
+
+class HybridSlabPipeline:
+    """Z-slabs, the two ways of feeding a pass mixed by what each costs.
+
+    A pass with step k needs the planes z +- k.  For the WIDE passes (k > nz/2: whole slabs of distant ranks) the planes are
+    recomputed as ghost planes, as in GhostSlabPipeline -- but only as far as the later WIDE passes reach, because the NARROW
+    passes (k <= nz/2) fetch their k halo planes from the two adjacent ranks (point-to-point, one send and one receive per side
+    and pass).  The halos of the NEXT pass are sent as soon as the boundary planes of the current one are computed -- those
+    sub-slabs are launched first -- so the transfer runs under the interior planes of the current pass.
+
+    Plane-passes per rank: sum of the wide regions + nz per narrow pass (n = 1024, 8 ranks: 2,304 against 3,220 for ghost planes
+    alone and 1,280 ideal); received: sum of the narrow k = nz - 1 planes per side and job.  Id buffers hold the planes of the
+    largest wide region (not the grid); the narrow passes run in place inside them.
+    """
+
+    def __init__(self, backend, frame: Frame, rank: int, world: int, dist):
+        self.be, self.dist = backend, dist
+        self.rank, self.world = rank, world
+        self.global_frame = frame
+        self.z0, self.z1 = slab_range(frame.n, rank, world)
+        self.nz = self.z1 - self.z0
+        self.frame = frame.slab(self.z0, self.z1)
+        self.wide, self.narrow = hybrid_plan(frame.n, rank, world)
+        idw = self.be.id_words(frame) if hasattr(self.be, "id_words") else 1
+        self.plane_ids = frame.n * frame.n * idw
+        self.plane_words = frame.n * frame.n // 32
+        self.words = self.be.empty_u32(frame.words)                  # whole grid: every rank rasterises it (0.06 ms at n = 512)
+        self.sdf = self.be.empty_f32(self.frame.voxels)
+        self.border = None
+        self._bufs = {}
+        self.bytes_received = 0
+        self.planes_computed = sum(b1 - b0 for _, b0, b1 in self.wide) + self.nz * len(self.narrow)
+
+    def describe(self):
+        return "z-slab x%d, hybrid: ghost planes for k > nz/2, p2p halos under the interior planes for k <= nz/2" % self.world
+
+    def report(self):
+        n, passes = self.global_frame.n, len(self.wide) + len(self.narrow)
+        return {"pipeline": "hybrid", "slab_planes": self.nz, "wide_regions": [[k, b0, b1] for k, b0, b1 in self.wide],
+                "narrow_steps": list(self.narrow), "plane_passes_this_rank": int(self.planes_computed),
+                "plane_passes_one_gpu": n * passes, "work_ceiling_speedup": round(n * passes / self.planes_computed, 3),
+                "bytes_received_total": int(self.bytes_received), "id_buffer_planes": getattr(self, "window", None)}
+
+    def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
+        out = self.words if out is None else out
+        self.be.voxelize(self.global_frame, out, d_xyz, d_tri, algo)
+        return out
+
+    def csg(self, other, op: int):
+        self.be.csg(self.words, other, op)
+        return self.words
+
+    # -- buffers: planes [lo, hi) of the id volume, twice ------------------------------------
+    def _window(self, mask_start: bool):
+        n, H = self.global_frame.n, (self.nz // 2 if self.world > 1 else 0)
+        lo, hi = max(0, self.z0 - H), min(n, self.z1 + H)            # room for the halos of the narrow passes
+        for i, (k, b0, b1) in enumerate(self.wide):
+            lo, hi = min(lo, b0), max(hi, b1)
+            if i > 0 or not mask_start:                               # every pass that reads ids reads k planes beyond its region
+                lo, hi = min(lo, max(0, b0 - k)), max(hi, min(n, b1 + k))
+        key = (lo, hi)
+        if key not in self._bufs:
+            self._bufs = {key: [self.be.empty_u32((hi - lo) * self.plane_ids) for _ in range(2)]}
+        self.window = [lo, hi]
+        return lo, hi, self._bufs[key]
+
+    def _planes(self, buf, lo, g0, g1):
+        return buf[(g0 - lo) * self.plane_ids:(g1 - lo) * self.plane_ids]
+
+    def _start_exchange(self, k: int, buf, lo):
+        """Halo of k planes for the pass with step k on the state in `buf`: my bottom / top k planes go down / up, theirs land
+        in the planes just outside my slab.  Returns the requests (waited for right before the pass that needs them)."""
+        d, P = self.dist, self.dist.P2POp
+        ops = []
+        if self.rank > 0:
+            ops.append(P(d.isend, self._planes(buf, lo, self.z0, self.z0 + k), self.rank - 1))
+            ops.append(P(d.irecv, self._planes(buf, lo, self.z0 - k, self.z0), self.rank - 1))
+            self.bytes_received += k * self.plane_ids * 4
+        if self.rank < self.world - 1:
+            ops.append(P(d.isend, self._planes(buf, lo, self.z1 - k, self.z1), self.rank + 1))
+            ops.append(P(d.irecv, self._planes(buf, lo, self.z1, self.z1 + k), self.rank + 1))
+            self.bytes_received += k * self.plane_ids * 4
+        return d.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def _wait(reqs):
+        for r in reqs:
+            r.wait()
+
+    def jfa(self, algo=ALGO_TILED, fill=-math.inf, out=None):
+        out = self.sdf if out is None else out
+        G, n, z0, z1, pw = self.global_frame, self.global_frame.n, self.z0, self.z1, self.plane_words
+        mask_start = (bool(self.wide) and len(self.wide) + len(self.narrow) > 1 and hasattr(self.be, "can_start_from_mask")
+                      and self.be.can_start_from_mask(G, algo))
+        lo, hi, (a, b) = self._window(mask_start)
+        slab_words = self.words[z0 * pw:z1 * pw]
+        npass = len(self.wide) + len(self.narrow)
+        # ---- wide passes: ghost planes
+        start = 0
+        if mask_start:
+            if self.border is None:
+                self.border = self.be.empty_u32(G.words)
+            self.be.surface(G, self.words, self.border)
+            k, b0, b1 = self.wide[0]
+            self.be.jfa_first_pass_window(G.slab(b0, b1), self.border, b, lo)
+            a, b = b, a
+            start = 1
+        else:
+            below = self.words[(lo - 1) * pw:lo * pw] if lo > 0 else None
+            above = self.words[hi * pw:(hi + 1) * pw] if hi < n else None
+            self.be.jfa_init(G.slab(lo, hi), self.words[lo * pw:hi * pw], below, above, a)
+        for i in range(start, len(self.wide)):
+            k, b0, b1 = self.wide[i]
+            if i == npass - 1:                                        # one rank: the last pass is a wide one
+                self.be.jfa_last_pass_window(G.slab(b0, b1), a, b, lo, slab_words, fill, out, algo)
+                return out
+            self.be.jfa_pass_window(G.slab(b0, b1), k, a, b, lo, algo)
+            a, b = b, a
+        # ---- narrow passes: halos from the adjacent ranks, the next pass's halo sent under this pass's interior planes
+        pend = None
+        for idx, k in enumerate(self.narrow):
+            if pend is None:
+                pend = self._start_exchange(k, a, lo)
+            self._wait(pend)
+            pend = None
+            if idx == len(self.narrow) - 1:
+                self.be.jfa_last_pass_window(self.frame, a, b, lo, slab_words, fill, out, algo)
+                return out
+            nk = self.narrow[idx + 1]
+            nb = -(-nk // 8) * 8                                       # sub-slabs are cut at multiples of 8 planes
+            if 2 * nb >= self.nz:
+                self.be.jfa_pass_window(self.frame, k, a, b, lo, algo)
+                pend = self._start_exchange(nk, b, lo)
+            else:
+                self.be.jfa_pass_window(G.slab(z0, z0 + nb), k, a, b, lo, algo)          # what the neighbours need next: first
+                self.be.jfa_pass_window(G.slab(z1 - nb, z1), k, a, b, lo, algo)
+                pend = self._start_exchange(nk, b, lo)
+                self.be.jfa_pass_window(G.slab(z0 + nb, z1 - nb), k, a, b, lo, algo)     # the transfer runs under this
+            a, b = b, a
+        return out
+
+
+# =============================================================================================
 def make_pipeline(kind: str, engine, frame: Frame, rank: int, world: int, dist):
-    """bench.py / callers: 'ghost' (no exchange) or 'halo' (RCCL point-to-point halos) on the HIP backend."""
+    """bench.py / callers: 'ghost' (no exchange), 'halo' (RCCL point-to-point halos before every pass) or 'hybrid' (ghost planes
+    for the wide passes, overlapped halos for the narrow ones) on the HIP backend."""
     be = HipSlabBackend(engine)
     if kind == "ghost":
         return GhostSlabPipeline(be, frame, rank, world)
     if kind == "halo":
         return SlabPipeline(be, frame, rank, world, dist)
+    if kind == "hybrid":
+        return HybridSlabPipeline(be, frame, rank, world, dist)
     raise ValueError("unknown multi-GPU pipeline %r" % kind)

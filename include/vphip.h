@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 2
+#define VP_ABI_VERSION 3
 
 enum {
     VP_OK = 0,

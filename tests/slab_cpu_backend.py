@@ -101,6 +101,27 @@ class CpuSlabBackend:
         ids = torch.from_numpy(_np(scratch_full).reshape(n, n, n)[region.z0:region.z1].reshape(-1).copy())
         self.jfa_finalize(region, words_region, ids, fill, sdf)
 
+    # -- buffers that hold the planes [lo, hi) only (HybridSlabPipeline) --
+    def jfa_pass_window(self, region, k, src, dst, lo, algo):
+        n = region.n
+        A = _np(src).reshape(-1, n, n)
+        hi = lo + A.shape[0]
+        none_plane = np.full((n, n), NONE, np.int32)
+
+        def plane(zg):
+            if zg < 0 or zg >= n:
+                return none_plane
+            assert lo <= zg < hi, "pass with step %d on [%d, %d) reads plane %d outside the window [%d, %d)" % (k, region.z0, region.z1, zg, lo, hi)
+            return A[zg - lo]
+
+        _np(dst).reshape(-1, n, n)[region.z0 - lo:region.z1 - lo] = self._pass(region, k, plane)
+
+    def jfa_last_pass_window(self, region, src, scratch, lo, words_region, fill, sdf, algo):
+        n = region.n
+        self.jfa_pass_window(region, 1, src, scratch, lo, algo)
+        ids = torch.from_numpy(_np(scratch).reshape(-1, n, n)[region.z0 - lo:region.z1 - lo].reshape(-1).copy())
+        self.jfa_finalize(region, words_region, ids, fill, sdf)
+
     def _pass(self, frame, k, plane):
         n, z0, z1 = frame.n, frame.z0, frame.z1
         nz = z1 - z0

@@ -152,3 +152,79 @@ def test_ghost_regions_feed_each_other():
                 r0, r1 = max(0, u0 - k), min(n, u1 + k)                    # what those planes read
                 assert prev_valid[0] <= r0 and r1 <= prev_valid[1], (n, world, rank, k)
                 prev_valid = (u0, u1)
+
+
+def _hybrid_worker(rank, world, port, n, asset, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuda_mesh_voxelization_amd import mesh as M
+        from cuda_mesh_voxelization_amd.capi import Frame
+        from cuda_mesh_voxelization_amd.slab import HybridSlabPipeline
+        from slab_cpu_backend import CpuSlabBackend
+        mesh = M.import_mesh(M.asset(asset))
+        origin, vs = M.frame([mesh[0]], n)
+        pipe = HybridSlabPipeline(CpuSlabBackend(mesh), Frame.make(n, vs, origin), rank, world, dist)
+        pipe.voxelize(None, None)
+        sdf = pipe.jfa()
+        dist.barrier()
+        np.save(os.path.join(outdir, "sdf_%d.npy" % rank), sdf.numpy())
+        np.save(os.path.join(outdir, "rep_%d.npy" % rank), np.array([pipe.bytes_received, pipe.planes_computed, pipe.window[0], pipe.window[1]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,asset", [(2, 32, "sphere.obj"), (4, 32, "torus.obj"), (2, 64, "bunny.obj"), (4, 64, "torus.obj")])
+def test_hybrid_slab_pipeline_matches_single_domain_oracle(tmp_path, world, n, asset):
+    """Ghost planes for the wide passes, p2p halos (sent a pass ahead, under the interior planes) for the narrow ones, id buffers
+    that hold only the planes the rank touches: the numpy backend asserts that no pass reads outside that window."""
+    sys.path.insert(0, ROOT)
+    from cuda_mesh_voxelization_amd import mesh as M
+    from cuda_mesh_voxelization_amd.slab import hybrid_plan
+    from oracle import oracle as O
+    mp.spawn(_hybrid_worker, args=(world, _free_port(), n, asset, str(tmp_path)), nprocs=world, join=True)
+    xyz, tri = M.import_mesh(M.asset(asset))
+    origin, vs = M.frame([xyz], n)
+    exp = O.jfa(O.voxelize(xyz, tri, n, vs, origin), n, vs, origin)
+    got = np.concatenate([np.load(tmp_path / ("sdf_%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    nz = n // world
+    for r in range(world):
+        rx, planes, lo, hi = [int(v) for v in np.load(tmp_path / ("rep_%d.npy" % r))]
+        wide, narrow = hybrid_plan(n, r, world)
+        sides = (r > 0) + (r < world - 1)
+        assert rx == sides * sum(narrow) * n * n * 4                  # k planes per side and narrow pass, nothing else
+        assert planes == sum(b1 - b0 for _, b0, b1 in wide) + nz * len(narrow)
+        assert 0 <= lo <= r * nz and (r + 1) * nz <= hi <= n
+
+
+def test_hybrid_plan_feeds_itself():
+    """Wide regions: each produces the slab widened by the reach of the later WIDE passes and reads only what the previous one
+    produced; the last wide pass leaves exactly the slab; narrow steps are the k <= nz/2 and end with 1; plane-passes per rank lie
+    between the ideal n/G per pass and the ghost-plane count."""
+    sys.path.insert(0, ROOT)
+    from cuda_mesh_voxelization_amd.slab import ghost_regions, hybrid_plan, slab_range
+    for n, world in ((64, 2), (64, 8), (512, 4), (512, 8), (1024, 4), (1024, 8), (2048, 8), (96, 2), (96, 4)):
+        nz = n // world
+        for rank in range(world):
+            z0, z1 = slab_range(n, rank, world)
+            wide, narrow = hybrid_plan(n, rank, world)
+            ks = [k for k, _, _ in wide] + narrow
+            assert ks == sorted(ks, reverse=True) and ks[0] == n // 2 and ks[-1] == 1 and len(ks) == len(set(ks))
+            assert all(k > nz // 2 for k, _, _ in wide) and all(k <= nz // 2 for k in narrow) and narrow
+            assert wide[-1][1:] == (z0, z1)
+            valid = (0, n)
+            for i, (k, b0, b1) in enumerate(wide):
+                g = sum(kk for kk, _, _ in wide[i + 1:])
+                u0, u1 = max(0, z0 - g), min(n, z1 + g)
+                assert b0 % 8 == 0 and b1 % 8 == 0 and 0 <= b0 <= u0 < u1 <= b1 <= n
+                assert valid[0] <= max(0, u0 - k) and min(n, u1 + k) <= valid[1]
+                valid = (u0, u1)
+            work = sum(b1 - b0 for _, b0, b1 in wide) + nz * len(narrow)
+            ghost = sum(b1 - b0 for _, b0, b1 in ghost_regions(n, rank, world))
+            assert nz * len(ks) <= work <= ghost
+    wide, narrow = hybrid_plan(64, 0, 1)
+    assert narrow == [] and [r[1:] for r in wide] == [(0, 64)] * 6

@@ -12,7 +12,7 @@ import torch
 from cuda_mesh_voxelization_amd import mesh as M
 from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, Frame
 from cuda_mesh_voxelization_amd.pipeline import Engine
-from cuda_mesh_voxelization_amd.slab import HipSlabBackend, SlabPipeline
+from cuda_mesh_voxelization_amd.slab import HipSlabBackend, HybridSlabPipeline, SlabPipeline
 
 pytestmark = pytest.mark.gpu
 
@@ -49,12 +49,13 @@ class LoopbackDist:
         return reqs
 
 
-def _run_slabs(world, frame, xyz, tri, algo):
+def _run_slabs(world, frame, xyz, tri, algo, kind="halo"):
     queues = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
     engines = [Engine(0) for _ in range(world)]
     pipes, errors = [], []
     for r in range(world):
-        pipes.append(SlabPipeline(HipSlabBackend(engines[r]), frame, r, world, LoopbackDist(r, queues)))
+        cls = SlabPipeline if kind == "halo" else HybridSlabPipeline
+        pipes.append(cls(HipSlabBackend(engines[r]), frame, r, world, LoopbackDist(r, queues)))
     meshes = [engines[r].mesh_to_device(xyz, tri) for r in range(world)]
 
     def work(r):
@@ -72,7 +73,11 @@ def _run_slabs(world, frame, xyz, tri, algo):
     for t in threads:
         t.join(300)
     assert not errors, errors
-    words = np.concatenate([Engine.words_to_numpy(p.words) for p in pipes])
+    if kind == "hybrid":                                         # every rank holds the whole bitmask there
+        pw = frame.n * frame.n // 32
+        words = np.concatenate([Engine.words_to_numpy(p.words[p.z0 * pw:p.z1 * pw]) for p in pipes])
+    else:
+        words = np.concatenate([Engine.words_to_numpy(p.words) for p in pipes])
     sdf = np.concatenate([p.sdf.cpu().numpy() for p in pipes])
     return words, sdf
 
@@ -89,6 +94,23 @@ def test_slabs_equal_whole_grid(engine, world, n, name, algo):
     ref_s = engine.jfa(fr, ref_w, algo=algo).cpu().numpy()
     ref_w = engine.words_to_numpy(ref_w)
     words, sdf = _run_slabs(world, fr, xyz, tri, algo)
+    assert np.array_equal(words, ref_w)
+    assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,n,name,algo", [(2, 64, "bunny.obj", ALGO_TILED), (4, 64, "torus.obj", ALGO_NAIVE), (2, 256, "bimba.obj", ALGO_TILED),
+                                               (8, 256, "bunny.obj", ALGO_TILED), (4, 512, "bimba.obj", ALGO_TILED), (8, 512, "bunny.obj", ALGO_TILED)])
+def test_hybrid_slabs_equal_whole_grid(engine, world, n, name, algo):
+    """HybridSlabPipeline with the real kernels: ghost planes for the wide passes inside id buffers that hold only the planes the rank
+    touches (window addressing), sub-slab launches (boundary planes first) and halos sent a pass ahead for the narrow ones."""
+    xyz, tri = M.import_mesh(M.asset(name))
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    ref_w = engine.voxelize(fr, dx, dt, algo=algo)
+    ref_s = engine.jfa(fr, ref_w, algo=algo).cpu().numpy()
+    ref_w = engine.words_to_numpy(ref_w)
+    words, sdf = _run_slabs(world, fr, xyz, tri, algo, kind="hybrid")
     assert np.array_equal(words, ref_w)
     assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
 
@@ -114,9 +136,9 @@ def test_ghost_slabs_equal_whole_grid(engine, world, n, name):
 
 
 def test_config4_n1024_four_slabs(engine):
-    """BASELINE config 4 at its stated shape: 1,348,128 faces, n = 1024, four Z-slabs -- both multi-GPU pipelines (RCCL-style
-    halo exchange through the loopback; ghost planes without exchange), four emulated ranks on one GPU with the real
-    kernels, bit-identical to the single-GPU result."""
+    """BASELINE config 4 at its stated shape: 1,348,128 faces, n = 1024, four Z-slabs -- all three multi-GPU pipelines (RCCL-style
+    halo exchange through the loopback; ghost planes without exchange; the hybrid of the two), four emulated ranks on one GPU
+    with the real kernels, bit-identical to the single-GPU result."""
     import gc
     from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
     xyz, tri = M.bunny(24)
@@ -137,6 +159,11 @@ def test_config4_n1024_four_slabs(engine):
         del pipe, s
         gc.collect(); torch.cuda.empty_cache()
     words, sdf = _run_slabs(world, fr, xyz, tri, ALGO_TILED)   # halo exchange: all ranks at once
+    assert np.array_equal(words, engine.words_to_numpy(ref_w))
+    assert np.array_equal(sdf.view(np.uint32), ref_s.cpu().numpy().view(np.uint32))
+    del words, sdf
+    gc.collect(); torch.cuda.empty_cache()
+    words, sdf = _run_slabs(world, fr, xyz, tri, ALGO_TILED, kind="hybrid")   # ghost planes for k = 512, 256; halos for k <= 128
     assert np.array_equal(words, engine.words_to_numpy(ref_w))
     assert np.array_equal(sdf.view(np.uint32), ref_s.cpu().numpy().view(np.uint32))
 
@@ -175,8 +202,8 @@ def test_config5_n2048_eight_ghost_slabs(engine):
     gc.collect(); torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_multi_process_launch_on_shared_gpu(world):
+@pytest.mark.parametrize("world,multi", [(2, "ghost"), (4, "ghost"), (4, "hybrid")])
+def test_bench_multi_process_launch_on_shared_gpu(world, multi):
     """The driver's multi-GPU invocation (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) end to end
     with one process per rank and the real kernels.  A one-GPU box cannot give every rank a device, so the ranks share it and
     rendezvous over gloo (VP_BENCH_SHARE_GPU=1, bench.py); everything else -- launcher env, barriers, max-over-ranks timing,
@@ -188,7 +215,7 @@ def test_bench_multi_process_launch_on_shared_gpu(world):
         port = s.getsockname()[1]
     env = dict(os.environ, VP_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--grid-n", "256"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--grid-n", "256", "--multi", multi]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
@@ -197,5 +224,5 @@ def test_bench_multi_process_launch_on_shared_gpu(world):
     assert out["n_gpus"] == world and out["steps"] == 3 and out["scaling"] == "strong"
     assert out["config"]["world_size_seen"] == world and out["config"]["n"] == 256
     assert out["value"] > 0 and out["ms_per_step"] > 0
-    assert out["multi"]["pipeline"] == "ghost"
+    assert out["multi"]["pipeline"] == multi
     assert out["roofline"]["kernel"] == "jfa_dense" and out["roofline"]["launches"] > 0

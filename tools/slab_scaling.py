@@ -5,6 +5,9 @@
 ghost planes (no exchange): every rank of a G-GPU job is run on THIS GPU with the real kernels and timed; ranks share
   nothing, so the job time on G GPUs is the slowest rank -- a measurement, not a model.  Also printed: plane-passes per
   rank against the single-GPU count (the work-replication ceiling of the scheme).
+hybrid (ghost planes for k > nz/2, halos of the adjacent ranks for k <= nz/2): plane-passes per rank and bytes received per side are
+  exact (slab.hybrid_plan); times are a MODEL: plane-passes x the measured single-GPU time per plane-pass, + the halo bytes of one
+  side at an assumed per-link rate, once fully hidden under the interior planes and once not hidden at all.
 halo exchange: bytes each rank must RECEIVE over xGMI per job (exact, from slab.halo_plan) and the time that takes at two
   assumed per-GPU ingest rates -- a model (no multi-GPU box is reachable from here); compute per rank is the measured
   single-GPU time / G at best.
@@ -15,7 +18,7 @@ import torch
 from cuda_mesh_voxelization_amd import mesh as M
 from cuda_mesh_voxelization_amd.capi import ALGO_TILED, Frame
 from cuda_mesh_voxelization_amd.pipeline import Engine
-from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline, HipSlabBackend, halo_plan, ghost_regions
+from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline, HipSlabBackend, HybridSlabPipeline, halo_plan, ghost_regions, hybrid_plan
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 refine = 24 if n <= 1024 else 192
@@ -61,3 +64,40 @@ for world in (2, 4, 8):
     t150, t400 = b / 150e9 * 1e3, b / 400e9 * 1e3
     print("  %d   %8.2f               %8.2f ms %8.2f ms   %8.2f ms         %.2fx .. %.2fx"
           % (world, b / 2**30, t150, t400, t1 / world, t1 / (t150 + t1 / world), t1 / (t400 + t1 / world)))
+
+class NullDist:
+    """No transfers at all: the halo planes keep whatever they held, so the RESULT of such a run is wrong -- its kernel sequence and
+    per-rank compute time are those of the real job (the transfers are what the model below adds)."""
+    isend, irecv = "isend", "irecv"
+    class P2POp:
+        def __init__(self, op, tensor, peer): pass
+    def batch_isend_irecv(self, ops): return []
+
+print("\nhybrid, compute only (every rank measured on this GPU with the real kernels and sub-slab launches, transfers left out)")
+print("  G   slowest rank ms   speedup if transfers were free   per-rank ms")
+hyb = {}
+for world in (2, 4, 8):
+    ts = []
+    for r in range(world):
+        pipe = HybridSlabPipeline(HipSlabBackend(eng), fr, r, world, NullDist())
+        def step(): pipe.voxelize(dx, dt); pipe.jfa()
+        ts.append(timeit(step, max(2, reps // 2)))
+        del pipe; torch.cuda.empty_cache()
+    hyb[world] = max(ts)
+    print("  %d   %8.3f          %5.2fx                            %s" % (world, max(ts), t1 / max(ts), " ".join("%.2f" % t for t in ts)))
+
+print("\nhybrid (plane-passes and bytes: exact; times: MODEL -- per plane-pass = 1-GPU job / (n x passes) = %.2f us)" % (t1 * 1e3 / (n * passes)))
+print("  G   plane-passes/rank  ceiling   id-buffer planes   GiB received per side   compute ms (measured)   + halos @150 GB/s per link: hidden .. exposed   vs 1 GPU")
+for world in (2, 4, 8):
+    worst, win, rx = 0, 0, 0
+    for r in range(world):
+        wide, narrow = hybrid_plan(n, r, world)
+        nz = n // world
+        worst = max(worst, sum(b1 - b0 for _, b0, b1 in wide) + nz * len(narrow))
+        lo = min([max(0, r * nz - nz // 2)] + [b0 for _, b0, _ in wide]); hi = max([min(n, (r + 1) * nz + nz // 2)] + [b1 for _, _, b1 in wide])
+        win = max(win, hi - lo)
+        rx = max(rx, sum(narrow) * plane)
+    tc = hyb[world]                                             # measured above (the plane-pass model would give worst * t1 / (n * passes))
+    tx = rx / 150e9 * 1e3
+    print("  %d   %8d           %5.2fx   %6d of %-6d    %8.2f                %8.2f     %8.2f .. %8.2f ms                          %.2fx .. %.2fx"
+          % (world, worst, n * passes / worst, win, n, rx / 2**30, tc, max(tc, tx), tc + tx, t1 / (tc + tx), t1 / max(tc, tx)))
