@@ -979,7 +979,23 @@ template <class ID> constexpr bool final_mask_global() { return VP_FINAL_GLOBAL_
 //     48 KB and three 512-thread workgroups share a CU; "none" (all ones: its fields are real coordinates at n = 2048) gets an
 //     infinite seed x by an explicit test, once per id.
 template <class ID> constexpr bool dense_wide() { return std::is_same<ID, Id64>::value; }
-template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP>
+// Pair mode (PM = 1, 2, 4, 8; round 3): the lanes of a wave are paired so that the voxels x and x + k sit in two lanes one DPP
+// permutation apart (quad_perm for k = 1, 2; row_half_mirror for k = 4; row_ror:8 for k >= 8 -- the map from lane to x below keeps
+// the 64 voxels of a wave inside at most two 128-byte runs).  Each lane then loads and decodes TWO ids per source row instead of
+// three -- its own column and the column beyond it (x - k for the lower lane of a pair, x + k for the upper) -- and evaluates the
+// third column, which IS its partner's own column, from the partner's decoded values: seed x, squared y / z differences arrive as
+// the DPP operand of the very v_sub_f32 / v_add_f32 that consumes them.  3.75 instead of 5.6 loads, decodes and table lookups per
+// voxel; the candidates, their order-defining ranks and every float operation are unchanged.  A DPP operand costs the instruction
+// 1.7 clocks more (tools/ubench/probe3.hip), which eats the VALU saved by the decodes: what is gained is LDS time, so the mode pays
+// where the LDS pipe is the limiter -- the fused last pass -- and is left off elsewhere (launch_dense).
+// Needs n a power of two and n % NT == 0 (every lane of every wave has its partner).
+template <int PM>
+__device__ __forceinline__ float from_partner(float v)
+{
+    constexpr int ctrl = PM == 1 ? 0xB1 : PM == 2 ? 0x4E : PM == 4 ? 0x141 : 0x128;   // quad_perm:[1,0,3,2] / [2,3,0,1] / row_half_mirror / row_ror:8
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
+}
+template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP, int PM>
 #ifndef VP_DENSE_WIDE_WAVES
 #define VP_DENSE_WIDE_WAVES 4
 #endif
@@ -995,7 +1011,9 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     constexpr int PXT = WIDE ? TAB : TAB + 1;                      // 32-bit ids: slot TAB = the x index of "none" = +inf
     constexpr int EY = 1, EZ = 1;                                  // floats per table entry (wider entries: measured slower)
     constexpr int NR = RY + 2;
-    constexpr int NI = NR * 3;
+    constexpr int NC = PM ? 2 : 3;                                 // id columns a lane loads per source row
+    constexpr int NI = NR * NC;
+    static_assert(!PM || (!SKIP && !WIDE), "pair mode: dense 32-bit-id passes");
     constexpr int CHT = WIDE ? 1 : CH;                             // z tables: squared differences per output plane / one table of positions
 #ifndef VP_DENSE_WIDE_YPOS
 #define VP_DENSE_WIDE_YPOS 0      // 1: 8-byte ids with a y table of positions too (24 KB of LDS, 256 threads, four workgroups per CU) instead of
@@ -1116,7 +1134,19 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     const int zbase0 = zbase, lbase0 = lbase, ybase0 = ybase;
     const uint32_t xiters = ((uint32_t)N + NT - 1) / NT, xper = (xiters + xparts - 1) / xparts * NT;
     const uint32_t xbeg = xpart * xper, xend = min((uint32_t)N, xbeg + xper);
-    for (uint32_t x = xbeg + tid; x < xend; x += NT) {
+    for (uint32_t xb = xbeg; xb < xend; xb += NT) {
+        uint32_t x = xb + tid;
+        bool upper = false;                                        // PM: this lane is the x + k end of its pair
+        if constexpr (PM != 0) {
+            // pair index -> x: the pairs of a chain block of 2k voxels are (x0, x0 + k), x0 = block * 2k + (pair % k)
+            uint32_t pl;
+            if (PM == 1) { upper = tid & 1u; pl = tid >> 1; }
+            else if (PM == 2) { upper = (tid >> 1) & 1u; pl = ((tid >> 2) << 1) | (tid & 1u); }
+            else if (PM == 4) { const uint32_t l8 = tid & 7u; upper = l8 >> 2; pl = ((tid >> 3) << 2) | (upper ? 7u - l8 : l8); }
+            else { upper = (tid >> 3) & 1u; pl = ((tid >> 4) << 3) | (tid & 7u); }
+            const uint32_t pr = (xb >> 1) + pl;
+            x = (((pr & ~(k - 1u)) << 1) | (pr & (k - 1u))) + (upper ? k : 0u);
+        } else if (x >= xend) break;
         // The uniform bases are re-read through an empty asm in every x iteration: otherwise every address of the ~10
         // planes of the tile is hoisted out of the x loop, does not fit the SGPR file and is spilled to VGPR lanes
         // (v_readlane / v_writelane were 6 % of the VALU instructions of the loop).
@@ -1135,6 +1165,8 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         const float px = PX[x];
         const bool hasM = x >= k, hasP = x + k < (uint32_t)N;
         const uint32_t xo = x * IDB, xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;   // a column outside the grid reads the centre column
+        // PM: the partner's column (always inside the grid) and the column beyond the own one
+        const uint32_t xpart = upper ? xo - kb : xo + kb, xout = upper ? xpo : xmo;
         // WIDE: rank of a candidate = (source row index << 14 | byte offset of the column it was read from) + 1
 
         // SKIP (wide passes, k >= n/4: half of the neighbour rows / planes / columns lie outside the grid): a source row that
@@ -1157,9 +1189,14 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             if (SKIP && !ok) return;
             const __amdgpu_buffer_rsrc_t b =
                 row_resource(ok ? pl.base + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
-            if (anyM) row_load(w[rr * 3 + 0], b, xmo);
-            row_load(w[rr * 3 + 1], b, xo);
-            if (anyP) row_load(w[rr * 3 + 2], b, xpo);
+            if constexpr (PM != 0) {
+                row_load(w[rr * 2 + 0], b, xo);
+                row_load(w[rr * 2 + 1], b, xout);
+            } else {
+                if (anyM) row_load(w[rr * 3 + 0], b, xmo);
+                row_load(w[rr * 3 + 1], b, xo);
+                if (anyP) row_load(w[rr * 3 + 2], b, xpo);
+            }
         };
 
         B best[RY][CH];
@@ -1196,19 +1233,24 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 #define VP_FINAL_MIN3 1
 #endif
         float hold[3][3];                                                   // FINAL: distances of column x - k of the current source row
-        auto steps = [&](int P, int rr, int c, const Dec& d, uint32_t prank) {
+        // c = position of the candidate column in the sequence of a source row (0, 1, 2: the FINAL form pairs the first two in one
+        // v_min3_f32); ownCol = it is the lane's own column (rank 0 for the own voxel); coloff = byte offset of the column in its row
+        // (the rank); DPPV = the decoded values are the PARTNER's (pair mode): they are read through the DPP permutation
+        auto steps_col = [&](int P, int rr, int c, bool ownCol, uint32_t coloff, const Dec& d, uint32_t prank, auto dppv) {
+            constexpr bool DPPV = decltype(dppv)::value;
+            auto val = [&](float v) { if constexpr (DPPV) return from_partner<PM ? PM : 1>(v); else return v; };
             const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
-            const float dxv = d.sx - px;
+            const float dxv = val(d.sx) - px;
             const float dx2 = dxv * dxv;
             u32x2 cand;
-            if (!FINAL) cand.x = (WIDE ? (uint32_t)(((P + 1) * NR + rr) << 14) + 1u : prank + ro[rr]) + (c == 0 ? xmo : c == 1 ? xo : xpo);
+            if (!FINAL) cand.x = (WIDE ? (uint32_t)(((P + 1) * NR + rr) << 14) + 1u : prank + ro[rr]) + coloff;
 #pragma unroll
             for (int a = alo; a <= ahi; ++a) {
-                const float pre = dx2 + d.dy2[a];
-                const bool ownRow = (rr == a + 1) && (c == 1);
+                const float pre = val(d.dy2[a]) + dx2;
+                const bool ownRow = (rr == a + 1) && ownCol;
 #pragma unroll
                 for (int o = olo; o <= ohi; ++o) {
-                    const float dd = pre + d.dz2[o];
+                    const float dd = val(d.dz2[o]) + pre;
                     if constexpr (FINAL) {
                         // distances only, so the order of the candidates no longer matters: the left column's distance waits for
                         // the centre column's and both go through one v_min3_f32 (27 -> 18 minimum instructions per voxel)
@@ -1226,6 +1268,19 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 #endif
                     }
                 }
+            }
+        };
+        // the candidate steps that follow the decode of id j of a plane (j = rr * NC + column slot)
+        auto steps = [&](int P, int rr, int c, const Dec& d, uint32_t prank) {
+            if constexpr (PM != 0) {
+                if (c == 0) {                                                   // own column, then the partner's evaluation of ITS own column
+                    steps_col(P, rr, 0, true, xo, d, prank, std::false_type{});
+                    steps_col(P, rr, 1, false, xpart, d, prank, std::true_type{});
+                } else {
+                    steps_col(P, rr, 2, false, xout, d, prank, std::false_type{});
+                }
+            } else {
+                steps_col(P, rr, c, c == 1, c == 0 ? xmo : c == 1 ? xo : xpo, d, prank, std::false_type{});
             }
         };
 #ifndef VP_DENSE_PIPE
@@ -1251,14 +1306,14 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                 constexpr int DEPTH = VP_DENSE_PIPE_DEPTH;
                 Dec d[DEPTH + 1];
 #pragma unroll
-                for (int j = 0; j < DEPTH && j < NI; ++j) lookup(P, j / 3, w[j], d[j]);
+                for (int j = 0; j < DEPTH && j < NI; ++j) lookup(P, j / NC, w[j], d[j]);
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    const int rr = j / 3, c = j % 3;
-                    if (j + DEPTH < NI) lookup(P, (j + DEPTH) / 3, w[j + DEPTH], d[(j + DEPTH) % (DEPTH + 1)]);
+                    const int rr = j / NC, c = j % NC;
+                    if (j + DEPTH < NI) lookup(P, (j + DEPTH) / NC, w[j + DEPTH], d[(j + DEPTH) % (DEPTH + 1)]);
                     __builtin_amdgcn_sched_barrier(0);
                     steps(P, rr, c, d[j % (DEPTH + 1)], prank);
-                    if (c == 2) {
+                    if (c == NC - 1) {
                         const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1);
 #pragma unroll
                         for (int a = alo; a <= ahi; ++a)
@@ -1275,10 +1330,10 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                 const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1);
                 if (!SKIP || (curOk && yv[rr])) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
+                    for (int c = 0; c < NC; ++c) {
                         if (SKIP && ((c == 0 && !anyM) || (c == 2 && !anyP))) continue;
                         Dec d;
-                        lookup(P, rr, w[rr * 3 + c], d);
+                        lookup(P, rr, w[rr * NC + c], d);
                         steps(P, rr, c, d, prank);
                     }
 #pragma unroll
@@ -1961,13 +2016,30 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 #ifndef VP_DENSE_RY
 #define VP_DENSE_RY 4             // output rows per tile (dev: 8 = 4.7 decoded ids per voxel instead of 5.6, 109 VGPRs, four waves per SIMD)
 #endif
-#define VP_LAUNCH_DENSE(CH, NT, F, S)                                                                                              \
+#ifndef VP_DENSE_PAIRS_DEFAULT
+#define VP_DENSE_PAIRS_DEFAULT 2  // pair mode (see jfa_pass_dense): 0 off, 1 the fused last pass only, 2 every dense pass too (profiles/r03/ab_pairs_*.txt)
+#endif
+    static const int pairs = env_int("VP_DENSE_PAIRS", VP_DENSE_PAIRS_DEFAULT);
+    const bool pow2 = (f.n & (f.n - 1)) == 0;
+#define VP_LAUNCH_DENSE_PM(CH, NT, F, S, PM)                                                                                       \
     do {                                                                                                                           \
         const uint32_t ty_ = nresY * ((ylen + VP_DENSE_RY - 1) / VP_DENSE_RY), t_ = ty_ * nres * ((zlen + CH - 1) / CH);           \
         /* a row of <= NT voxels has no halves */                                                                                  \
         const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, dense_wide<ID>() ? (NT == 256 ? 5u : 2u) : ID::kTab == 512 ? ((F) && !final_mask_global<ID>() ? 5u : 6u) : NT == 512 ? ((F) && !final_mask_global<ID>() ? 2u : 3u) : 4u) : 0u;                      \
-        hipLaunchKernelGGL((jfa_pass_dense<ID, VP_DENSE_RY, CH, NT, F, true, S>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,            \
+        hipLaunchKernelGGL((jfa_pass_dense<ID, VP_DENSE_RY, CH, NT, F, true, S, PM>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,        \
                            (const T*)d_in, (T*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                               \
+    } while (0)
+    // pair mode where it applies: 32-bit ids, n a power of two, whole rows of NT-thread iterations; the lane permutation follows k
+#define VP_LAUNCH_DENSE(CH, NT, F, S)                                                                                              \
+    do {                                                                                                                           \
+        if constexpr (!dense_wide<ID>() && !(S)) {                                                                                 \
+            const bool pm_ = pow2 && f.n % NT == 0 && pairs >= ((F) ? 1 : 2) && ((F) || k >= 2);                                   \
+            if (pm_ && (F))        { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 1); break; }                                                 \
+            if (pm_ && k == 2)     { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 2); break; }                                                 \
+            if (pm_ && k == 4)     { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 4); break; }                                                 \
+            if (pm_)               { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 8); break; }                                                 \
+        }                                                                                                                          \
+        VP_LAUNCH_DENSE_PM(CH, NT, F, S, 0);                                                                                       \
     } while (0)
 #define VP_DENSE_F(CH, NT) do { if (fin) VP_LAUNCH_DENSE(CH, NT, (VP_JFA_DENSE_FINAL != 0), false);                                \
                                 else if (wideK) VP_LAUNCH_DENSE(CH, NT, false, (VP_JFA_DENSE_WIDEK != 0));                          \
@@ -1979,6 +2051,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     else                           { if (deep) VP_DENSE_F(8, 512); else VP_DENSE_F(4, 256); }
 #undef VP_DENSE_F
 #undef VP_LAUNCH_DENSE
+#undef VP_LAUNCH_DENSE_PM
     return 0;
 }
 
