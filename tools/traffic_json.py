@@ -9,16 +9,20 @@ def counters(name, n, kernel_re):
     if not os.path.exists(path):
         return out
     cur = None
+    acc = {}
     for line in open(path):
         if not line.startswith(" "):
             cur = line.strip()
         elif cur and re.match(kernel_re, cur):
             m = re.match(r"\s+(\S+)\s+n=\s*(\d+)\s+mean=(\S+)", line)
-            if m:
-                out[m.group(1)] = float(m.group(3))
+            if m:                                                    # several instantiations match (pair modes 8 / 4 / 2): launch-weighted mean
+                a = acc.setdefault(m.group(1), [0.0, 0])
+                a[0] += float(m.group(3)) * int(m.group(2)); a[1] += int(m.group(2))
+    for k, (tot, cnt) in acc.items():
+        out[k] = tot / cnt
     return out
 
-res = {"round": 2, "source": "separate rocprofv3 --pmc passes over tools/run_passes.py <n> 1 (tools/profile_round.sh), per-kernel means",
+res = {"round": int(re.sub(r"\D", "", os.path.basename(os.path.normpath(d))) or 0), "source": "separate rocprofv3 --pmc passes over tools/run_passes.py <n> 1 (tools/profile_round.sh), per-kernel means",
        "correction": "gfx950: read bytes = 2 x FETCH_SIZE (128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section); FETCH_SIZE / WRITE_SIZE are in KB"}
 # the dense-pass instantiations of jfa_pass_dense (template arguments: id format, rows, planes, threads, ...)
 for n, prefix, kre in ((512, "jfa_pass_dense<IdU<9>, 4, 8, 256, false", r"jfa_pass_dense<(vp::)?(\(anonymous namespace\)::)?IdU<9>, 4, 8, 256, false"),
@@ -32,7 +36,8 @@ for n, prefix, kre in ((512, "jfa_pass_dense<IdU<9>, 4, 8, 256, false", r"jfa_pa
     alg = 2 * 4 * n ** 3
     cycles = c.get("GRBM_GUI_ACTIVE", 0) / 8.0                       # summed over the 8 XCDs
     # VALU issue: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles, v_min_f64 for 4 (tools/ubench/probe.hip);
-    # every output voxel takes exactly 27 v_min_f64 steps, i.e. 27 n^3 / 64 wave instructions per launch
+    # every output voxel takes exactly 27 v_min_f64 steps, i.e. 27 n^3 / 64 wave instructions per launch.  (Pair mode: the
+    # DPP forms cost ~1.7 clocks more each, tools/ubench/probe3.hip -- not in this estimate, which is therefore a lower bound.)
     valu = c.get("SQ_INSTS_VALU", 0)
     issue = valu * 2.0 + 2.0 * 27.0 * n ** 3 / 64.0
     entry = {"kernel": prefix + ", ...> (dense passes, bunny x24)", "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
