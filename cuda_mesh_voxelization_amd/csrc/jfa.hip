@@ -317,17 +317,19 @@ constexpr int kFirstRows = VP_FIRST_ROWS;     // rows per wave: their mask loads
 
 template <class ID>
 __global__ void __launch_bounds__(256)
-jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out)
+jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out, uint32_t gx, uint32_t gy)
 {
+    // one-dimensional launch (see jfa_first_two): x block fastest, then row block, then plane
+    const uint32_t bIdxX = blockIdx.x % gx, bIdxY = (blockIdx.x / gx) % gy, bIdxZ = blockIdx.x / (gx * gy);
     using T = typename ID::T;
     const int N = (int)f.n;
     const int K = (int)k;                                           // = n / 2: per axis exactly one of -k / +k is inside the grid
     const int lane = threadIdx.x & 63;
-    const int x0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 256u + (threadIdx.x & ~63u)));   // segment start
+    const int x0 = __builtin_amdgcn_readfirstlane((int)(bIdxX * 256u + (threadIdx.x & ~63u)));   // segment start
     if (x0 >= N) return;                                            // whole wave
     const int x = x0 + lane;
-    const int ybase = blockIdx.y * kFirstRows;
-    const int zl = blockIdx.z;
+    const int ybase = bIdxY * kFirstRows;
+    const int zl = bIdxZ;
     const int zg = zl + (int)f.z0;
     // The in-grid neighbour along each axis (wave-uniform: k is a multiple of 64, the rows of a wave are 8-aligned): 8
     // candidate segments in all -- the own one and 7 others -- instead of the 27 of a general pass.
@@ -612,7 +614,7 @@ template <class ID, int TAB, int PXT, int RY, int CH, bool SKIP, bool CHECK_NONE
 __global__ void __launch_bounds__(256)
 jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, const typename ID::T* __restrict__ minus,
                  const typename ID::T* __restrict__ plus, typename ID::T* __restrict__ out,
-                 const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf)
+                 const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf, uint32_t tilesY)
 {
     using T = typename ID::T;
     constexpr int kTab = TAB;                                      // table entries; fields are masked to it
@@ -646,8 +648,13 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
     // round 1 at n = 512, round 2 at n = 2048 with 8-byte ids, 45.44 vs 45.50 ms at k = 4, 46.1 vs 47.4 ms at k = 32.)
     // (bench step 4.52 -> 4.45 ms.)
     const bool rev = ((31 - __builtin_clz(k)) & 1) != 0;
-    const uint32_t bx = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
-    const uint32_t by = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+    // One-dimensional launch (round 3; a 2-D grid of the same tiles in the same order ran the passes N/2 + N/4 8 - 14 % slower,
+    // see jfa_first_two): tile = y tile fastest, then z tile.
+#ifndef VP_ZSTREAM_1D
+#define VP_ZSTREAM_1D 1
+#endif
+    const uint32_t lin = rev ? gridDim.x * gridDim.y - 1 - (blockIdx.x + gridDim.x * blockIdx.y) : blockIdx.x + gridDim.x * blockIdx.y;
+    const uint32_t bx = lin % tilesY, by = lin / tilesY;
     const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
     // z: the same over the local plane index of the slab
     const int nres = min(K, nzl);
@@ -1869,10 +1876,11 @@ int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, 
 int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out)
 {
     ProfScope p(ctx, VP_K_JFA_FIRST);
-    const dim3 grid((f.n + 255) / 256, f.n / kFirstRows, f.z1 - f.z0);
-    if (wide(f)) hipLaunchKernelGGL(jfa_first_pass<Id64>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint2*)d_out);
-    else if (f.n <= 512) hipLaunchKernelGGL(jfa_first_pass<Id9>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint32_t*)d_out);
-    else         hipLaunchKernelGGL(jfa_first_pass<Id10>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint32_t*)d_out);
+    const uint32_t gx = (f.n + 255) / 256, gy = f.n / kFirstRows;
+    const dim3 grid(gx * gy * (f.z1 - f.z0));
+    if (wide(f)) hipLaunchKernelGGL(jfa_first_pass<Id64>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint2*)d_out, gx, gy);
+    else if (f.n <= 512) hipLaunchKernelGGL(jfa_first_pass<Id9>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint32_t*)d_out, gx, gy);
+    else         hipLaunchKernelGGL(jfa_first_pass<Id10>, grid, dim3(256), 0, ctx->stream, f, f.n / 2, d_border, (uint32_t*)d_out, gx, gy);
     VP_HIP(hipGetLastError());
     return 0;
 }
@@ -1917,8 +1925,8 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     // Tile = RY rows x CH planes per workgroup and the table size.
 #define VP_LAUNCH_CHAIN(TAB, PXT, RY, CH, S, C, F)                                                                                   \
     hipLaunchKernelGGL((jfa_pass_zstream<ID, TAB, PXT, RY, CH, S, C, F>),                                                            \
-                       dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(256), 0, ctx->stream, f, k,         \
-                       (const T*)d_in, (const T*)d_minus, (const T*)d_plus, (T*)d_out, none_row, d_words, fill, d_sdf)
+                       VP_ZSTREAM_1D ? dim3(nresY * ((ylen + RY - 1) / RY) * nres * ((zlen + CH - 1) / CH)) : dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(256), 0, ctx->stream, f, k,         \
+                       (const T*)d_in, (const T*)d_minus, (const T*)d_plus, (T*)d_out, none_row, d_words, fill, d_sdf, nresY * ((ylen + RY - 1) / RY))
     // 64-bit ids: chk = n == table size, "none" has no spare table slot -> explicit test.  32-bit ids (U): the x table has one
     // more slot (+inf, the x index of "none"), "none" needs no test; the sparse variant keeps the flag all the same (most ids
     // are "none" there and the flag skips their updates: 0.355 vs 0.377 ms, round 1).
