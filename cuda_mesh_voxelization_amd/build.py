@@ -41,10 +41,22 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC, "vp_internal.h"), os.path.join(ROOT, "include", "vphip.h")]
     if force or _newer(LIB, deps):
-        cmd = [_hipcc()] + HIP_FLAGS + srcs + ["-o", LIB]
+        # one hipcc per source, side by side (jfa.hip alone is ~2 minutes of template instantiations), then one link
+        from concurrent.futures import ThreadPoolExecutor
+        objdir = os.path.join(PKG, "build")
+        os.makedirs(objdir, exist_ok=True)
+        flags = [f for f in HIP_FLAGS if f != "-shared"]
+        objs = [os.path.join(objdir, os.path.basename(s_) + ".o") for s_ in srcs]
+        cmds = [[_hipcc()] + flags + ["-c", s_, "-o", o] for s_, o in zip(srcs, objs)]
         if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+            for c in cmds:
+                print(" ".join(c))
+        with ThreadPoolExecutor(max_workers=min(4, len(cmds))) as ex:
+            list(ex.map(subprocess.check_call, cmds))
+        link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(link))
+        subprocess.check_call(link)
     return LIB
 
 

@@ -2040,7 +2040,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     // pair mode where it applies: 32-bit ids, n a power of two, whole rows of NT-thread iterations; the lane permutation follows k
 #define VP_LAUNCH_DENSE(CH, NT, F, S)                                                                                              \
     do {                                                                                                                           \
-        if constexpr (!dense_wide<ID>() && !(S)) {                                                                                 \
+        if constexpr (!dense_wide<ID>() && !(S) && CH == 8) {    /* the 4-plane tiles of shallow slabs keep the plain form (fewer kernels to build) */ \
             const bool pm_ = pow2 && f.n % NT == 0 && pairs >= ((F) ? 1 : 2) && ((F) || k >= 2);                                   \
             if (pm_ && (F))        { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 1); break; }                                                 \
             if (pm_ && k == 2)     { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 2); break; }                                                 \

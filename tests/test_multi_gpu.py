@@ -97,6 +97,32 @@ def test_multi_headline_size_equals_single(engine, world, mode):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("mode", [MULTI_HALO, MULTI_GHOST])
+def test_multi_config4_n1024_four_slabs(engine, mode):
+    """BASELINE config 4 at its stated shape through the C++ driver: 1,348,128 faces, n = 1024, four Z-slabs (four contexts on the
+    one device of the test box): grid and sdf bit-identical to the single-context result."""
+    import gc
+    xyz, tri = M.bunny(24)
+    n, world = 1024, 4
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    ref_w, ref_s = _single(engine, fr, xyz, tri)
+    engine._work = None
+    gc.collect(); torch.cuda.empty_cache()
+    m = capi.Multi([0] * world)
+    try:
+        m.set_mesh(xyz, tri)
+        m.voxelize(fr)
+        assert np.array_equal(m.get_grid(), ref_w)
+        m.jfa(mode=mode)
+        assert np.array_equal(m.get_sdf().view(np.uint32), ref_s.view(np.uint32))
+        if mode == MULTI_HALO:                                      # SURVEY 8(e): ~5 GiB received per interior rank over the 10 passes
+            assert 3 * 2**30 < m.bytes_moved / world < 6 * 2**30
+    finally:
+        m.close()
+        gc.collect(); torch.cuda.empty_cache()
+
+
 def test_multi_rejects_bad_splits_and_order(engine):
     fr = Frame.make(96, 1.0, (0, 0, 0))
     m = capi.Multi([0, 0, 0, 0, 0])
