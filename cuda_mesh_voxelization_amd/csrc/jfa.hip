@@ -611,7 +611,10 @@ __device__ __forceinline__ void pin(uint32_t& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(uint2& a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
 
 template <class ID, int TAB, int PXT, int RY, int CH, bool SKIP, bool CHECK_NONE, bool FINAL>
-__global__ void __launch_bounds__(256)
+#ifndef VP_ZSTREAM_WIDE_WAVES
+#define VP_ZSTREAM_WIDE_WAVES 0      // 8-byte ids: minimum waves per SIMD asked of the register allocator (0 = none: 143 VGPRs, 3 waves)
+#endif
+__global__ void __launch_bounds__(256, (std::is_same<ID, Id64>::value && VP_ZSTREAM_WIDE_WAVES) ? VP_ZSTREAM_WIDE_WAVES : 1)
 jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, const typename ID::T* __restrict__ minus,
                  const typename ID::T* __restrict__ plus, typename ID::T* __restrict__ out,
                  const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf, uint32_t tilesY)
