@@ -1005,7 +1005,15 @@ __device__ __forceinline__ float from_partner(float v)
     constexpr int ctrl = PM == 1 ? 0xB1 : PM == 2 ? 0x4E : PM == 4 ? 0x141 : 0x128;   // quad_perm:[1,0,3,2] / [2,3,0,1] / row_half_mirror / row_ror:8
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
 }
-template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP, int PM>
+// Closed tiles (CLOSED; round 3): at k = n/8 a chain of rows or planes has exactly eight members, so a tile of 8 rows x 8 planes IS a
+// pair of whole chains: it has no halo rows and no halo planes at all -- where the 4 x 8 tile read 6 x 10 row-planes (two planes and
+// one row of them outside the grid: a third of that pass's candidate steps were spent on "none") it reads 8 x 8, every one of them
+// its own.  2 instead of 3.75 decoded ids per voxel (pair mode), 22.7 instead of 27 candidate steps (edge outputs have fewer
+// neighbours), at the price of 48 running-pair registers (four waves per SIMD).  Compile-time: the loops simply lose their halo
+// iterations.  Whole grids with n = 8 k only.  CLOSED is a mask: 1 = the rows of a tile are a whole chain (RY = n / k), 2 = the planes
+// are (CH = n / k); with the 4-KB tables (n = 1024) eight row tables do not fit the 64 KB a workgroup may have, so only the planes
+// are closed there (4 x 8 tiles, 3 decoded ids per voxel).
+template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP, int PM, int CLOSED = 0>
 #ifndef VP_DENSE_WIDE_WAVES
 #define VP_DENSE_WIDE_WAVES 4
 #endif
@@ -1020,7 +1028,10 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     constexpr int TAB = ID::kTab;
     constexpr int PXT = WIDE ? TAB : TAB + 1;                      // 32-bit ids: slot TAB = the x index of "none" = +inf
     constexpr int EY = 1, EZ = 1;                                  // floats per table entry (wider entries: measured slower)
-    constexpr int NR = RY + 2;
+    constexpr int HY = (CLOSED & 1) ? 0 : 1;                       // halo rows on each side of the tile's output rows
+    constexpr bool CZ = (CLOSED & 2) != 0;                         // no halo planes
+    constexpr int NR = RY + 2 * HY;
+    static_assert(!CLOSED || (!WIDE && !SKIP && !FINAL && ROLL), "closed tiles: dense 32-bit-id passes");
     constexpr int NC = PM ? 2 : 3;                                 // id columns a lane loads per source row
     constexpr int NI = NR * NC;
     static_assert(!PM || (!SKIP && !WIDE), "pair mode: dense 32-bit-id passes");
@@ -1168,8 +1179,8 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         bool yv[NR];
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
-            const int ny = ybase + (rr - 1) * K;
-            yv[rr] = ny >= 0 && ny < N && max(rr - 2, 0) < yout;
+            const int ny = ybase + (rr - HY) * K;
+            yv[rr] = ny >= 0 && ny < N && max(rr - HY - 1, 0) < yout;
             ro[rr] = (uint32_t)(yv[rr] ? ny : 0) * rowBytes;
         }
         const float px = PX[x];
@@ -1215,7 +1226,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         // z differences to the output planes -- one LDS lookup each.
         struct Dec { float sx; float dy2[RY]; float dz2[CH]; };
         auto lookup = [&](int P, int rr, T id, Dec& d) {
-            const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
+            const int alo = max(rr - HY - 1, 0), ahi = min(rr - HY + 1, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
             d.sx = lds_f32(tx + ID::xoff(id));                              // 32-bit ids: "none" reads slot TAB = +inf
             if constexpr (WIDE) d.sx = ID::is_none(id) ? INFINITY : d.sx;   // (inf - px)^2 = inf: "none" loses every '<'
             const uint32_t yo = ID::yoff(id), zo = ID::zoff(id);
@@ -1249,7 +1260,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         auto steps_col = [&](int P, int rr, int c, bool ownCol, uint32_t coloff, const Dec& d, uint32_t prank, auto dppv) {
             constexpr bool DPPV = decltype(dppv)::value;
             auto val = [&](float v) { if constexpr (DPPV) return from_partner<PM ? PM : 1>(v); else return v; };
-            const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
+            const int alo = max(rr - HY - 1, 0), ahi = min(rr - HY + 1, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
             const float dxv = val(d.sx) - px;
             const float dx2 = dxv * dxv;
             u32x2 cand;
@@ -1257,7 +1268,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 #pragma unroll
             for (int a = alo; a <= ahi; ++a) {
                 const float pre = val(d.dy2[a]) + dx2;
-                const bool ownRow = (rr == a + 1) && ownCol;
+                const bool ownRow = (rr == a + HY) && ownCol;
 #pragma unroll
                 for (int o = olo; o <= ohi; ++o) {
                     const float dd = val(d.dz2[o]) + pre;
@@ -1303,7 +1314,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             const int olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
             const bool curOk = P <= nout && zbase + P * K >= 0 && zbase + P * K < N;      // SKIP: does this source plane exist
             Plane next{nullptr, false};
-            if (ROLL && P + 1 <= CH) next = plane_of(zbase + (P + 1) * K, P + 1 <= nout);
+            if (ROLL && P + 1 <= CH - (CZ ? 1 : 0)) next = plane_of(zbase + (P + 1) * K, P + 1 <= nout);
             if (VP_DENSE_PIPE && !SKIP) {
                 // Software pipeline over the 18 ids of the plane: the table lookups of id j + 1 are issued BEFORE the candidate
                 // steps of id j (the scheduling barriers keep the compiler from sinking them back to their first use), so a wave
@@ -1324,12 +1335,12 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                     __builtin_amdgcn_sched_barrier(0);
                     steps(P, rr, c, d[j % (DEPTH + 1)], prank);
                     if (c == NC - 1) {
-                        const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1);
+                        const int alo = max(rr - HY - 1, 0), ahi = min(rr - HY + 1, RY - 1);
 #pragma unroll
                         for (int a = alo; a <= ahi; ++a)
 #pragma unroll
                             for (int o = olo; o <= ohi; ++o) pin(best[a][o]);
-                        if (ROLL && P + 1 <= CH) load_row(next, rr, w);     // rolling prefetch (see below)
+                        if (ROLL && P + 1 <= CH - (CZ ? 1 : 0)) load_row(next, rr, w);     // rolling prefetch (see below)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1337,7 +1348,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             }
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
-                const int alo = max(rr - 2, 0), ahi = min(rr, RY - 1);
+                const int alo = max(rr - HY - 1, 0), ahi = min(rr - HY + 1, RY - 1);
                 if (!SKIP || (curOk && yv[rr])) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
@@ -1354,7 +1365,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                 // Rolling prefetch: the three ids of this row are spent, so the same row of the NEXT source plane is
                 // requested into their registers right away -- a whole plane of evaluation ahead of its use, without a
                 // second id buffer (18 VGPRs).  A plane that is not needed reads "none" (never memory past the slab's halo).
-                if (ROLL && P + 1 <= CH) load_row(next, rr, w);
+                if (ROLL && P + 1 <= CH - (CZ ? 1 : 0)) load_row(next, rr, w);
             }
         };
 
@@ -1364,14 +1375,14 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         T w[NI], w2[ROLL ? 1 : NI];
         T pend[RY];                                                // gathered winners of the previous output plane, stored a plane later
         {
-            const Plane first = plane_of(zbase - K, true);
+            const Plane first = plane_of(CZ ? zbase : zbase - K, true);   // closed tiles start at their own first plane
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) load_row(first, rr, w);
         }
 #pragma clang loop unroll(full)
         for (int P = -1; P <= CH; ++P) {
             T (&cur)[NI] = (ROLL || !((P + 1) & 1)) ? w : reinterpret_cast<T (&)[NI]>(w2);
-            if (!ROLL && P + 1 <= CH) {
+            if (!ROLL && P + 1 <= CH - (CZ ? 1 : 0) && !(CZ && P == -1)) {
                 T (&nxt)[NI] = ((P + 1) & 1) ? w : reinterpret_cast<T (&)[NI]>(w2);
                 const Plane np = plane_of(zbase + (P + 1) * K, P + 1 <= nout);
 #pragma unroll
@@ -1395,7 +1406,27 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                     }
                 }
             }
-            scatter(P, cur);
+#ifndef VP_DENSE_END_SKIP
+#define VP_DENSE_END_SKIP 0
+#endif
+            // (dev, off) The planes before the first and after the last output plane may lie outside the grid (one of them does for every
+            // tile at k = n/16, for half the tiles at n/32, ...): then they hold nothing but "none" and could be skipped with a
+            // workgroup-uniform branch.  Measured: a branch around EVERY plane and around the first / last row +1.7 % (and spills with
+            // the rows), a branch at the two ends of the chain only -0.3 % / +0.3 % (profiles/r03/ab_edge_*.txt, ab_endskip_*.txt): what
+            // pays is removing the halo at compile time, which only the closed tiles of k = n/8 can.
+            const bool endPlane = P == -1 || P == CH;
+            const bool endOutside = endPlane && (zbase + P * K < 0 || zbase + P * K >= N || P > nout);
+            if (CZ && endPlane) {
+                // closed tiles have no plane before the first or after the last
+            } else if (VP_DENSE_END_SKIP && !SKIP && ROLL && endPlane && endOutside) {
+                if (P + 1 <= CH) {
+                    const Plane next = plane_of(zbase + (P + 1) * K, P + 1 <= nout);
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) load_row(next, rr, cur);
+                }
+            } else {
+                scatter(P, cur);
+            }
             if constexpr (FINAL) {
                 if (P >= 1 && P - 1 < nout) {
 #pragma unroll
@@ -1431,7 +1462,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                             pend[a] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(in) + row * (ptrdiff_t)rowBytes + (ptrdiff_t)(r & 16383u));
 #endif
                         } else {
-                            const uint32_t ownOff = orank + ro[a + 1] + xo;
+                            const uint32_t ownOff = orank + ro[a + HY] + xo;
                             const uint32_t off = lo ? lo - 1u : ownOff;
 #if defined(VP_ABL_NOGATHER)
                             pend[a] = T(off);
@@ -2056,6 +2087,20 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
                                 else if (wideK) VP_LAUNCH_DENSE(CH, NT, false, (VP_JFA_DENSE_WIDEK != 0));                          \
                                 else VP_LAUNCH_DENSE(CH, NT, false, false); } while (0)
     const bool deep = zlen % 8 == 0;
+#ifndef VP_DENSE_CLOSED
+#define VP_DENSE_CLOSED 1         // closed tiles at k = n/8 (see jfa_pass_dense)
+#endif
+    if constexpr (!dense_wide<ID>()) {
+        constexpr uint32_t NTC = ID::kTab == 512 ? 256u : 512u;
+        if (VP_DENSE_CLOSED && pairs >= 2 && pow2 && !fin && f.z0 == 0 && f.z1 == f.n && f.n == 8u * k && f.n % NTC == 0) {
+            constexpr int RYC = ID::kTab == 512 ? 8 : 4, CL = ID::kTab == 512 ? 3 : 2;
+            const uint32_t ty_ = nresY * ((ylen + RYC - 1) / RYC), t_ = ty_ * nres;          // one plane chain per tile
+            const uint32_t sp_ = f.n > NTC ? tail_split(ctx, t_, ID::kTab == 512 ? 4u : 3u) : 0u;
+            hipLaunchKernelGGL((jfa_pass_dense<ID, RYC, 8, NTC, false, true, false, 8, CL>), dim3(t_ + sp_), dim3(NTC), 0, ctx->stream, f, k,
+                               (const T*)d_in, (T*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);
+            return 0;
+        }
+    }
     // 8-byte ids: 8-KB tables (PX + 4 x TY + one z position table = 48 KB), 512 threads
     if constexpr (dense_wide<ID>()) { if (deep) VP_DENSE_F(8, VP_DENSE_WIDE_NT); else VP_DENSE_F(4, VP_DENSE_WIDE_NT); }
     else if constexpr (ID::kTab == 512) { if (deep) VP_DENSE_F(8, 256); else VP_DENSE_F(4, 256); }

@@ -36,7 +36,8 @@ for algo in [int(x) for x in a.algos.split(",")]:
         for _ in range(a.reps):
             ctx.jfa_pass(fr, k, st.data_ptr(), None, None, out.data_ptr(), algo)
         ctx.prof_enable(False)
-        p = ctx.prof()["jfa_pass"]; ms = p["ms"] / p["launches"]; tot += ms
+        pr = ctx.prof()                                            # the tile kernels are timed under one key per variant
+        ms = sum(v["ms"] for v in pr.values()) / max(sum(v["launches"] for v in pr.values()), 1); tot += ms
         print("algo %d k=%4d seeded=%5.1f%%  %.3f ms  %.0f GB/s alg" % (algo, k, 100.0 * seeds / fr.voxels, ms, 8.0 * fr.voxels / ms / 1e6))
     print("algo %d total passes %.3f ms" % (algo, tot))
     # the fused last pass (k = 1 + id -> sdf) on the true k = 1 input
