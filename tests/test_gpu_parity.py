@@ -344,6 +344,35 @@ def test_surface_mask_matches_oracle(engine):
         assert not (border & ~w).any()                           # a subset of the solid
 
 
+def test_surface_mask_on_slabs_with_halo_planes(engine):
+    """vp_surface on Z-slab frames (the marching-lane kernel for rows of a power-of-two number of words, jfa_init's mask form
+    otherwise): with the neighbouring slabs' boundary planes as halos the concatenated slab masks equal the whole-grid mask;
+    without a halo plane the slab boundary counts as the outside of the grid."""
+    m = M.import_mesh(M.asset("bunny.obj"))
+    for n, cuts in ((128, (0, 32, 96, 128)), (160, (0, 80, 160)), (512, (0, 64, 256, 512))):
+        fr, origin, vs = _frame([m], n)
+        g = _gpu_grid(engine, fr, m[0], m[1], ALGO_TILED)
+        whole = engine.words_to_numpy(engine.surface(fr, g)).copy()
+        pw = n * n // 32
+        parts, closed = [], []
+        for z0, z1 in zip(cuts[:-1], cuts[1:]):
+            sf = fr.slab(z0, z1)
+            out = torch.empty(sf.words, dtype=torch.int32, device=engine.device)
+            below = g[(z0 - 1) * pw:z0 * pw] if z0 > 0 else None
+            above = g[z1 * pw:(z1 + 1) * pw] if z1 < n else None
+            engine.ctx.surface(sf, g[z0 * pw:z1 * pw].data_ptr(), below.data_ptr() if below is not None else None,
+                               above.data_ptr() if above is not None else None, out.data_ptr())
+            parts.append(engine.words_to_numpy(out).copy())
+            engine.ctx.surface(sf, g[z0 * pw:z1 * pw].data_ptr(), None, None, out.data_ptr())
+            closed.append(engine.words_to_numpy(out).copy())
+        assert np.array_equal(np.concatenate(parts), whole), n
+        iso = np.concatenate(closed)
+        w = engine.words_to_numpy(g)
+        for z in cuts[1:-1]:                                       # set voxels of the two planes at a cut are all border voxels then
+            for zz in (z - 1, z):
+                assert np.array_equal(iso[zz * pw:(zz + 1) * pw], w[zz * pw:(zz + 1) * pw]), (n, zz)
+
+
 def test_surface_mask_is_jfa_zero_set(engine):
     m = M.import_mesh(M.asset("bunny.obj"))
     fr, origin, vs = _frame([m], 128)
