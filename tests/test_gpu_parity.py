@@ -615,7 +615,7 @@ def test_extract_records_match_numpy(engine):
                 assert np.array_equal(r2[:10].view(np.uint64), exp[:10]) and (r2[10:] == -1).all()
 
 
-@pytest.mark.parametrize("n,kind", [(512, "noise"), (512, "sparse"), (512, "mesh"), (1024, "sparse"), (288, "noise"), (1152, "noise")])
+@pytest.mark.parametrize("n,kind", [(512, "noise"), (512, "sparse"), (512, "mesh"), (1024, "sparse"), (288, "noise"), (1152, "noise"), (256, "noise"), (1024, "noise")])
 def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
     """Pass by pass, on the SAME input state: the packed seed ids the tile kernels write (sparse, dense with the
     v_min_f64 pair update, every k; and the first pass in its from-the-border-mask form) equal those of the one-thread-per-voxel kernel, which walks the 27
