@@ -2093,9 +2093,12 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     if constexpr (!dense_wide<ID>()) {
         constexpr uint32_t NTC = ID::kTab == 512 ? 256u : 512u;
         if (VP_DENSE_CLOSED && pairs >= 2 && pow2 && !fin && f.z0 == 0 && f.z1 == f.n && f.n == 8u * k && f.n % NTC == 0) {
-            constexpr int RYC = ID::kTab == 512 ? 8 : 4, CL = ID::kTab == 512 ? 3 : 2;
+#ifndef VP_DENSE_CLOSED_ROWS
+#define VP_DENSE_CLOSED_ROWS 1    // 2-KB tables: close the rows as well (8 x 8 tiles); 0 = planes only (4 x 8 tiles), as with the 4-KB tables
+#endif
+            constexpr int RYC = (ID::kTab == 512 && VP_DENSE_CLOSED_ROWS) ? 8 : 4, CL = (ID::kTab == 512 && VP_DENSE_CLOSED_ROWS) ? 3 : 2;
             const uint32_t ty_ = nresY * ((ylen + RYC - 1) / RYC), t_ = ty_ * nres;          // one plane chain per tile
-            const uint32_t sp_ = f.n > NTC ? tail_split(ctx, t_, ID::kTab == 512 ? 4u : 3u) : 0u;
+            const uint32_t sp_ = f.n > NTC ? tail_split(ctx, t_, ID::kTab == 512 ? (RYC == 8 ? 4u : 6u) : 3u) : 0u;
             hipLaunchKernelGGL((jfa_pass_dense<ID, RYC, 8, NTC, false, true, false, 8, CL>), dim3(t_ + sp_), dim3(NTC), 0, ctx->stream, f, k,
                                (const T*)d_in, (T*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);
             return 0;
