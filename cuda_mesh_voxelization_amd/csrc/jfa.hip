@@ -610,7 +610,9 @@ __device__ __forceinline__ void pin(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(uint32_t& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(uint2& a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
 
-template <class ID, int TAB, int PXT, int RY, int CH, bool SKIP, bool CHECK_NONE, bool FINAL>
+// CZ (round 3): the tile's planes are a whole chain (CH = n / k, whole grid): the planes before the first and after the last output
+// plane lie outside the grid, and their iterations are removed at compile time (see the closed tiles of jfa_pass_dense).
+template <class ID, int TAB, int PXT, int RY, int CH, bool SKIP, bool CHECK_NONE, bool FINAL, bool CZ = false>
 #ifndef VP_ZSTREAM_WIDE_WAVES
 #define VP_ZSTREAM_WIDE_WAVES 0      // 8-byte ids: minimum waves per SIMD asked of the register allocator (0 = none: 143 VGPRs, 3 waves)
 #endif
@@ -851,19 +853,19 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
         };
 
         T wa[NI], wb[NI];
-        load_plane(zbase - K, wa, true);
+        if (!CZ) load_plane(zbase - K, wa, true);
         // No branch on `nout` around the planes: a plane that is not needed reads the row of "none" (never memory past
         // the slab's halo) and its outputs are simply not stored, so the whole chain stays one basic block.
 #pragma clang loop unroll(full)
         for (int P = -1; P <= CH; ++P) {
             T (&cur)[NI] = ((P + 1) & 1) ? wb : wa;                // P = -1 -> wa, 0 -> wb, ...
             T (&nxt)[NI] = ((P + 1) & 1) ? wa : wb;
-            if (P + 1 <= CH) load_plane(zbase + (P + 1) * K, nxt, P + 1 <= nout);   // in flight while P is evaluated
+            if (P + 1 <= CH - (CZ ? 1 : 0)) load_plane(zbase + (P + 1) * K, nxt, P + 1 <= nout);   // in flight while P is evaluated
             if (P + 1 < CH) {                                      // plane P is the first candidate plane of output P + 1
 #pragma unroll
                 for (int a = 0; a < RY; ++a) { best[a][P + 1] = ID::none(); bestd[a][P + 1] = INFINITY; }
             }
-            scatter(P, cur);
+            if (!(CZ && (P == -1 || P == CH))) scatter(P, cur);
 #pragma unroll
             for (int a = 0; a < RY; ++a) {
                 if (P >= 1 && P - 1 < nout && a < yout) store(a, P - 1);
@@ -1956,9 +1958,11 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     const bool skip = k * 4 >= f.n, fin = d_sdf != nullptr;
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k; // residue classes of the local plane index, planes per class
     const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
+    const bool closedZ = f.z0 == 0 && f.z1 == f.n && f.n == 8u * k;         // plane chains of exactly eight: no halo planes (CZ)
     // Tile = RY rows x CH planes per workgroup and the table size.
-#define VP_LAUNCH_CHAIN(TAB, PXT, RY, CH, S, C, F)                                                                                   \
-    hipLaunchKernelGGL((jfa_pass_zstream<ID, TAB, PXT, RY, CH, S, C, F>),                                                            \
+#define VP_LAUNCH_CHAIN(TAB, PXT, RY, CH, S, C, F) VP_LAUNCH_CHAIN_CZ(TAB, PXT, RY, CH, S, C, F, false)
+#define VP_LAUNCH_CHAIN_CZ(TAB, PXT, RY, CH, S, C, F, Z)                                                                            \
+    hipLaunchKernelGGL((jfa_pass_zstream<ID, TAB, PXT, RY, CH, S, C, F, Z>),                                                            \
                        VP_ZSTREAM_1D ? dim3(nresY * ((ylen + RY - 1) / RY) * nres * ((zlen + CH - 1) / CH)) : dim3(nresY * ((ylen + RY - 1) / RY), nres * ((zlen + CH - 1) / CH)), dim3(256), 0, ctx->stream, f, k,         \
                        (const T*)d_in, (const T*)d_minus, (const T*)d_plus, (T*)d_out, none_row, d_words, fill, d_sdf, nresY * ((ylen + RY - 1) / RY))
     // 64-bit ids: chk = n == table size, "none" has no spare table slot -> explicit test.  32-bit ids (U): the x table has one
@@ -1972,6 +1976,7 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
         if (skip)      { if (chk || U) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, true, true, false);  else VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, true, false, false); }  \
         else if (fin && deep) { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, !U, true);  else VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, false, true); }  \
         else if (fin)  { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, !U, true);   else VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, false, true); }  \
+        else if (deep && closedZ && CHD == 8) { if (chk) VP_LAUNCH_CHAIN_CZ(TAB, PXW, RY, CHD, false, !U, false, true); else VP_LAUNCH_CHAIN_CZ(TAB, PXW, RY, CHD, false, false, false, true); } \
         else if (deep) { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, !U, false); else VP_LAUNCH_CHAIN(TAB, PXW, RY, CHD, false, false, false); } \
         else           { if (chk) VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, !U, false);  else VP_LAUNCH_CHAIN(TAB, PXW, RY, CH, false, false, false); } \
     } while (0)
@@ -1980,6 +1985,7 @@ static int launch_chain(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     else VP_LAUNCH_TILE(1024, true, kRows, kPlanes, kPlanes);     // 4-KB tables: 4x8 costs occupancy (4.93 vs 4.70 ms at n = 1024)
 #undef VP_LAUNCH_TILE
 #undef VP_LAUNCH_CHAIN
+#undef VP_LAUNCH_CHAIN_CZ
     return 0;
 }
 
