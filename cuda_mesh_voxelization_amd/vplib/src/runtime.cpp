@@ -20,6 +20,10 @@ void SetDevice(int device) { g_device = device; }
 
 void SetDevices(const std::vector<int>& devices, bool ghost)
 {
+    if (g_multi && devices != g_devices) {                         // another device list: the slab driver is rebuilt on next use
+        vp_multi_destroy(g_multi);
+        g_multi = nullptr;
+    }
     g_devices = devices;
     g_ghost = ghost;
     if (!devices.empty()) g_device = devices[0];                   // exports and single-device calls use the first one

@@ -1,6 +1,7 @@
 // Exercises the C++ vplib mirror the way reference user code would (T = uint32_t and uint64_t,
 // every Types value) and prints FNV-1a-64 hashes for the Python test to compare with the oracle.
-//   api_check <obj> <n> <gpu:0|1>
+//   api_check <obj> <n> <gpu:0|1> [slabs]      slabs > 1: the GPU variants once more on that many Z-slabs (vplib::SetDevices; the
+//                                              contexts share device 0 here -- the code path is the multi-device one)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 #include <jfa/jfa.h>
 #include <mesh/mesh_io.h>
 #include <vox/vox.h>
+#include <vp_runtime.h>
 
 static uint64_t fnv(const void* p, size_t n)
 {
@@ -62,6 +64,16 @@ int main(int argc, char** argv)
         run<Types::NAIVE, uint64_t>("naive64", mesh, n, vs, o);
         run<Types::TILED, uint32_t>("tiled32", mesh, n, vs, o);
         run<Types::TILED, uint64_t>("tiled64", mesh, n, vs, o);
+        const int slabs = argc > 4 ? std::atoi(argv[4]) : 1;
+        if (slabs > 1) {
+            // what replaces the reference's cudaSetDevice(0) (apps/cli/main.cpp:22-23) for a library user with several GPUs
+            vplib::SetDevices(std::vector<int>(static_cast<size_t>(slabs), 0), /*ghost=*/false);
+            run<Types::TILED, uint32_t>("halo32", mesh, n, vs, o);
+            run<Types::NAIVE, uint64_t>("halo64", mesh, n, vs, o);
+            vplib::Shutdown();                                      // a new device list takes a new driver
+            vplib::SetDevices(std::vector<int>(static_cast<size_t>(slabs), 0), /*ghost=*/true);
+            run<Types::TILED, uint32_t>("ghost32", mesh, n, vs, o);
+        }
     }
     return 0;
 }

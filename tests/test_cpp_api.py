@@ -68,9 +68,10 @@ def test_cpp_api_cpu_variants(api_check):
 @pytest.mark.gpu
 def test_cpp_api_gpu_variants(api_check):
     exp = _expected("bunny.obj", 64)
-    p = subprocess.run([api_check, M.asset("bunny.obj"), "64", "1"], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([api_check, M.asset("bunny.obj"), "64", "1", "4"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
-    _check(p.stdout, ["seq32", "seq64", "omp32", "naive32", "naive64", "tiled32", "tiled64"], exp)
+    # ... and the same calls on four Z-slabs (vplib::SetDevices: halo copies, then ghost planes)
+    _check(p.stdout, ["seq32", "seq64", "omp32", "naive32", "naive64", "tiled32", "tiled64", "halo32", "halo64", "ghost32"], exp)
 
 
 def test_device_types_compile(device_types_check):
