@@ -159,7 +159,25 @@ vox_setup(Frame f, const float* __restrict__ xyz, size_t nverts, const uint32_t*
     if (t < ntris) valid = make_record(f, xyz, nverts, tri, t, r, sy, ey, sz, ez);
     const int ny = ey - sy, cells = valid ? ny * (ez - sz) : 0;
     const bool small = cells <= kSmallCells;
-    if (valid && small) {
+    // large triangles are rare in fine meshes: their records go to a COMPACT list (small ones write nothing at all --
+    // a 16-byte marker per triangle cost 0.4 ms on the 10.8M-face mesh).  The list holds what earlier calls needed (grow-only,
+    // the count comes back lazily like the work queue's); a large triangle that finds it full is walked right here, column by
+    // column, like a small one: slow for that call, correct for any input, and the next call has the room.
+    bool big = valid && !small;
+    bool walk = valid && small;
+    if (big) {
+        const uint32_t slot = atomicAdd(nbig, 1u);                // counts every large triangle, recorded or not
+        if (slot >= rec_cap) { big = false; walk = true; }
+        else {
+            uint4* dst = rec + (size_t)slot * 5;
+            dst[0] = make_uint4(__float_as_uint(r[0]),  __float_as_uint(r[1]),  __float_as_uint(r[2]),  __float_as_uint(r[3]));
+            dst[1] = make_uint4(__float_as_uint(r[4]),  __float_as_uint(r[5]),  __float_as_uint(r[6]),  __float_as_uint(r[7]));
+            dst[2] = make_uint4(__float_as_uint(r[8]),  __float_as_uint(r[9]),  __float_as_uint(r[10]), __float_as_uint(r[11]));
+            dst[3] = make_uint4(__float_as_uint(r[12]), __float_as_uint(r[13]), __float_as_uint(r[14]), __float_as_uint(r[15]));
+            dst[4] = make_uint4((uint32_t)sy | ((uint32_t)ey << 16), (uint32_t)sz | ((uint32_t)ez << 16), (uint32_t)t, 0u);
+        }
+    }
+    if (walk) {
         for (int i = 0; i < cells; ++i) {                         // same columns, same tests as the tile kernel
             const int y = sy + i % ny, z = sz + i / ny;
             int sx;
@@ -167,20 +185,6 @@ vox_setup(Frame f, const float* __restrict__ xyz, size_t nverts, const uint32_t*
                 const size_t row = ((size_t)(z - (int)f.z0) * f.n + (size_t)y) * f.w;
                 atomicXor(&toggles[row + (sx >> 5)], 1u << (sx & 31));
             }
-        }
-    }
-    // large triangles are rare in fine meshes: their records go to a COMPACT list (small ones write nothing at all --
-    // a 16-byte marker per triangle cost 0.4 ms on the 10.8M-face mesh)
-    const bool big = valid && !small;
-    if (big) {
-        const uint32_t slot = atomicAdd(nbig, 1u);
-        if (slot < rec_cap) {                                     // host re-runs with a larger list if this overflows
-            uint4* dst = rec + (size_t)slot * 5;
-            dst[0] = make_uint4(__float_as_uint(r[0]),  __float_as_uint(r[1]),  __float_as_uint(r[2]),  __float_as_uint(r[3]));
-            dst[1] = make_uint4(__float_as_uint(r[4]),  __float_as_uint(r[5]),  __float_as_uint(r[6]),  __float_as_uint(r[7]));
-            dst[2] = make_uint4(__float_as_uint(r[8]),  __float_as_uint(r[9]),  __float_as_uint(r[10]), __float_as_uint(r[11]));
-            dst[3] = make_uint4(__float_as_uint(r[12]), __float_as_uint(r[13]), __float_as_uint(r[14]), __float_as_uint(r[15]));
-            dst[4] = make_uint4((uint32_t)sy | ((uint32_t)ey << 16), (uint32_t)sz | ((uint32_t)ez << 16), (uint32_t)t, 0u);
         }
     }
     const int ty0 = sy / kTile, ty1 = big ? (ey - 1) / kTile : 0;
@@ -216,10 +220,10 @@ vox_scan(const uint32_t* __restrict__ cnt, uint32_t m, uint32_t* __restrict__ of
 // One thread per record of the compact large-triangle list.  The list length is only known on the device (*nbig):
 // the grid is fixed and strides over it, whole waves at a time (for_each_tile must be reached by all lanes).
 __global__ void __launch_bounds__(256)
-vox_scatter(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ nbig, uint32_t* __restrict__ cur,
+vox_scatter(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ nbig, uint32_t rec_cap, uint32_t* __restrict__ cur,
             uint32_t* __restrict__ pairs, uint32_t cap)
 {
-    const size_t nrec = *nbig;
+    const size_t nrec = min(*nbig, rec_cap);                       // triangles beyond the list's capacity were walked by vox_setup
     const int tilesY = f.n / kTile;
     const int tzBase = f.z0 / kTile;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -249,7 +253,7 @@ constexpr int kMaxW = 64;         // words per x-row at n = 2048
 // `cap` = capacity of `pairs`.  A tile whose slice of the work queue does not fit completely scans the whole record list
 // itself (correct for any input; the host grows the queue for the next call from the total it reads back lazily).
 __global__ void __launch_bounds__(256)
-vox_tile(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ nbig, const uint32_t* __restrict__ off,
+vox_tile(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ nbig, uint32_t rec_cap, const uint32_t* __restrict__ off,
          const uint32_t* __restrict__ pairs, uint32_t cap, uint32_t* tog)
 {
     const int tilesY = f.n / kTile;
@@ -264,7 +268,7 @@ vox_tile(Frame f, const uint4* __restrict__ rec, const uint32_t* __restrict__ nb
     const int W = f.w, stride = W + 1;
     const int ty = tile % tilesY, tzl = tile / tilesY;           // tzl: tile row inside the slab
     const bool listed = end <= cap;                               // the tile's slice of the work queue is complete
-    if (!listed) { begin = 0; end = *nbig; }
+    if (!listed) { begin = 0; end = min(*nbig, rec_cap); }
 
     const int rowWords = 64 * W;
     // global word index of LDS row r (= lz*8+ly), word w:  base + (r>>3)*n*W + (r&7)*W + w
@@ -450,10 +454,10 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
     }
 
     // ---- TILED (hybrid) ----
-    // Every stage is enqueued unconditionally and sized on the host from upper bounds: the record list can hold every
-    // triangle, the work queue keeps the capacity the previous calls needed (a tile whose slice does not fit scans the
-    // record list instead), scatter and tile kernels read the list sizes on the device and leave at once when there is
-    // nothing to do.  No read-back, no stream synchronisation: the call is asynchronous and graph-capturable.
+    // Every stage is enqueued unconditionally and sized on the host from what earlier calls needed: the record list and the
+    // work queue keep that capacity (a large triangle that finds the record list full is walked in place by vox_setup, a tile
+    // whose slice of the queue does not fit scans the record list instead), scatter and tile kernels read the list sizes on
+    // the device and leave at once when there is nothing to do.  No read-back, no stream synchronisation in steady state.
     const uint32_t tilesY = f.n / kTile;
     const uint32_t numTiles = tilesY * (uint32_t)(nz / kTile);
     VP_TRY(reserve(ctx, ctx->tile_cnt, ((size_t)numTiles + 1) * 4));
@@ -464,22 +468,27 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
     uint32_t* cur = (uint32_t*)ctx->tile_cur.ptr;
     uint32_t* d_nbig = cnt + numTiles;                             // one extra counter after the tile histogram
     if (ntris) {
-        // work-queue size of the previous call, if its copy has landed (never waited for)
+        // work-queue size and large-triangle count of the previous call, if their copies have landed (never waited for)
         if (ctx->vox_total_event && ctx->vox_total_pending && hipEventQuery(ctx->vox_total_event) == hipSuccess) {
             ctx->vox_total_pending = false;
-            ctx->vox_total_seen = std::max<uint64_t>(ctx->vox_total_seen, *ctx->vox_total_host);
+            ctx->vox_total_seen = std::max<uint64_t>(ctx->vox_total_seen, ctx->vox_total_host[0]);
+            ctx->vox_nbig_seen = std::max<uint64_t>(ctx->vox_nbig_seen, ctx->vox_total_host[1]);
         }
         const size_t want = std::max<size_t>((size_t)1 << 20, (size_t)ctx->vox_total_seen + ctx->vox_total_seen / 4);
         VP_TRY(reserve(ctx, ctx->pairs, want * 4));
-        VP_TRY(reserve(ctx, ctx->rec, ntris * (size_t)kRecDwords * 4));   // only the records of large triangles are ever touched
+        // record list: 64 Ki records (5 MiB) or what earlier calls needed + 25 %, never more than one per triangle
+        const size_t wantRec = std::min<size_t>(ntris, std::max<size_t>((size_t)1 << 16, (size_t)ctx->vox_nbig_seen + ctx->vox_nbig_seen / 4));
+        VP_TRY(reserve(ctx, ctx->rec, wantRec * (size_t)kRecDwords * 4));
         uint4* rec = (uint4*)ctx->rec.ptr;
+        uint32_t rcap = (uint32_t)std::min<size_t>(ctx->rec.bytes / ((size_t)kRecDwords * 4), ntris);
+        if (const char* e = getenv("VP_VOX_REC_CAP")) rcap = std::min<uint32_t>(rcap, (uint32_t)strtoul(e, nullptr, 10));   // tests: force the walk-in-place path
         uint32_t* pairs = (uint32_t*)ctx->pairs.ptr;
         uint32_t pcap = (uint32_t)std::min<size_t>(ctx->pairs.bytes / 4, 0xFFFFFFFFu);
         if (const char* e = getenv("VP_VOX_QUEUE_CAP")) pcap = std::min<uint32_t>(pcap, (uint32_t)strtoul(e, nullptr, 10));   // tests: force the overflow path
         VP_HIP(hipMemsetAsync(cnt, 0, ((size_t)numTiles + 1) * 4, st));
         {
             ProfScope p(ctx, VP_K_VOX_SETUP);
-            hipLaunchKernelGGL(vox_setup, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, rec, (uint32_t)ntris,
+            hipLaunchKernelGGL(vox_setup, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, rec, rcap,
                                d_nbig, cnt, tog);
         }
         {
@@ -487,22 +496,23 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
             hipLaunchKernelGGL(vox_scan, dim3(1), dim3(1024), 0, st, cnt, numTiles, off, cur);
         }
         if (!ctx->vox_total_host) {
-            VP_HIP(hipHostMalloc((void**)&ctx->vox_total_host, sizeof(uint32_t), hipHostMallocDefault));
-            *ctx->vox_total_host = 0;
+            VP_HIP(hipHostMalloc((void**)&ctx->vox_total_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
+            ctx->vox_total_host[0] = ctx->vox_total_host[1] = 0;
             VP_HIP(hipEventCreateWithFlags(&ctx->vox_total_event, hipEventDisableTiming));
         }
         if (!ctx->vox_total_pending) {                             // lazily: the next call may grow the queue from it
             VP_HIP(hipMemcpyAsync(ctx->vox_total_host, off + numTiles, 4, hipMemcpyDeviceToHost, st));
+            VP_HIP(hipMemcpyAsync(ctx->vox_total_host + 1, d_nbig, 4, hipMemcpyDeviceToHost, st));
             VP_HIP(hipEventRecord(ctx->vox_total_event, st));
             ctx->vox_total_pending = true;
         }
         {
             ProfScope p(ctx, VP_K_VOX_SCATTER);
-            hipLaunchKernelGGL(vox_scatter, dim3(std::min<unsigned>(tblocks, 1024u)), dim3(256), 0, st, f, rec, d_nbig, cur, pairs, pcap);
+            hipLaunchKernelGGL(vox_scatter, dim3(std::min<unsigned>(tblocks, 1024u)), dim3(256), 0, st, f, rec, d_nbig, rcap, cur, pairs, pcap);
         }
         {
             ProfScope p(ctx, VP_K_VOX_TILE);
-            hipLaunchKernelGGL(vox_tile, dim3(numTiles), dim3(256), 0, st, f, rec, d_nbig, off, pairs, pcap, tog);
+            hipLaunchKernelGGL(vox_tile, dim3(numTiles), dim3(256), 0, st, f, rec, d_nbig, rcap, off, pairs, pcap, tog);
         }
     }
     VP_TRY(launch_fill(ctx, f, tog, d_words, accumulate));

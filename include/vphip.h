@@ -102,9 +102,9 @@ size_t vp_grid_voxels(const vp_frame* f);
  *                   vox/tiled.cu:572-575); 1: XOR into the existing words (sequential semantics).
  * Asynchronous in steady state: list sizes stay on the device (no read-back, no stream synchronisation).  The FIRST call, and
  * any call that needs a larger internal buffer than the context has (grow-only), synchronises the stream and allocates:
- * 80 B per triangle for the record list of large triangles (sized for the worst case, every triangle large: 0.86 GB for the
- * 10.8 M-face mesh; only the records actually appended are touched), the tile work queue (>= 4 MiB, grows with what earlier
- * calls needed) and the 8 x 8-column tile tables. */
+ * the record list of large triangles (80 B each; 5 MiB, then what earlier calls counted + 25 %, at most one per triangle -- a
+ * large triangle that finds it full is rasterised in place, so any size is correct), the tile work queue (>= 4 MiB, grows
+ * the same way) and the 8 x 8-column tile tables. */
 int vp_voxelize(vp_ctx* ctx, const vp_frame* f, uint32_t* d_words,
                 const float* d_xyz, size_t nverts, const uint32_t* d_tri, size_t ntris,
                 int algo, int accumulate);

@@ -118,6 +118,32 @@ def test_voxelize_work_queue_overflow_path(engine, monkeypatch):
         assert np.array_equal(got, exp), (name, n)
 
 
+def test_voxelize_record_list_overflow_path(engine):
+    """The list of large-triangle records is sized from what earlier calls counted; a large triangle that finds it full is
+    rasterised in place by the setup kernel.  VP_VOX_REC_CAP forces that: a record list of 0 / 3 / 7 entries for a mesh of 20
+    huge triangles (child processes: the switch is read per call, the contexts are fresh) -- same bitmask, bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from cuda_mesh_voxelization_amd import mesh as M\n"
+        "from cuda_mesh_voxelization_amd.capi import Frame, ALGO_TILED\n"
+        "from cuda_mesh_voxelization_amd.pipeline import Engine\n"
+        "from oracle import oracle as O\n"
+        "eng = Engine(0)\n"
+        "for name, n in (('d20.obj', 256), ('torus.obj', 128), ('sphere.obj', 512)):\n"
+        "    xyz, tri = M.import_mesh(M.asset(name)); origin, vs = M.frame([xyz], n); fr = Frame.make(n, vs, origin)\n"
+        "    dx, dt = eng.mesh_to_device(xyz, tri)\n"
+        "    for rep in range(3):\n"                                  # the second and third call see the lazily read counts
+        "        g = eng.voxelize(fr, dx, dt, algo=ALGO_TILED); eng.sync()\n"
+        "        assert np.array_equal(eng.words_to_numpy(g), O.voxelize(xyz, tri, n, vs, origin)), (name, n, rep)\n"
+        "print('ok')\n" % root)
+    for cap in ("0", "3", "7"):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VP_VOX_REC_CAP=cap))
+        assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (cap, p.stdout[-500:], p.stderr[-2000:])
+
+
 def test_prof_select_times_only_the_named_kernels(engine):
     """vp_prof_select: bench.py brackets only the dominant kernel inside its timed region; the launch counts are exact."""
     n = 256
