@@ -1038,14 +1038,11 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     constexpr int NI = NR * NC;
     static_assert(!PM || (!SKIP && !WIDE), "pair mode: dense 32-bit-id passes");
     constexpr int CHT = WIDE ? 1 : CH;                             // z tables: squared differences per output plane / one table of positions
-#ifndef VP_DENSE_WIDE_YPOS
-#define VP_DENSE_WIDE_YPOS 0      // 1: 8-byte ids with a y table of positions too (24 KB of LDS, 256 threads, four workgroups per CU) instead of
-#endif                            // RY tables of squared differences (48 KB, 512 threads, two workgroups): measured 52.7 against 51.2 ms per pass
-    constexpr bool YPOS = WIDE && VP_DENSE_WIDE_YPOS;
-    constexpr int RYT = YPOS ? 1 : RY;
+    // (8-byte ids with a y table of POSITIONS too -- 24 KB of LDS, 256 threads, four workgroups per CU -- instead of RY tables of squared
+    // differences -- 48 KB, 512 threads, two workgroups: measured 52.7 against 51.2 ms per pass at n = 2048, removed.)
     using B = typename std::conditional<FINAL, float, double>::type;
     __shared__ float PX[PXT];
-    __shared__ __attribute__((aligned(16))) float TY[RYT / EY][TAB][EY];
+    __shared__ __attribute__((aligned(16))) float TY[RY / EY][TAB][EY];
     __shared__ __attribute__((aligned(16))) float TZ[CHT / EZ][TAB][EZ];
     __shared__ uint32_t RB[WIDE ? (CH + 2) * NR : 1];              // WIDE: row number (inside the id buffer) of every source row of the tile
     constexpr bool GM = final_mask_global<ID>();
@@ -1057,13 +1054,11 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     const uint32_t tid = threadIdx.x;
     const int nresY = min(K, N);
     const bool rev = ((31 - __builtin_clz(k)) & 1) != 0;          // alternate the traversal direction between passes
-#ifndef VP_DENSE_XCD
-#define VP_DENSE_XCD 0
-#endif
     // Workgroups are dealt round-robin to the 8 XCDs (dispatch index mod 8), each with its own L2, so neighbouring tiles --
     // which share halo rows and planes -- land on different L2s.  Re-mapping the dispatch index so that each XCD walks one
-    // contiguous eighth of the tile sequence (-DVP_DENSE_XCD=1) was measured twice (round 1: +-0; round 2, tools/ab_pass.py:
-    // -1 % .. +1 % at n = 512, 0 .. -4 % at n = 1024): the halos come from the Infinity Cache either way.  Off.
+    // contiguous eighth of the tile sequence was measured twice (round 1: +-0; round 2, tools/ab_pass.py: -1 % .. +1 % at
+    // n = 512, 0 .. -4 % at n = 1024; round 3 together with the tile order below: +1.5 % / +5 %): the halos come from the
+    // Infinity Cache either way, and the pass is not traffic-bound.  Removed.
     // Units in dispatch order: whole tiles first, then the last `splitTiles` tiles as two half-row units each (x halves), so
     // that what the chip runs while it drains is made of short units (see launch_dense).
     uint32_t lin = blockIdx.x;
@@ -1073,25 +1068,12 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         const uint32_t u = lin - (total - splitTiles);
         lin = total - splitTiles + (u >> 1); xpart = u & 1u; xparts = 2;
     }
-    if (VP_DENSE_XCD && total % 8u == 0u) lin = (lin % 8u) * (total / 8u) + lin / 8u;
     if (rev) lin = total - 1u - lin;
     const int nres = min(K, nzl);
-#ifndef VP_DENSE_ORDER
-#define VP_DENSE_ORDER 0
-#endif
-    // Tile order.  0: y residue fastest -- consecutive tiles are adjacent rows of the volume and share nothing.  1: the tiles of
-    // one (y residue, z residue) pair -- the only tiles that share halo rows and planes -- are consecutive, chunk along y fastest,
-    // so that the rows two neighbours both read are requested at about the same time (measured: profiles/r03/ab_order_*.txt).
-    uint32_t bx, by;
-    if (VP_DENSE_ORDER == 1) {
-        const uint32_t ncy = tilesY / (uint32_t)nresY, tilesZ = total / tilesY, ncz = tilesZ / (uint32_t)nres;
-        const uint32_t cy = lin % ncy; uint32_t t = lin / ncy;
-        const uint32_t cz = t % ncz; t /= ncz;
-        bx = t % (uint32_t)nresY + cy * (uint32_t)nresY;
-        by = t / (uint32_t)nresY + cz * (uint32_t)nres;
-    } else {
-        bx = lin % tilesY; by = lin / tilesY;
-    }
+    // Tile order: y residue fastest -- consecutive tiles are adjacent rows of the volume and share nothing.  (Making the tiles of
+    // one (y residue, z residue) pair -- the only ones that share halo rows and planes -- consecutive, so that the rows two
+    // neighbours both read are requested at about the same time: +1.5 % / +5 %, profiles/r03/ab_order_*.txt.  Removed.)
+    const uint32_t bx = lin % tilesY, by = lin / tilesY;
     const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
     const int lbase = (int)(by % nres) + (int)(by / nres) * CH * K;
     if (ybase >= N || lbase >= nzl) return;
@@ -1106,11 +1088,8 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         if (i < (uint32_t)N) {
             const uint32_t si = scr(i);
             const float sy = axis_pos(f.oy, i, f.vs), sz = axis_pos(f.oz, i, f.vs);
-            if (YPOS) TY[0][si][0] = sy;
-            else {
 #pragma unroll
-                for (int j = 0; j < RYT; ++j) { const float d = sy - py[j]; TY[j / EY][si][j % EY] = d * d; }
-            }
+            for (int j = 0; j < RY; ++j) { const float d = sy - py[j]; TY[j / EY][si][j % EY] = d * d; }
             if (WIDE) TZ[0][si][0] = sz;
             else {
 #pragma unroll
@@ -1118,7 +1097,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             }
         } else {                                                   // slots no real id refers to ("none" does: TAB - 1); finite: inf + it = inf
 #pragma unroll
-            for (int j = 0; j < RYT; ++j) TY[j / EY][i][j % EY] = 0.0f;
+            for (int j = 0; j < RY; ++j) TY[j / EY][i][j % EY] = 0.0f;
 #pragma unroll
             for (int j = 0; j < CHT; ++j) TZ[j / EZ][i][j % EZ] = 0.0f;
         }
@@ -1232,17 +1211,11 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             d.sx = lds_f32(tx + ID::xoff(id));                              // 32-bit ids: "none" reads slot TAB = +inf
             if constexpr (WIDE) d.sx = ID::is_none(id) ? INFINITY : d.sx;   // (inf - px)^2 = inf: "none" loses every '<'
             const uint32_t yo = ID::yoff(id), zo = ID::zoff(id);
-#if defined(VP_ABL_NOLDS)
+#if defined(VP_ABL_NOLDS)                                                  // VP_ABL_*: ablation builds for the pipe analysis of DESIGN.md section 4 (WRONG results, timing only)
             for (int a = 0; a < RY; ++a) d.dy2[a] = __uint_as_float(yo + a);
             for (int o = 0; o < CH; ++o) d.dz2[o] = __uint_as_float(zo + o);
 #else
-            if constexpr (YPOS) {
-                const float sy = lds_f32(ty + yo);
-#pragma unroll
-                for (int a = alo; a <= ahi; ++a) { const float dyv = sy - py[a]; d.dy2[a] = dyv * dyv; }
-            } else {
-                lds_span<RY, EY, TAB>(ty, yo, alo, ahi, d.dy2);
-            }
+            lds_span<RY, EY, TAB>(ty, yo, alo, ahi, d.dy2);
             if constexpr (WIDE) {
                 const float sz = lds_f32(tz + zo);                          // seed z position; the squares per output plane are formed here
 #pragma unroll
@@ -1408,27 +1381,12 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                     }
                 }
             }
-#ifndef VP_DENSE_END_SKIP
-#define VP_DENSE_END_SKIP 0
-#endif
-            // (dev, off) The planes before the first and after the last output plane may lie outside the grid (one of them does for every
-            // tile at k = n/16, for half the tiles at n/32, ...): then they hold nothing but "none" and could be skipped with a
-            // workgroup-uniform branch.  Measured: a branch around EVERY plane and around the first / last row +1.7 % (and spills with
-            // the rows), a branch at the two ends of the chain only -0.3 % / +0.3 % (profiles/r03/ab_edge_*.txt, ab_endskip_*.txt): what
-            // pays is removing the halo at compile time, which only the closed tiles of k = n/8 can.
-            const bool endPlane = P == -1 || P == CH;
-            const bool endOutside = endPlane && (zbase + P * K < 0 || zbase + P * K >= N || P > nout);
-            if (CZ && endPlane) {
-                // closed tiles have no plane before the first or after the last
-            } else if (VP_DENSE_END_SKIP && !SKIP && ROLL && endPlane && endOutside) {
-                if (P + 1 <= CH) {
-                    const Plane next = plane_of(zbase + (P + 1) * K, P + 1 <= nout);
-#pragma unroll
-                    for (int rr = 0; rr < NR; ++rr) load_row(next, rr, cur);
-                }
-            } else {
-                scatter(P, cur);
-            }
+            // The planes before the first and after the last output plane may lie outside the grid (one of them does for every tile at
+            // k = n/16, for half the tiles at n/32, ...): then they hold nothing but "none" and could be skipped with a workgroup-uniform
+            // branch.  Measured: a branch around EVERY plane and around the first / last row +1.7 % (and spills with the rows), a branch at
+            // the two ends of the chain only -0.3 % / +0.3 % (profiles/r03/ab_edge_*.txt, ab_endskip_*.txt) -- removed: what pays is
+            // dropping the halo at compile time, which only the closed tiles of k = n/8 can.
+            if (!(CZ && (P == -1 || P == CH))) scatter(P, cur);      // closed tiles have no plane before the first or after the last
             if constexpr (FINAL) {
                 if (P >= 1 && P - 1 < nout) {
 #pragma unroll
@@ -2059,7 +2017,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     // Tile 4 rows x 8 planes when the plane chains divide by 8, else 4 x 4.  2-KB tables (n <= 512): 256 threads, 26 KB of LDS,
     // six workgroups per CU.  4-KB tables: the 4 x 8 tile takes 52 KB, shared by the 8 waves of a 512-thread workgroup (three per CU).
 #ifndef VP_DENSE_WIDE_NT
-#define VP_DENSE_WIDE_NT 512      // threads per workgroup with 8-byte ids (256 with -DVP_DENSE_WIDE_YPOS=1)
+#define VP_DENSE_WIDE_NT 512      // threads per workgroup with 8-byte ids
 #endif
 #ifndef VP_DENSE_RY
 #define VP_DENSE_RY 4             // output rows per tile (dev: 8 = 4.7 decoded ids per voxel instead of 5.6, 109 VGPRs, four waves per SIMD)
