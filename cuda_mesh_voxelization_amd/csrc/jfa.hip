@@ -2149,8 +2149,12 @@ extern "C" int vp_dev_first_two_times(unsigned long long* out16, int reset)
     static std::vector<unsigned long long> host((size_t)kFtSlots * 16);
     if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_ft_slots), host.size() * 8) != hipSuccess) return 1;
     for (int i = 0; i < 16; ++i) out16[i] = 0;
+    // VP_FT_PHASE=p: only the tiles with tile % VP_FIRST_TWO_TPW == p (first, second, ... tile of a workgroup)
+    const char* ph = getenv("VP_FT_PHASE");
+    const long phase = ph ? atol(ph) : -1;
     for (size_t w = 0; w < kFtSlots; ++w)
-        for (int i = 0; i < 16; ++i) out16[i] += host[w * 16 + i];
+        if (phase < 0 || (long)(w % VP_FIRST_TWO_TPW) == phase)
+            for (int i = 0; i < 16; ++i) out16[i] += host[w * 16 + i];
     if (reset) { std::fill(host.begin(), host.end(), 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(g_ft_slots), host.data(), host.size() * 8) != hipSuccess) return 1; }
     return 0;
 }
