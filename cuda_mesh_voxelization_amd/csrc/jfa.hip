@@ -1459,6 +1459,46 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 // The minimum is commutative, so the loops run (row, column, plane): dx^2 + dy^2 is formed once per row and column.
 // The minimum is commutative, so the loops run (row, column, plane): dx^2 + dy^2 is formed once per row and column.  (Spreading
 // the 27 proposals of a seed over nine threads was measured: -3 % at n = 1024, +5 .. 14 % at n = 512, profiles/r02/ab34.txt.)
+// An empty slot holds (+inf, rank 0, slot 0): every key with a finite distance is smaller, and a proposal whose distance is not
+// finite (sequential.cpp:106 never takes such a candidate) is >= it and leaves the slot as it is -- no test needed.
+constexpr unsigned long long kEmptyKey = 0x7F80000000000000ull;
+
+// STEP = 2 (the pass with k = n/2 inside a closed 4-chain tile): along each axis a voxel has exactly two in-grid chain positions two
+// steps apart -- its own and position ^ 2 -- so a seed has 8 targets, all valid: no tests, no branches (the general form below
+// compiles to 27 predicated blocks of which a wave of border voxels executes every one).  Scan index of s as seen from the partner
+// along an axis: partner = position - t * 2 with t = +1 if position >= 2 else -1, i.e. t + 1 = position & 2.
+// Measured (profiles/r03/ab_propose_*.txt): jfa_first_two 0.339 -> 0.311 ms at n = 512, 2.56 -> 2.37 ms at n = 1024.  The same idea for
+// STEP = 1 -- 27 straight-line minima, targets outside the chain neutralised with the key ~0 -- trades 4 SALU for 2 VALU per candidate
+// and gave the gain back (0.338 / 2.53): the kernel is bound by vector issue of the one wave that proposes.
+template <int XR>
+__device__ __forceinline__ void propose_half(unsigned long long* keys, uint32_t s, float sx, float sy, float sz, const Frame& f,
+                                             uint32_t rx0, uint32_t ry, uint32_t rz, uint32_t k)
+{
+    const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
+    float dx2[2], dy2[2], dz2[2];
+#pragma unroll
+    for (uint32_t j = 0; j < 2; ++j) {                             // 0: the seed's own chain position, 1: the partner's
+        const float dxv = sx - axis_pos(f.ox, rx0 + xr + (xs ^ (2u * j)) * k, f.vs);
+        const float dyv = sy - axis_pos(f.oy, ry + (jr ^ (2u * j)) * k, f.vs);
+        const float dzv = sz - axis_pos(f.oz, rz + (jp ^ (2u * j)) * k, f.vs);
+        dx2[j] = dxv * dxv; dy2[j] = dyv * dyv; dz2[j] = dzv * dzv;
+    }
+    const uint32_t ra[2] = {1u, xs & 2u}, rb[2] = {3u, (jr & 2u) * 3u}, rc[2] = {9u, (jp & 2u) * 9u};      // (t + 1) * {1, 3, 9}
+#pragma unroll
+    for (uint32_t ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (uint32_t ia = 0; ia < 2; ++ia) {
+            const float pre = dx2[ia] + dy2[ib];
+#pragma unroll
+            for (uint32_t ic = 0; ic < 2; ++ic) {
+                const float d = pre + dz2[ic];
+                const uint32_t rank = (ia | ib | ic) ? rc[ic] + rb[ib] + ra[ia] + 1u : 0u;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | ((rank << 27) | s);
+                __hip_atomic_fetch_min(&keys[s ^ (ia * 2u * XR) ^ (ib * 8u * XR) ^ (ic * 32u * XR)], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+}
+
 template <int XR, int STEP>
 __device__ __forceinline__ void propose(unsigned long long* keys, uint32_t s, float sx, float sy, float sz, const Frame& f,
                                         uint32_t rx0, uint32_t ry, uint32_t rz, uint32_t k)
@@ -1487,8 +1527,7 @@ __device__ __forceinline__ void propose(unsigned long long* keys, uint32_t s, fl
             for (int c = -1; c <= 1; ++c) {
                 if (!vc[c + 1]) continue;
                 const float d = pre + dz2[c + 1];
-                const bool own = a == 0 && b == 0 && c == 0;
-                if (!own && !(d < INFINITY)) continue;             // sequential.cpp:106 never takes such a candidate
+                const bool own = a == 0 && b == 0 && c == 0;       // (a distance that is not finite never wins: kEmptyKey)
                 const uint32_t rank = own ? 0u : (uint32_t)((c + 1) * 9 + (b + 1) * 3 + (a + 1) + 1);
                 const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | ((rank << 27) | s);
                 __hip_atomic_fetch_min(&keys[t0 + (uint32_t)((1 - c) * STEP) * (16u * XR)], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1513,7 +1552,7 @@ jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 {
     using T = typename ID::T;
     constexpr uint32_t SLOTS = 64u * XR;                           // slot = ((plane * 4 + row) * 4 + segment) * XR + residue
-    constexpr unsigned long long kEmpty = 0x7F800000FFFFFFFFull;   // (+inf, no candidate)
+    constexpr unsigned long long kEmpty = kEmptyKey;
     __shared__ unsigned long long keys[SLOTS];
     __shared__ T ids[SLOTS];
     __shared__ uint16_t list[SLOTS];
@@ -1602,6 +1641,9 @@ __device__ unsigned long long g_ft_slots[kFtSlots][16];          // one row per 
 // tile sequence, the next tile's mask words requested a tile ahead -- ran 0.493 ms against 0.404 (n = 512) and 3.44 against 2.92
 // (n = 1024).  The launch already keeps 7.5 of 8 wave slots per SIMD occupied (SQ_WAVE_CYCLES is in quad-cycles), so there was no
 // dispatch gap to close, and workgroups that start together walk their five stages in step and meet at the LDS.
+#ifndef VP_PROPOSE_HALF
+#define VP_PROPOSE_HALF 1
+#endif
 template <class ID, int XR, int NT, int TPW>
 __global__ void __launch_bounds__(NT)
 jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out, uint32_t tilesX, uint32_t tiles)
@@ -1609,7 +1651,7 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
     using T = typename ID::T;
     constexpr uint32_t SLOTS = 64u * XR;                           // slot = ((plane * 4 + row) * 4 + segment) * XR + residue
     constexpr int PER = (int)(SLOTS / NT);
-    constexpr unsigned long long kEmpty = 0x7F800000FFFFFFFFull;
+    constexpr unsigned long long kEmpty = kEmptyKey;
     constexpr uint16_t kNoSeed = 0xFFFFu;
     static_assert(SLOTS < 0xFFFFu && SLOTS % NT == 0, "tile");
     __shared__ unsigned long long keys[SLOTS];
@@ -1682,7 +1724,8 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
                 const uint32_t s = list[e];
                 uint32_t qx, qy, qz;
                 coords(seed_slot(s), qx, qy, qz);
-                propose<XR, STEP>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k);
+                if constexpr (STEP == 2 && VP_PROPOSE_HALF) propose_half<XR>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k);
+                else propose<XR, STEP>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k);
             }
         };
         // ---- stage A: border voxels -> pass with k = n/2
