@@ -1455,7 +1455,9 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 // ------------------------------------------------------------------------------------------ seed scatter: one proposal round
 // The seed at (sx, sy, sz), held by the voxel of slot s of a closed 4-chain tile (slot = ((plane * 4 + row) * 4 + segment) * XR +
 // residue), proposes itself to the voxels STEP chain positions away along each axis, s itself included (rank 0).
-//     key = distance bits << 32 | rank << 27 | s,   rank = 1 + scan index of s as seen from the target (sequential.cpp:84-112)
+//     key = distance bits << 32 | rank << 27 | tag,   rank = 1 + scan index of s as seen from the target (sequential.cpp:84-112)
+// (tag: what the winner is to be known by -- the slot s, or the slot of the seed it carries; it never decides a comparison, since two
+// proposals to one target with equal rank come from the same slot)
 // The minimum is commutative, so the loops run (row, column, plane): dx^2 + dy^2 is formed once per row and column.
 // The minimum is commutative, so the loops run (row, column, plane): dx^2 + dy^2 is formed once per row and column.  (Spreading
 // the 27 proposals of a seed over nine threads was measured: -3 % at n = 1024, +5 .. 14 % at n = 512, profiles/r02/ab34.txt.)
@@ -1478,9 +1480,9 @@ __device__ __forceinline__ void propose_half(unsigned long long* keys, uint32_t 
     float dx2[2], dy2[2], dz2[2];
 #pragma unroll
     for (uint32_t j = 0; j < 2; ++j) {                             // 0: the seed's own chain position, 1: the partner's
-        const float dxv = sx - axis_pos(f.ox, rx0 + xr + (xs ^ (2u * j)) * k, f.vs);
-        const float dyv = sy - axis_pos(f.oy, ry + (jr ^ (2u * j)) * k, f.vs);
-        const float dzv = sz - axis_pos(f.oz, rz + (jp ^ (2u * j)) * k, f.vs);
+        const float dxv = sx - axis_pos(f.ox, rx0 + xr + __umul24(xs ^ (2u * j), k), f.vs);
+        const float dyv = sy - axis_pos(f.oy, ry + __umul24(jr ^ (2u * j), k), f.vs);
+        const float dzv = sz - axis_pos(f.oz, rz + __umul24(jp ^ (2u * j), k), f.vs);
         dx2[j] = dxv * dxv; dy2[j] = dyv * dyv; dz2[j] = dzv * dzv;
     }
     const uint32_t ra[2] = {1u, xs & 2u}, rb[2] = {3u, (jr & 2u) * 3u}, rc[2] = {9u, (jp & 2u) * 9u};      // (t + 1) * {1, 3, 9}
@@ -1501,7 +1503,7 @@ __device__ __forceinline__ void propose_half(unsigned long long* keys, uint32_t 
 
 template <int XR, int STEP>
 __device__ __forceinline__ void propose(unsigned long long* keys, uint32_t s, float sx, float sy, float sz, const Frame& f,
-                                        uint32_t rx0, uint32_t ry, uint32_t rz, uint32_t k)
+                                        uint32_t rx0, uint32_t ry, uint32_t rz, uint32_t k, uint32_t tag)
 {
     const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
     float dx2[3], dy2[3], dz2[3];
@@ -1509,9 +1511,9 @@ __device__ __forceinline__ void propose(unsigned long long* keys, uint32_t s, fl
 #pragma unroll
     for (int t = -1; t <= 1; ++t) {                                // target = s - t STEP positions: s is its neighbour at +t
         va[t + 1] = xs - t * STEP <= 3u; vb[t + 1] = jr - t * STEP <= 3u; vc[t + 1] = jp - t * STEP <= 3u;   // unsigned: also rejects < 0
-        const float dxv = sx - axis_pos(f.ox, rx0 + xr + (xs - t * STEP) * k, f.vs);
-        const float dyv = sy - axis_pos(f.oy, ry + (jr - t * STEP) * k, f.vs);
-        const float dzv = sz - axis_pos(f.oz, rz + (jp - t * STEP) * k, f.vs);
+        const float dxv = sx - axis_pos(f.ox, rx0 + xr + __umul24(xs - t * STEP, k), f.vs);
+        const float dyv = sy - axis_pos(f.oy, ry + __umul24(jr - t * STEP, k), f.vs);
+        const float dzv = sz - axis_pos(f.oz, rz + __umul24(jp - t * STEP, k), f.vs);
         dx2[t + 1] = dxv * dxv; dy2[t + 1] = dyv * dyv; dz2[t + 1] = dzv * dzv;
     }
 #pragma unroll
@@ -1529,7 +1531,7 @@ __device__ __forceinline__ void propose(unsigned long long* keys, uint32_t s, fl
                 const float d = pre + dz2[c + 1];
                 const bool own = a == 0 && b == 0 && c == 0;       // (a distance that is not finite never wins: kEmptyKey)
                 const uint32_t rank = own ? 0u : (uint32_t)((c + 1) * 9 + (b + 1) * 3 + (a + 1) + 1);
-                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | ((rank << 27) | s);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | ((rank << 27) | tag);
                 __hip_atomic_fetch_min(&keys[t0 + (uint32_t)((1 - c) * STEP) * (16u * XR)], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
@@ -1567,7 +1569,7 @@ jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     constexpr uint32_t RPW = 4u * XR;
     constexpr uint32_t G = NT / RPW;
     static_assert(NT % RPW == 0 && RPW % 64u == 0, "a wave must stay inside one row-plane");
-    const uint32_t col = tid % RPW, myx = rx0 + col % XR + (col / XR) * k;
+    const uint32_t col = tid % RPW, myx = rx0 + col % XR + __umul24(col / XR, k);
     const bool xin = rx0 + col % XR < k;
     const uint32_t rpb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / RPW));
     auto row_of = [&](int i) {                                     // voxel index of x = 0 of the row-plane of iteration i
@@ -1587,7 +1589,7 @@ jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         const uint32_t s = tid + (uint32_t)i * NT;
         keys[s] = kEmpty;
         ids[s] = mine[i];
-        ms[i] = __ballot(!ID::is_none(mine[i]));
+        ms[i] = __builtin_amdgcn_ballot_w64(!ID::is_none(mine[i]));
         nmine += (uint32_t)__popcll(ms[i]);
     }
     uint32_t base = 0;
@@ -1604,7 +1606,7 @@ jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         const uint32_t s = list[e];
         const T id = ids[s];
         propose<XR, 1>(keys, s, axis_pos(f.ox, ID::xoff(id) >> 2, f.vs), axis_pos(f.oy, scr(ID::yoff(id) >> 2), f.vs),
-                       axis_pos(f.oz, scr(ID::zoff(id) >> 2), f.vs), f, rx0, ry, rz, k);
+                       axis_pos(f.oz, scr(ID::zoff(id) >> 2), f.vs), f, rx0, ry, rz, k, s);
     }
     __syncthreads();
     unsigned long long won[PER];
@@ -1646,18 +1648,16 @@ __device__ unsigned long long g_ft_slots[kFtSlots][16];          // one row per 
 #endif
 template <class ID, int XR, int NT, int TPW>
 __global__ void __launch_bounds__(NT)
-jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out, uint32_t tilesX, uint32_t tiles)
+jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out, uint32_t tilesX, uint32_t tiles, uint32_t shifts)
 {
     using T = typename ID::T;
     constexpr uint32_t SLOTS = 64u * XR;                           // slot = ((plane * 4 + row) * 4 + segment) * XR + residue
     constexpr int PER = (int)(SLOTS / NT);
     constexpr unsigned long long kEmpty = kEmptyKey;
-    constexpr uint16_t kNoSeed = 0xFFFFu;
-    static_assert(SLOTS < 0xFFFFu && SLOTS % NT == 0, "tile");
+    static_assert(SLOTS <= 0x10000u && SLOTS % NT == 0, "tile");
     __shared__ unsigned long long keys[SLOTS];
-    __shared__ uint16_t seedOf[SLOTS];                             // after stage A: slot of the voxel's pass-1 seed
     __shared__ T idOf[SLOTS];                                      // packed id of the voxel of a slot (what a seed at that slot is called)
-    __shared__ uint16_t list[SLOTS];
+    __shared__ uint32_t list[SLOTS];                               // entries: slot | slot of the seed it holds << 16
     __shared__ uint32_t cnt[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, N = f.n, k = N / 4u;
     // slot tid + i NT = row-plane (rpb + i G) x column `col` (see jfa_pass_seeds): row addresses are scalar work
@@ -1667,22 +1667,30 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
     const uint32_t col = tid % RPW;
     const uint32_t rpb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / RPW));
     // wave-cooperative append of the slots whose flag is set (one reservation per wave)
-    auto append = [&](const bool (&flag)[PER], uint32_t& counter) {
+    auto append = [&](const bool (&flag)[PER], const uint32_t (&seed)[PER], uint32_t& counter) {
         unsigned long long ms[PER];
         uint32_t n = 0;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { ms[i] = __ballot(flag[i]); n += (uint32_t)__popcll(ms[i]); }
+        for (int i = 0; i < PER; ++i) { ms[i] = __builtin_amdgcn_ballot_w64(flag[i]); n += (uint32_t)__popcll(ms[i]); }
+        if (n == 0) return;                                        // uniform; every lane of the wave is here (no divergence above)
         uint32_t base = 0;
-        if (lane == 0 && n) base = atomicAdd(&counter, n);
-        base = (uint32_t)__shfl((int)base, 0);
+        if (lane == 0) base = atomicAdd(&counter, n);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            if (flag[i]) list[base + (uint32_t)__popcll(ms[i] & ((1ull << lane) - 1ull))] = (uint16_t)(tid + (uint32_t)i * NT);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(ms[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms[i], 0u));
+            if (flag[i]) list[base + below] = (tid + (uint32_t)i * NT) | (seed[i] << 16);
             base += (uint32_t)__popcll(ms[i]);
         }
     };
+    // shifts = log2(tilesX) | log2(k) << 8 | 1 << 16 when both are powers of two: two run-time divisions per tile are ~50 instructions
+    // of a wave that executes ~450 in all (the kernel is issue-bound, see profiles/r03/first_two_stages_tpw2_n512.txt)
     auto tile_origin = [&](uint32_t t, uint32_t& rx0, uint32_t& ry, uint32_t& rz) {
-        rx0 = (t % tilesX) * XR; const uint32_t q = t / tilesX; ry = q % k; rz = q / k;
+        if (shifts >> 16) {
+            rx0 = (t & (tilesX - 1u)) * XR; const uint32_t q = t >> (shifts & 31u); ry = q & (k - 1u); rz = q >> ((shifts >> 8) & 31u);
+        } else {
+            rx0 = (t % tilesX) * XR; const uint32_t q = t / tilesX; ry = q % k; rz = q / k;
+        }
     };
     // A workgroup works through TPW consecutive tiles (default 1).  Their border words -- the only thing read from memory, and 37 % of
     // a one-tile workgroup's life spent waiting for them (profiles/r03/first_two_stages_n512.txt) -- are ALL requested before the
@@ -1694,12 +1702,12 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
     for (int u = 0; u < TPW; ++u) {
         uint32_t rx0, ry, rz;
         tile_origin(min(tile0 + u, tiles - 1u), rx0, ry, rz);
-        const uint32_t myx = rx0 + col % XR + (col / XR) * k;
+        const uint32_t myx = rx0 + col % XR + __umul24(col / XR, k);
         const bool xin = rx0 + col % XR < k;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const uint32_t rp = rpb + (uint32_t)i * G, y = ry + (rp & 3u) * k, z = rz + (rp >> 2) * k;
-            mw[u][i] = xin ? border[((size_t)z * N + y) * f.w + (myx >> 5)] : 0u;
+            mw[u][i] = xin ? border[(z * N + y) * f.w + (myx >> 5)] : 0u;          // < 2^28 words at n = 2048: 32-bit index arithmetic
         }
     }
 #pragma unroll
@@ -1708,28 +1716,29 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
         if (tile >= tiles) break;                                  // uniform
         uint32_t rx0, ry, rz;
         tile_origin(tile, rx0, ry, rz);
-        const uint32_t myx = rx0 + col % XR + (col / XR) * k;
+        const uint32_t myx = rx0 + col % XR + __umul24(col / XR, k);
         const bool xin = rx0 + col % XR < k;
         VP_FT_STAMP(0);
         if (tid < 2) cnt[tid] = 0;
-        __syncthreads();                                           // also: the previous tile's output stage has read keys / seedOf / idOf
+        __syncthreads();                                           // also: the previous tile's output stage has read keys / idOf
         VP_FT_STAMP(1);
         auto coords = [&](uint32_t s, uint32_t& x, uint32_t& y, uint32_t& z) {
-            x = rx0 + s % XR + ((s / XR) & 3u) * k; y = ry + ((s / (4u * XR)) & 3u) * k; z = rz + (s / (16u * XR)) * k;
+            x = rx0 + s % XR + __umul24((s / XR) & 3u, k); y = ry + __umul24((s / (4u * XR)) & 3u, k); z = rz + __umul24(s / (16u * XR), k);
         };
         // every entry of the list proposes the seed that sits at slot q (its coordinates are those of q) from slot s
-        auto scatter = [&](uint32_t nlist, auto seed_slot, auto step) {
+        auto scatter = [&](uint32_t nlist, auto step) {
             constexpr int STEP = decltype(step)::value;
             for (uint32_t e = tid; e < nlist; e += NT) {
-                const uint32_t s = list[e];
+                const uint32_t entry = list[e], s = entry & 0xFFFFu, q = entry >> 16;
                 uint32_t qx, qy, qz;
-                coords(seed_slot(s), qx, qy, qz);
+                coords(q, qx, qy, qz);
                 if constexpr (STEP == 2 && VP_PROPOSE_HALF) propose_half<XR>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k);
-                else propose<XR, STEP>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k);
+                else propose<XR, STEP>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k, q);
             }
         };
         // ---- stage A: border voxels -> pass with k = n/2
         bool flag[PER];
+        uint32_t seed[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const uint32_t s = tid + (uint32_t)i * NT;
@@ -1737,13 +1746,14 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
             flag[i] = xin && ((mw[u][i] >> (myx & 31u)) & 1u);
             keys[s] = kEmpty;
             idOf[s] = ID::pack(myx, y, z);
+            seed[i] = s;                                           // a border voxel is its own seed
         }
         VP_FT_STAMP(2);                                            // border words arrived (first tile of the workgroup), keys / ids written
-        append(flag, cnt[0]);
+        append(flag, seed, cnt[0]);
         VP_FT_STAMP(3);
         __syncthreads();
         VP_FT_STAMP(4);
-        scatter(cnt[0], [](uint32_t s) { return s; }, std::integral_constant<int, 2>{});
+        scatter(cnt[0], std::integral_constant<int, 2>{});
         VP_FT_STAMP(5);
         __syncthreads();
         VP_FT_STAMP(6);
@@ -1753,15 +1763,15 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
             const uint32_t s = tid + (uint32_t)i * NT;
             const unsigned long long key = keys[s];
             flag[i] = key != kEmpty;
-            seedOf[s] = flag[i] ? (uint16_t)((uint32_t)key & 0x07FFFFFFu) : kNoSeed;
+            seed[i] = (uint32_t)key & 0xFFFFu;                     // slot of the voxel's pass-1 seed (garbage where flag is false: not appended)
             keys[s] = kEmpty;                                      // own slots only: nobody else touches them before the barrier
         }
         VP_FT_STAMP(7);
-        append(flag, cnt[1]);
+        append(flag, seed, cnt[1]);
         VP_FT_STAMP(8);
         __syncthreads();
         VP_FT_STAMP(9);
-        scatter(cnt[1], [&](uint32_t s) { return (uint32_t)seedOf[s]; }, std::integral_constant<int, 1>{});
+        scatter(cnt[1], std::integral_constant<int, 1>{});
         VP_FT_STAMP(10);
         __syncthreads();
         VP_FT_STAMP(11);
@@ -1769,9 +1779,9 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
         for (int i = 0; i < PER; ++i) {
             if (!xin) continue;
             const unsigned long long key = keys[tid + (uint32_t)i * NT];
-            const T id = key == kEmpty ? ID::none() : idOf[seedOf[(uint32_t)key & 0x07FFFFFFu]];
+            const T id = key == kEmpty ? ID::none() : idOf[(uint32_t)key & 0x07FFFFFFu];       // stage B tags its proposals with the seed's slot
             const uint32_t rp = rpb + (uint32_t)i * G;
-            out[((size_t)(rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx] = id;
+            out[(size_t)((rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx] = id;
         }
         VP_FT_STAMP(12);
         VP_FT_FLUSH(tile);
@@ -1902,9 +1912,11 @@ int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, 
     const uint32_t xr = small ? 16u : 32u;
     const uint32_t tilesX = (k + xr - 1) / xr, tiles = tilesX * k * k;
     const dim3 grid((tiles + VP_FIRST_TWO_TPW - 1) / VP_FIRST_TWO_TPW);
-    if (wide(f))    hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles);
-    else if (small) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles);
-    else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles);
+    auto pow2 = [](uint32_t v) { return v != 0 && (v & (v - 1)) == 0; };
+    const uint32_t shifts = (pow2(tilesX) && pow2(k)) ? ((uint32_t)__builtin_ctz(tilesX) | ((uint32_t)__builtin_ctz(k) << 8) | (1u << 16)) : 0u;
+    if (wide(f))    hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles, shifts);
+    else if (small) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
+    else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
     VP_HIP(hipGetLastError());
     return 0;
 }
