@@ -41,6 +41,14 @@ namespace {
 // involution and stays inside [0, n) because n % 32 == 0.
 __device__ __forceinline__ uint32_t scr(uint32_t i) { return i ^ ((i >> 5) & 31u); }
 
+// a / b and a % b for workgroup-uniform operands: shifts when b is a power of two (it is for every power-of-two grid), the
+// ~25-instruction reciprocal sequence otherwise.  Three of these open every tile of the pass kernels.
+__device__ __forceinline__ void udivmod(uint32_t a, uint32_t b, uint32_t& q, uint32_t& r)
+{
+    if ((b & (b - 1u)) == 0u) { q = a >> (uint32_t)__builtin_ctz(b); r = a & (b - 1u); }
+    else { q = a / b; r = a % b; }
+}
+
 // Id formats.  An accessor returns a coordinate field as a BYTE offset into a table of floats (index * 4).
 //
 // 32-bit formats IdU<BITS> (BITS = 9: n <= 512, BITS = 10: n <= 1024).  x sits UNSHIFTED in the low BITS + 1 bits -- its
@@ -659,11 +667,13 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
 #define VP_ZSTREAM_1D 1
 #endif
     const uint32_t lin = rev ? gridDim.x * gridDim.y - 1 - (blockIdx.x + gridDim.x * blockIdx.y) : blockIdx.x + gridDim.x * blockIdx.y;
-    const uint32_t bx = lin % tilesY, by = lin / tilesY;
-    const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
+    uint32_t bx, by, bxq, bxr, byq, byr;
+    udivmod(lin, tilesY, by, bx); udivmod(bx, (uint32_t)nresY, bxq, bxr);
+    const int ybase = (int)bxr + (int)bxq * RY * K;
     // z: the same over the local plane index of the slab
     const int nres = min(K, nzl);
-    const int lbase = (int)(by % nres) + (int)(by / nres) * CH * K;
+    udivmod(by, (uint32_t)nres, byq, byr);
+    const int lbase = (int)byr + (int)byq * CH * K;
     if (ybase >= N || lbase >= nzl) return;
     const int zbase = lbase + (int)f.z0;                           // global plane of chain element 0
     float py[RY], pz[CH];                                          // positions of the output rows / planes (wave-uniform)
@@ -1073,9 +1083,11 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     // Tile order: y residue fastest -- consecutive tiles are adjacent rows of the volume and share nothing.  (Making the tiles of
     // one (y residue, z residue) pair -- the only ones that share halo rows and planes -- consecutive, so that the rows two
     // neighbours both read are requested at about the same time: +1.5 % / +5 %, profiles/r03/ab_order_*.txt.  Removed.)
-    const uint32_t bx = lin % tilesY, by = lin / tilesY;
-    const int ybase = (int)(bx % nresY) + (int)(bx / nresY) * RY * K;
-    const int lbase = (int)(by % nres) + (int)(by / nres) * CH * K;
+    uint32_t bx, by, bxq, bxr, byq, byr;
+    udivmod(lin, tilesY, by, bx); udivmod(bx, (uint32_t)nresY, bxq, bxr);
+    const int ybase = (int)bxr + (int)bxq * RY * K;
+    udivmod(by, (uint32_t)nres, byq, byr);
+    const int lbase = (int)byr + (int)byq * CH * K;
     if (ybase >= N || lbase >= nzl) return;
     const int zbase = lbase + (int)f.z0;
     float py[RY], pz[CH];
@@ -2075,8 +2087,12 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 #define VP_DENSE_WIDE_NT 512      // threads per workgroup with 8-byte ids
 #endif
 #ifndef VP_DENSE_RY
-#define VP_DENSE_RY 4             // output rows per tile (dev: 8 = 4.7 decoded ids per voxel instead of 5.6, 109 VGPRs, four waves per SIMD)
+#define VP_DENSE_RY 4             // output rows per tile
 #endif
+#ifndef VP_DENSE_RY_SMALL
+#define VP_DENSE_RY_SMALL 8       // ... of the id passes with the 2-KB tables (n <= 512): 8 rows = 109 VGPRs, four waves per SIMD, but half the tiles -- half the
+#endif                            // table builds and tile prologues -- and 3.1 instead of 3.75 decoded ids per voxel: dense -1.1 % at n = 512; with the 4-KB tables
+                                  // +1.1 %, the fused last pass +1.1 % / +5 % (profiles/r03/ab_ry8_*.txt): those keep 4 rows
 #ifndef VP_DENSE_PAIRS_DEFAULT
 #define VP_DENSE_PAIRS_DEFAULT 2  // pair mode (see jfa_pass_dense): 0 off, 1 the fused last pass only, 2 every dense pass too (profiles/r03/ab_pairs_*.txt)
 #endif
@@ -2084,10 +2100,11 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     const bool pow2 = (f.n & (f.n - 1)) == 0;
 #define VP_LAUNCH_DENSE_PM(CH, NT, F, S, PM)                                                                                       \
     do {                                                                                                                           \
-        const uint32_t ty_ = nresY * ((ylen + VP_DENSE_RY - 1) / VP_DENSE_RY), t_ = ty_ * nres * ((zlen + CH - 1) / CH);           \
+        constexpr int RY_ = (ID::kTab == 512 && !(F) && !(S) && CH == 8) ? VP_DENSE_RY_SMALL : VP_DENSE_RY;                         \
+        const uint32_t ty_ = nresY * ((ylen + RY_ - 1) / RY_), t_ = ty_ * nres * ((zlen + CH - 1) / CH);                           \
         /* a row of <= NT voxels has no halves */                                                                                  \
-        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, dense_wide<ID>() ? (NT == 256 ? 5u : 2u) : ID::kTab == 512 ? ((F) && !final_mask_global<ID>() ? 5u : 6u) : NT == 512 ? ((F) && !final_mask_global<ID>() ? 2u : 3u) : 4u) : 0u;                      \
-        hipLaunchKernelGGL((jfa_pass_dense<ID, VP_DENSE_RY, CH, NT, F, true, S, PM>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,        \
+        const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, dense_wide<ID>() ? (NT == 256 ? 5u : 2u) : ID::kTab == 512 ? (RY_ == 8 ? 4u : (F) && !final_mask_global<ID>() ? 5u : 6u) : NT == 512 ? ((F) && !final_mask_global<ID>() ? 2u : 3u) : 4u) : 0u;                      \
+        hipLaunchKernelGGL((jfa_pass_dense<ID, RY_, CH, NT, F, true, S, PM>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,                \
                            (const T*)d_in, (T*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                               \
     } while (0)
     // pair mode where it applies: 32-bit ids, n a power of two, whole rows of NT-thread iterations; the lane permutation follows k
