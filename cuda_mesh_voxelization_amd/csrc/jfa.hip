@@ -2093,6 +2093,9 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 #define VP_DENSE_RY_SMALL 8       // ... of the id passes with the 2-KB tables (n <= 512): 8 rows = 109 VGPRs, four waves per SIMD, but half the tiles -- half the
 #endif                            // table builds and tile prologues -- and 3.1 instead of 3.75 decoded ids per voxel: dense -1.1 % at n = 512; with the 4-KB tables
                                   // +1.1 %, the fused last pass +1.1 % / +5 % (profiles/r03/ab_ry8_*.txt): those keep 4 rows
+#ifndef VP_DENSE_K2_PLAIN
+#define VP_DENSE_K2_PLAIN 1
+#endif
 #ifndef VP_DENSE_PAIRS_DEFAULT
 #define VP_DENSE_PAIRS_DEFAULT 2  // pair mode (see jfa_pass_dense): 0 off, 1 the fused last pass only, 2 every dense pass too (profiles/r03/ab_pairs_*.txt)
 #endif
@@ -2114,7 +2117,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
             const bool pm_ = pow2 && f.n % NT == 0 && pairs >= ((F) ? 1 : 2) && ((F) || k >= 2);                                   \
             if (pm_ && (F))        { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 1); break; }                                                 \
             /* k = 2 with the 2-KB tables: the plain form is 7 % faster (0.370 vs 0.396 ms; with the 4-KB tables pairs win by 3 %) */ \
-            if (pm_ && k == 2 && ID::kTab == 512) { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 0); break; }                                  \
+            if (pm_ && k == 2 && ID::kTab == 512 && VP_DENSE_K2_PLAIN) { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 0); break; }                                  \
             if (pm_ && k == 2)     { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 2); break; }                                                 \
             if (pm_ && k == 4)     { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 4); break; }                                                 \
             if (pm_)               { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 8); break; }                                                 \
