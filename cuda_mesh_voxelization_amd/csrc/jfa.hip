@@ -1023,8 +1023,9 @@ __device__ __forceinline__ float from_partner(float v)
 // its own.  2 instead of 3.75 decoded ids per voxel (pair mode), 22.7 instead of 27 candidate steps (edge outputs have fewer
 // neighbours), at the price of 48 running-pair registers (four waves per SIMD).  Compile-time: the loops simply lose their halo
 // iterations.  Whole grids with n = 8 k only.  CLOSED is a mask: 1 = the rows of a tile are a whole chain (RY = n / k), 2 = the planes
-// are (CH = n / k); with the 4-KB tables (n = 1024) eight row tables do not fit the 64 KB a workgroup may have, so only the planes
-// are closed there (4 x 8 tiles, 3 decoded ids per voxel).
+// are (CH = n / k).  With the 4-KB tables (n = 1024) the 8 x 8 tile takes 68 KB of LDS -- more than the 64 KB of older parts, fine on
+// gfx950 (160 KB per CU, two 512-thread workgroups = four waves per SIMD, what the 109 VGPRs allow anyway): k = 128 at n = 1024
+// 2.83 -> 2.66 ms against the planes-only form (4 x 8 tiles, CLOSED = 2) that round 3 first shipped (profiles/r03/ab_clbig_1024.txt).
 template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP, int PM, int CLOSED = 0>
 #ifndef VP_DENSE_WIDE_WAVES
 #define VP_DENSE_WIDE_WAVES 4
@@ -2135,11 +2136,11 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
         constexpr uint32_t NTC = ID::kTab == 512 ? 256u : 512u;
         if (VP_DENSE_CLOSED && pairs >= 2 && pow2 && !fin && f.z0 == 0 && f.z1 == f.n && f.n == 8u * k && f.n % NTC == 0) {
 #ifndef VP_DENSE_CLOSED_ROWS
-#define VP_DENSE_CLOSED_ROWS 1    // 2-KB tables: close the rows as well (8 x 8 tiles); 0 = planes only (4 x 8 tiles), as with the 4-KB tables
+#define VP_DENSE_CLOSED_ROWS 1    // close the rows as well (8 x 8 tiles); 0 = planes only (4 x 8 tiles)
 #endif
-            constexpr int RYC = (ID::kTab == 512 && VP_DENSE_CLOSED_ROWS) ? 8 : 4, CL = (ID::kTab == 512 && VP_DENSE_CLOSED_ROWS) ? 3 : 2;
+            constexpr int RYC = VP_DENSE_CLOSED_ROWS ? 8 : 4, CL = VP_DENSE_CLOSED_ROWS ? 3 : 2;
             const uint32_t ty_ = nresY * ((ylen + RYC - 1) / RYC), t_ = ty_ * nres;          // one plane chain per tile
-            const uint32_t sp_ = f.n > NTC ? tail_split(ctx, t_, ID::kTab == 512 ? (RYC == 8 ? 4u : 6u) : 3u) : 0u;
+            const uint32_t sp_ = f.n > NTC ? tail_split(ctx, t_, ID::kTab == 512 ? (RYC == 8 ? 4u : 6u) : (RYC == 8 ? 2u : 3u)) : 0u;
             hipLaunchKernelGGL((jfa_pass_dense<ID, RYC, 8, NTC, false, true, false, 8, CL>), dim3(t_ + sp_), dim3(NTC), 0, ctx->stream, f, k,
                                (const T*)d_in, (T*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);
             return 0;
