@@ -1485,17 +1485,34 @@ constexpr unsigned long long kEmptyKey = 0x7F80000000000000ull;
 // Measured (profiles/r03/ab_propose_*.txt): jfa_first_two 0.339 -> 0.311 ms at n = 512, 2.56 -> 2.37 ms at n = 1024.  The same idea for
 // STEP = 1 -- 27 straight-line minima, targets outside the chain neutralised with the key ~0 -- trades 4 SALU for 2 VALU per candidate
 // and gave the gain back (0.338 / 2.53): the kernel is bound by vector issue of the one wave that proposes.
+// Where the positions of a tile's chain members come from: computed (cvt, mul, add and the index arithmetic before them: ~5
+// instructions per position, nine positions per proposal round), or read from three small LDS tables the tile fills once
+// (jfa_first_two: the proposing wave's instruction stream is the tile's critical path).  Chain positions outside 0..3 are only ever
+// asked for targets that are then skipped; the tables wrap them, the arithmetic lets them run wild.
+struct ChainPosCalc {
+    const Frame& f; uint32_t rx0, ry, rz, k;
+    __device__ __forceinline__ float x(uint32_t seg, uint32_t xr) const { return axis_pos(f.ox, rx0 + xr + __umul24(seg, k), f.vs); }
+    __device__ __forceinline__ float y(uint32_t j) const { return axis_pos(f.oy, ry + __umul24(j, k), f.vs); }
+    __device__ __forceinline__ float z(uint32_t j) const { return axis_pos(f.oz, rz + __umul24(j, k), f.vs); }
+};
 template <int XR>
-__device__ __forceinline__ void propose_half(unsigned long long* keys, uint32_t s, float sx, float sy, float sz, const Frame& f,
-                                             uint32_t rx0, uint32_t ry, uint32_t rz, uint32_t k)
+struct ChainPosLds {
+    const float* px; const float* py; const float* pz;             // [4 * XR], [4], [4]
+    __device__ __forceinline__ float x(uint32_t seg, uint32_t xr) const { return px[(seg & 3u) * XR + xr]; }
+    __device__ __forceinline__ float y(uint32_t j) const { return py[j & 3u]; }
+    __device__ __forceinline__ float z(uint32_t j) const { return pz[j & 3u]; }
+};
+
+template <int XR, class POS>
+__device__ __forceinline__ void propose_half(unsigned long long* keys, uint32_t s, float sx, float sy, float sz, const POS& pos)
 {
     const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
     float dx2[2], dy2[2], dz2[2];
 #pragma unroll
     for (uint32_t j = 0; j < 2; ++j) {                             // 0: the seed's own chain position, 1: the partner's
-        const float dxv = sx - axis_pos(f.ox, rx0 + xr + __umul24(xs ^ (2u * j), k), f.vs);
-        const float dyv = sy - axis_pos(f.oy, ry + __umul24(jr ^ (2u * j), k), f.vs);
-        const float dzv = sz - axis_pos(f.oz, rz + __umul24(jp ^ (2u * j), k), f.vs);
+        const float dxv = sx - pos.x(xs ^ (2u * j), xr);
+        const float dyv = sy - pos.y(jr ^ (2u * j));
+        const float dzv = sz - pos.z(jp ^ (2u * j));
         dx2[j] = dxv * dxv; dy2[j] = dyv * dyv; dz2[j] = dzv * dzv;
     }
     const uint32_t ra[2] = {1u, xs & 2u}, rb[2] = {3u, (jr & 2u) * 3u}, rc[2] = {9u, (jp & 2u) * 9u};      // (t + 1) * {1, 3, 9}
@@ -1514,9 +1531,8 @@ __device__ __forceinline__ void propose_half(unsigned long long* keys, uint32_t 
         }
 }
 
-template <int XR, int STEP>
-__device__ __forceinline__ void propose(unsigned long long* keys, uint32_t s, float sx, float sy, float sz, const Frame& f,
-                                        uint32_t rx0, uint32_t ry, uint32_t rz, uint32_t k, uint32_t tag)
+template <int XR, int STEP, class POS>
+__device__ __forceinline__ void propose(unsigned long long* keys, uint32_t s, float sx, float sy, float sz, const POS& pos, uint32_t tag)
 {
     const uint32_t xr = s % XR, xs = (s / XR) & 3u, jr = (s / (4u * XR)) & 3u, jp = s / (16u * XR);
     float dx2[3], dy2[3], dz2[3];
@@ -1524,9 +1540,9 @@ __device__ __forceinline__ void propose(unsigned long long* keys, uint32_t s, fl
 #pragma unroll
     for (int t = -1; t <= 1; ++t) {                                // target = s - t STEP positions: s is its neighbour at +t
         va[t + 1] = xs - t * STEP <= 3u; vb[t + 1] = jr - t * STEP <= 3u; vc[t + 1] = jp - t * STEP <= 3u;   // unsigned: also rejects < 0
-        const float dxv = sx - axis_pos(f.ox, rx0 + xr + __umul24(xs - t * STEP, k), f.vs);
-        const float dyv = sy - axis_pos(f.oy, ry + __umul24(jr - t * STEP, k), f.vs);
-        const float dzv = sz - axis_pos(f.oz, rz + __umul24(jp - t * STEP, k), f.vs);
+        const float dxv = sx - pos.x(xs - t * STEP, xr);
+        const float dyv = sy - pos.y(jr - t * STEP);
+        const float dzv = sz - pos.z(jp - t * STEP);
         dx2[t + 1] = dxv * dxv; dy2[t + 1] = dyv * dyv; dz2[t + 1] = dzv * dzv;
     }
 #pragma unroll
@@ -1619,7 +1635,7 @@ jfa_pass_seeds(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         const uint32_t s = list[e];
         const T id = ids[s];
         propose<XR, 1>(keys, s, axis_pos(f.ox, ID::xoff(id) >> 2, f.vs), axis_pos(f.oy, scr(ID::yoff(id) >> 2), f.vs),
-                       axis_pos(f.oz, scr(ID::zoff(id) >> 2), f.vs), f, rx0, ry, rz, k, s);
+                       axis_pos(f.oz, scr(ID::zoff(id) >> 2), f.vs), ChainPosCalc{f, rx0, ry, rz, k}, s);
     }
     __syncthreads();
     unsigned long long won[PER];
@@ -1659,6 +1675,9 @@ __device__ unsigned long long g_ft_slots[kFtSlots][16];          // one row per 
 #ifndef VP_PROPOSE_HALF
 #define VP_PROPOSE_HALF 1
 #endif
+#ifndef VP_FT_POS_LDS
+#define VP_FT_POS_LDS 1
+#endif
 template <class ID, int XR, int NT, int TPW>
 __global__ void __launch_bounds__(NT)
 jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out, uint32_t tilesX, uint32_t tiles, uint32_t shifts)
@@ -1671,6 +1690,7 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
     __shared__ unsigned long long keys[SLOTS];
     __shared__ T idOf[SLOTS];                                      // packed id of the voxel of a slot (what a seed at that slot is called)
     __shared__ uint32_t list[SLOTS];                               // entries: slot | slot of the seed it holds << 16
+    __shared__ float posX[4 * XR], posY[4], posZ[4];
     __shared__ uint32_t cnt[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, N = f.n, k = N / 4u;
     // slot tid + i NT = row-plane (rpb + i G) x column `col` (see jfa_pass_seeds): row addresses are scalar work
@@ -1733,21 +1753,24 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
         const bool xin = rx0 + col % XR < k;
         VP_FT_STAMP(0);
         if (tid < 2) cnt[tid] = 0;
+        if (VP_FT_POS_LDS) {                                       // positions of the tile's 4 XR columns, 4 rows, 4 planes (see ChainPosLds)
+            if (tid < RPW) posX[tid] = axis_pos(f.ox, myx, f.vs);  // tid < RPW: col == tid
+            if (tid < 4) { posY[tid] = axis_pos(f.oy, ry + tid * k, f.vs); posZ[tid] = axis_pos(f.oz, rz + tid * k, f.vs); }
+        }
         __syncthreads();                                           // also: the previous tile's output stage has read keys / idOf
         VP_FT_STAMP(1);
-        auto coords = [&](uint32_t s, uint32_t& x, uint32_t& y, uint32_t& z) {
-            x = rx0 + s % XR + __umul24((s / XR) & 3u, k); y = ry + __umul24((s / (4u * XR)) & 3u, k); z = rz + __umul24(s / (16u * XR), k);
-        };
         // every entry of the list proposes the seed that sits at slot q (its coordinates are those of q) from slot s
         auto scatter = [&](uint32_t nlist, auto step) {
             constexpr int STEP = decltype(step)::value;
-            for (uint32_t e = tid; e < nlist; e += NT) {
-                const uint32_t entry = list[e], s = entry & 0xFFFFu, q = entry >> 16;
-                uint32_t qx, qy, qz;
-                coords(q, qx, qy, qz);
-                if constexpr (STEP == 2 && VP_PROPOSE_HALF) propose_half<XR>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k);
-                else propose<XR, STEP>(keys, s, axis_pos(f.ox, qx, f.vs), axis_pos(f.oy, qy, f.vs), axis_pos(f.oz, qz, f.vs), f, rx0, ry, rz, k, q);
-            }
+            auto run = [&](const auto& pos) {
+                for (uint32_t e = tid; e < nlist; e += NT) {
+                    const uint32_t entry = list[e], s = entry & 0xFFFFu, q = entry >> 16;
+                    const float sx = pos.x((q / XR) & 3u, q % XR), sy = pos.y((q / (4u * XR)) & 3u), sz = pos.z(q / (16u * XR));
+                    if constexpr (STEP == 2 && VP_PROPOSE_HALF) propose_half<XR>(keys, s, sx, sy, sz, pos);
+                    else propose<XR, STEP>(keys, s, sx, sy, sz, pos, q);
+                }
+            };
+            if constexpr (VP_FT_POS_LDS) run(ChainPosLds<XR>{posX, posY, posZ}); else run(ChainPosCalc{f, rx0, ry, rz, k});
         };
         // ---- stage A: border voxels -> pass with k = n/2
         bool flag[PER];
