@@ -1125,9 +1125,11 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     }
     if (FINAL && !GM) {
         for (uint32_t i = tid; i < (uint32_t)(RY * CH) * f.w; i += NT) {
-            const int o = (int)(i / f.w), a = o / CH, j = o % CH;
+            uint32_t ou, c;
+            udivmod(i, f.w, ou, c);                                // (the divisor is uniform; word indices stay below 2^28: 32-bit arithmetic)
+            const int o = (int)ou, a = o / CH, j = o % CH;
             const int oy = ybase + a * K, oz = zbase + j * K;
-            WM[o * (TAB / 32) + i % f.w] = (oy < N && oz < (int)f.z1) ? words[((size_t)(oz - (int)f.z0) * N + oy) * f.w + i % f.w] : 0u;
+            WM[o * (TAB / 32) + (int)c] = (oy < N && oz < (int)f.z1) ? words[(uint32_t)((oz - (int)f.z0) * N + oy) * f.w + c] : 0u;
         }
     }
     __syncthreads();
