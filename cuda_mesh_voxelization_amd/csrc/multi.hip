@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 using namespace vp;
@@ -272,9 +273,12 @@ int jfa_ghost(vp_multi* m, float fill, int algo)
         if (maskStart) VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
         else           VP_TRY(vp_jfa_init(me.ctx, &G, words, nullptr, nullptr, a));
         size_t skip = 0;
-        // the first two passes as ONE whole-grid launch where the second pass would cover most of the grid anyway: break-even of the
-        // measured kernel times at 61 % of the grid (n = 512) and 73 % (n = 1024), as in slab.py: fused_first_two_threshold()
-        if (maskStart && last >= 2 && vp_jfa_can_fuse_first_two(&G, algo) && (uint64_t)(regs[1].b1 - regs[1].b0) * 100 >= (n <= 512 ? 65ull : 73ull) * n) {
+        // the first two passes as ONE whole-grid launch where the second pass covers at least 35 % of the grid: break-even of the
+        // measured kernel times (jfa_first_two 0.30 / 2.13 ms against first pass + fraction x second pass), as in slab.py:
+        // fused_first_two_threshold(); every rank of 2 .. 8 slabs is above it
+        const char* pct = getenv("VP_FUSED_FIRST_TWO_PCT");       // dev / tests: 101 forces the two region passes
+        const uint64_t threshold = pct ? strtoull(pct, nullptr, 10) : 35ull;
+        if (maskStart && last >= 2 && vp_jfa_can_fuse_first_two(&G, algo) && (uint64_t)(regs[1].b1 - regs[1].b0) * 100 >= threshold * n) {
             VP_TRY(vp_jfa_first_two(me.ctx, &G, (const uint32_t*)me.border.ptr, b));
             std::swap(a, b);
             skip = 2;

@@ -321,8 +321,14 @@ def ghost_regions(n: int, rank: int, world: int):
 
 def fused_first_two_threshold(n: int) -> int:
     """Per cent of the grid the second pass of a rank must cover before the whole-grid launch of the first two passes is the cheaper
-    way to run them (measured kernel times, see GhostSlabPipeline.jfa; the same rule lives in csrc/multi.hip)."""
-    return 65 if n <= 512 else 73
+    way to run them.  Break-even of the measured kernel times: jfa_first_two 0.30 ms at n = 512 against 0.18 for the first pass + 0.36 x
+    the covered fraction for the second (33 %); 2.13 ms against 1.39 + 2.12 x the fraction at n = 1024 (35 %).  Swept on the GPU
+    (profiles/r03/slab_scaling_*.txt: 35 against round 2's 65 / 73): 8 slabs 1.26 -> 1.09 ms at n = 512, 11.2 -> 9.1 ms at n = 1024,
+    195 -> 144 ms at n = 2048.  The same rule lives in csrc/multi.hip."""
+    import os
+    if os.environ.get("VP_FUSED_FIRST_TWO_PCT"):                   # dev: tools/slab_scaling.py sweeps it
+        return int(os.environ["VP_FUSED_FIRST_TWO_PCT"])
+    return 35
 
 
 class GhostSlabPipeline:
@@ -385,7 +391,7 @@ class GhostSlabPipeline:
             self.be.jfa_init(self.global_frame, self.words, None, None, a)
         # The first two passes (k = n/2, n/4) as ONE launch over the whole grid (vp_jfa_first_two) where the second pass would cover
         # most of the grid anyway: 0.40 ms at n = 512 against 0.18 for the first pass + 0.36 x the covered fraction for the second
-        # (break-even at 61 %), 2.94 ms at n = 1024 against 1.39 + 2.12 x the fraction (73 %): fused_first_two_threshold().
+        # (break-even at 61 % in round 2; the kernel has since come down to 0.30 / 2.13 ms: 35 %, see fused_first_two_threshold()).
         skip = 0
         if (mask_start and last >= 2 and hasattr(self.be, "can_fuse_first_two") and self.be.can_fuse_first_two(self.global_frame, algo)
                 and (self.regions[1][2] - self.regions[1][1]) * 100 >= fused_first_two_threshold(self.global_frame.n) * self.global_frame.n):

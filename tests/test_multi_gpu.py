@@ -76,10 +76,14 @@ def test_multi_csg_and_set_grid(engine):
         m.close()
 
 
-@pytest.mark.parametrize("world,mode", [(2, MULTI_HALO), (4, MULTI_HALO), (8, MULTI_HALO), (4, MULTI_GHOST), (8, MULTI_GHOST)])
-def test_multi_headline_size_equals_single(engine, world, mode):
+@pytest.mark.parametrize("world,mode,fused_pct", [(2, MULTI_HALO, None), (4, MULTI_HALO, None), (8, MULTI_HALO, None), (4, MULTI_GHOST, None),
+                                                  (8, MULTI_GHOST, None), (8, MULTI_GHOST, "101")])
+def test_multi_headline_size_equals_single(engine, world, mode, fused_pct, monkeypatch):
     """n = 512 on the benchmark mesh: narrow passes land next to the slab (dense tile kernel), wide ones in the whole-slab
-    buffers; ghost regions at 4 and 8 ranks take the fused first two passes or the two region passes respectively."""
+    buffers; ghost regions take the first two passes as the one whole-grid launch (every rank of 2 .. 8 slabs is above the 35 %
+    break-even) or, forced with VP_FUSED_FIRST_TWO_PCT=101, as the two region passes."""
+    if fused_pct:
+        monkeypatch.setenv("VP_FUSED_FIRST_TWO_PCT", fused_pct)
     xyz, tri = M.bunny(24)
     n = 512
     origin, vs = M.frame([xyz], n)

@@ -115,10 +115,14 @@ def test_hybrid_slabs_equal_whole_grid(engine, world, n, name, algo):
     assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
 
 
-@pytest.mark.parametrize("world,n,name", [(2, 64, "bunny.obj"), (4, 64, "torus.obj"), (8, 256, "bunny.obj"), (4, 512, "bimba.obj")])
-def test_ghost_slabs_equal_whole_grid(engine, world, n, name):
-    """Communication-free variant: every emulated rank recomputes its ghost planes; no exchange at all."""
+@pytest.mark.parametrize("world,n,name,fused_pct", [(2, 64, "bunny.obj", None), (4, 64, "torus.obj", None), (8, 256, "bunny.obj", None),
+                                                    (4, 512, "bimba.obj", None), (4, 512, "bimba.obj", "101")])
+def test_ghost_slabs_equal_whole_grid(engine, world, n, name, fused_pct, monkeypatch):
+    """Communication-free variant: every emulated rank recomputes its ghost planes; no exchange at all.  The first two passes run as
+    the one whole-grid launch (slab.fused_first_two_threshold) or, forced, as the two region passes."""
     from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
+    if fused_pct:
+        monkeypatch.setenv("VP_FUSED_FIRST_TWO_PCT", fused_pct)
     xyz, tri = M.import_mesh(M.asset(name))
     origin, vs = M.frame([xyz], n)
     fr = Frame.make(n, vs, origin)
