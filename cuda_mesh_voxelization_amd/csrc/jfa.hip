@@ -1775,6 +1775,10 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
             if constexpr (VP_FT_POS_LDS) run(ChainPosLds<XR>{posX, posY, posZ}); else run(ChainPosCalc{f, rx0, ry, rz, k});
         };
         // ---- stage A: border voxels -> pass with k = n/2
+        // (Measured and dropped, profiles/r03/ab_gather_*.txt: stage A as a GATHER -- the wave ballots of the border flags in LDS, "some
+        // candidate of this voxel is a border voxel" as an OR of four ballot words, the <= 8 candidates evaluated by the thread that
+        // proposes the voxel in stage B; no list, scatter, collect or key reset and two barriers fewer.  Bit-identical, 0.302 -> 0.300 ms
+        // at n = 512, 2.12 -> 2.32 ms at n = 1024: what it adds to the one proposing wave outweighs what it takes from the others.)
         bool flag[PER];
         uint32_t seed[PER];
 #pragma unroll
