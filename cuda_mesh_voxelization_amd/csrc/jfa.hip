@@ -1778,7 +1778,9 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
         // (Measured and dropped, profiles/r03/ab_gather_*.txt: stage A as a GATHER -- the wave ballots of the border flags in LDS, "some
         // candidate of this voxel is a border voxel" as an OR of four ballot words, the <= 8 candidates evaluated by the thread that
         // proposes the voxel in stage B; no list, scatter, collect or key reset and two barriers fewer.  Bit-identical, 0.302 -> 0.300 ms
-        // at n = 512, 2.12 -> 2.32 ms at n = 1024: what it adds to the one proposing wave outweighs what it takes from the others.)
+        // at n = 512, 2.12 -> 2.32 ms at n = 1024: what it adds to the one proposing wave outweighs what it takes from the others.
+        // The opposite trade -- three waves per 64 entries of stage B, one target plane each, a third of the instruction stream per wave
+        // but the set-up three times -- ran 0.305 -> 0.344 ms / 2.13 -> 2.27 ms (ab_split_*.txt): total issue decides, not the critical path.)
         bool flag[PER];
         uint32_t seed[PER];
 #pragma unroll
