@@ -2113,6 +2113,24 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     const bool wideK = k * 4 >= f.n;                               // half of the neighbour rows / planes are outside the grid: SKIP variant
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k;
     const uint32_t nresY = std::min(k, f.n), ylen = (f.n + k - 1) / k;
+    // Plane chains that are not a multiple of eight (the sub-slab regions of the multi-GPU pipelines: 288 planes at k = 32 are chains
+    // of nine).  A tile of CH planes walks CH + 2 plane iterations whatever it outputs, so 4-plane tiles -- what round 2 ran on every
+    // such chain -- cost 6 per 4 planes.  The first 8 q members of every chain are the CONTIGUOUS planes [z0, z0 + 8 q k): they go to
+    // the 8-plane form as a sub-slab of their own (the id volume is contiguous, so each part sees the other as its halo), the remaining
+    // r < 8 members as a second launch with whichever tile is cheaper for r (10 iterations for one 8-tile, 6 per 4-tile).
+    // Measured per rank on one GPU (tools/ghost_prof.py, tools/slab_scaling.py): see DESIGN.md section 6.
+#ifndef VP_DENSE_SPLIT_CHAINS
+#define VP_DENSE_SPLIT_CHAINS 1
+#endif
+    if (VP_DENSE_SPLIT_CHAINS && !dense_wide<ID>() && nz % k == 0 && k < nz && zlen > 8 && zlen % 8 != 0) {
+        const uint32_t planesA = (zlen / 8u) * 8u * k;
+        Frame fa = f, fb = f;
+        fa.z1 = f.z0 + planesA; fb.z0 = fa.z1;
+        const size_t idPlane = (size_t)f.n * f.n * jfa_id_bytes(f), wordPlane = (size_t)f.n * f.w, sdfPlane = (size_t)f.n * f.n;
+        VP_TRY(launch_dense<ID>(ctx, fa, k, d_in, d_out, d_words, fill, d_sdf));
+        return launch_dense<ID>(ctx, fb, k, (const char*)d_in + planesA * idPlane, (char*)d_out + planesA * idPlane,
+                                d_words ? d_words + planesA * wordPlane : nullptr, fill, d_sdf ? d_sdf + planesA * sdfPlane : nullptr);
+    }
     // Tile 4 rows x 8 planes when the plane chains divide by 8, else 4 x 4.  2-KB tables (n <= 512): 256 threads, 26 KB of LDS,
     // six workgroups per CU.  4-KB tables: the 4 x 8 tile takes 52 KB, shared by the 8 waves of a 512-thread workgroup (three per CU).
 #ifndef VP_DENSE_WIDE_NT
@@ -2159,7 +2177,8 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 #define VP_DENSE_F(CH, NT) do { if (fin) VP_LAUNCH_DENSE(CH, NT, (VP_JFA_DENSE_FINAL != 0), false);                                \
                                 else if (wideK) VP_LAUNCH_DENSE(CH, NT, false, (VP_JFA_DENSE_WIDEK != 0));                          \
                                 else VP_LAUNCH_DENSE(CH, NT, false, false); } while (0)
-    const bool deep = zlen % 8 == 0;
+    // one 8-plane tile per chain also where the chain has 5 .. 7 members (10 plane iterations against 2 x 6)
+    const bool deep = zlen % 8 == 0 || (VP_DENSE_SPLIT_CHAINS && !dense_wide<ID>() && zlen > 4 && zlen < 8);
 #ifndef VP_DENSE_CLOSED
 #define VP_DENSE_CLOSED 1         // closed tiles at k = n/8 (see jfa_pass_dense)
 #endif
