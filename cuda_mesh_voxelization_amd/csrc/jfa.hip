@@ -2197,9 +2197,11 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
         }
     }
     // 8-byte ids: 8-KB tables (PX + 4 x TY + one z position table = 48 KB), 512 threads
+    // chains of one or two planes (the remainders of the split above are mostly that): 2-plane tiles, 4 plane iterations instead of 6
+    const bool tiny = VP_DENSE_SPLIT_CHAINS && !fin && !wideK && zlen <= 2;
     if constexpr (dense_wide<ID>()) { if (deep) VP_DENSE_F(8, VP_DENSE_WIDE_NT); else VP_DENSE_F(4, VP_DENSE_WIDE_NT); }
-    else if constexpr (ID::kTab == 512) { if (deep) VP_DENSE_F(8, 256); else VP_DENSE_F(4, 256); }
-    else                           { if (deep) VP_DENSE_F(8, 512); else VP_DENSE_F(4, 256); }
+    else if constexpr (ID::kTab == 512) { if (deep) VP_DENSE_F(8, 256); else if (tiny) VP_LAUNCH_DENSE(2, 256, false, false); else VP_DENSE_F(4, 256); }
+    else                           { if (deep) VP_DENSE_F(8, 512); else if (tiny) VP_LAUNCH_DENSE(2, 256, false, false); else VP_DENSE_F(4, 256); }
 #undef VP_DENSE_F
 #undef VP_LAUNCH_DENSE
 #undef VP_LAUNCH_DENSE_PM
