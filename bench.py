@@ -16,8 +16,16 @@ Rank 0 prints ONE JSON line (DESIGN.md "Measurement"):
   n1024                 (N = 1, default size only) the same JFA at n = 1024, where the north star puts its roofline target
   cpu_baseline          the oracle (C restatement of the reference's sequential path) on the box's host cores:
                         1-thread voxelize + OpenMP JFA with ALL passes -- measured, not extrapolated
+  copy_peak             (N = 1) vp_stream_copy over 1 GiB on this box: roofline.measured_copy_GBs / frac_of_measured
+  config3               (N = 1, default size) BASELINE config 3 as a pipeline: bimba + bunny voxelize, CSG union, JFA at n = 512,
+                        device-resident; kernels.csg_words against 3 n^3/8 bytes; checked against the reference's golden row
+  totals_incl_transfers (N = 1, default size) one host-in / host-out round (vp_voxelize_host + vp_jfa_host) = what the
+                        reference's Compute() calls time as Memory + Processing (38.6 + 829.6 ms)
 
-N > 1: strong scaling of the same n^3 job over N Z-slabs, one process per GPU (cuda_mesh_voxelization_amd/slab.py).
+N > 1: strong scaling of the same n^3 job over N Z-slabs, one process per GPU (cuda_mesh_voxelization_amd/slab.py).  After the
+timed region every rank runs the ONE-GPU path on its own device and compares its slab of the bitmask and of the sdf bit for
+bit (`parity_ok`; a mismatch on any rank makes the run exit non-zero), then times the OTHER transport (`multi_alt`: RCCL halos
+when the job ran ghost planes and vice versa) over a shorter region, checked the same way.
 """
 from __future__ import annotations
 
@@ -85,6 +93,133 @@ def cpu_baseline(xyz, tri, origin, vs, n):
     }
 
 
+def copy_peak(eng, gib=1, reps=5):
+    """HBM copy rate of THIS box: vp_stream_copy (16 B per lane, grid-stride, nothing computed) over `gib` GiB, bytes read +
+    bytes written per second, best of `reps` (torch events: the context runs on torch's current stream)."""
+    nbytes = gib << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=eng.device)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=eng.device)
+    src.zero_()
+    for _ in range(2):
+        eng.ctx.stream_copy(dst.data_ptr(), src.data_ptr(), nbytes)
+    best = None
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eng.ctx.stream_copy(dst.data_ptr(), src.data_ptr(), nbytes)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    del src, dst
+    return {"GB/s": round(2 * nbytes / (best * 1e-3) / 1e9, 1), "bytes_copied": nbytes, "best_ms": round(best, 4), "reps": reps,
+            "kernel": "vp_stream_copy (16 B per lane, grid-stride); rate = (bytes read + bytes written) / time"}
+
+
+def popcount_words(t):
+    """set bits of an int32 tensor (device), via a 256-entry byte table"""
+    table = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=t.device)
+    return int(table[t.view(torch.uint8).to(torch.int64)].sum().item())
+
+
+def golden_row(meshes, n, op):
+    """row of tests/golden/survey_table.json (outputs of the reference's own sequential path); None if absent"""
+    try:
+        rows = json.load(open(os.path.join(ROOT, "tests", "golden", "survey_table.json")))["rows"]
+    except Exception:
+        return None
+    for r in rows:
+        if r["meshes"] == meshes and r["n"] == n and r["op"] == op:
+            return r
+    return None
+
+
+def run_config3(eng, steps=10, warmup=2):
+    """BASELINE config 3: bimba.obj then bunny.obj in the bbox frame of both (apps/cli/main.cpp:62-87), tiled voxelize each,
+    CSG union into the first grid (-p 1), JFA sdf at n = 512 -- device-resident, through the same C-ABI calls."""
+    from cuda_mesh_voxelization_amd import mesh as M
+    from cuda_mesh_voxelization_amd.capi import ALGO_TILED, Frame
+    n = 512
+    a_xyz, a_tri = M.import_mesh(M.asset("bimba.obj"))
+    b_xyz, b_tri = M.import_mesh(M.asset("bunny.obj"))
+    origin, vs = M.frame([a_xyz, b_xyz], n)
+    fr = Frame.make(n, vs, origin)
+    da = eng.mesh_to_device(a_xyz, a_tri)
+    db = eng.mesh_to_device(b_xyz, b_tri)
+    ga, gb = eng.new_grid(fr), eng.new_grid(fr)
+    sdf = torch.empty(fr.voxels, dtype=torch.float32, device=eng.device)
+
+    def step():
+        eng.voxelize(fr, da[0], da[1], out=ga, algo=ALGO_TILED)
+        eng.voxelize(fr, db[0], db[1], out=gb, algo=ALGO_TILED)
+        eng.csg(ga, gb, 1)                                          # VP_OP_UNION
+        eng.jfa(fr, ga, out=sdf, algo=ALGO_TILED)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.ctx.prof_reset(); eng.ctx.prof_select(None); eng.ctx.prof_enable(True)
+    for _ in range(TABLE_STEPS):
+        step()
+    torch.cuda.synchronize()
+    eng.ctx.prof_enable(False)
+    S = eng.ctx.jfa_id_bytes(fr)
+    kb = kernel_bytes(n, n, S, int(a_tri.shape[0] + b_tri.shape[0]) // 2, int(a_xyz.shape[0] + b_xyz.shape[0]) // 2)
+    kernels = kernel_table(eng.ctx.prof(), TABLE_STEPS, kb)
+    row = golden_row(["bimba.obj", "bunny.obj"], n, 1)
+    got = {"union_popcount": popcount_words(ga), "sdf_zeros": int((sdf == 0).sum().item()),
+           "sdf_sum_pos": float(sdf[sdf > 0].double().sum().item()), "sdf_sum_neg": float(sdf[sdf < 0].double().sum().item())}
+    ok = None
+    if row:
+        want = {"union_popcount": row["csg"][0], "sdf_zeros": row["sdf"]["zeros"], "sdf_sum_pos": row["sdf"]["sum_pos"], "sdf_sum_neg": row["sdf"]["sum_neg"]}
+        # counts exact; the sums are double accumulations of identical floats in another order (tree vs index order): 1e-6 relative
+        ok = (got["union_popcount"] == want["union_popcount"] and got["sdf_zeros"] == want["sdf_zeros"]
+              and abs(got["sdf_sum_pos"] - want["sdf_sum_pos"]) <= 1e-6 * abs(want["sdf_sum_pos"])
+              and abs(got["sdf_sum_neg"] - want["sdf_sum_neg"]) <= 1e-6 * abs(want["sdf_sum_neg"]))
+    csg = kernels.get("csg_words", {})
+    return {"workload": "bimba.obj (%d faces) + bunny.obj (%d faces), frame = bbox of both, tiled voxelize x2 + CSG union + JFA sdf at n = %d, "
+                        "device-resident" % (a_tri.shape[0], b_tri.shape[0], n),
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "Mvoxels/s": round(n ** 3 / (elapsed / steps) / 1e6, 1), "steps": steps,
+            "kernels": kernels, "kernels_ms_per_step": {k: v["ms_per_step"] for k, v in kernels.items()},
+            "csg": {"avg_ms": csg.get("avg_ms"), "bytes": csg.get("bytes"), "GB/s": csg.get("GB/s"), "frac_of_peak": csg.get("frac_of_peak"),
+                    "note": "3 n^3/8 = 48 MiB at n = 512: a ~10 us kernel, launch- and ramp-bound rather than HBM-bound; the reference's "
+                            "kernel takes 1.59 ms (benchmarks_v2/bunny_1348128/bunny_1348128_naive_csg.csv:82-101)"},
+            "checks": got, "golden": "tests/golden/survey_table.json (bimba + bunny, n = 512, union)", "parity_ok": ok}
+
+
+def host_totals(eng, frame, xyz, tri, algo):
+    """Reference-style totals: host arrays in, host arrays out, synchronous -- vp_voxelize_host + vp_jfa_host,
+    i.e. the Memory + Processing scopes of TiledVox / TiledJFA (vox/tiled.cu:504-575, jfa/tiled.cu:254-257,334-335).
+    One warm round first (workspace growth), then one timed round."""
+    words = np.zeros(frame.words, dtype=np.uint32)
+    sdf = np.empty(frame.voxels, dtype=np.float32)
+    xyz32 = np.ascontiguousarray(xyz, dtype=np.float32)
+    tri32 = np.ascontiguousarray(tri, dtype=np.uint32)
+    out = {}
+    for rnd in ("warm", "timed"):
+        words[:] = 0
+        t0 = time.perf_counter()
+        eng.ctx.voxelize_host(frame, words, xyz32, tri32, algo)
+        t1 = time.perf_counter()
+        sdf.fill(-np.inf)
+        t2 = time.perf_counter()
+        eng.ctx.jfa_host(frame, words, -math.inf, sdf, algo)
+        t3 = time.perf_counter()
+        out = {"voxelize_ms": round((t1 - t0) * 1e3, 3), "jfa_ms": round((t3 - t2) * 1e3, 3)}
+    out["total_ms"] = round(out["voxelize_ms"] + out["jfa_ms"], 3)
+    out["Mvoxels/s"] = round(frame.n ** 3 / (out["total_ms"] * 1e-3) / 1e6, 1)
+    out["bytes_moved"] = {"h2d": int(xyz32.nbytes + tri32.nbytes + words.nbytes), "d2h": int(words.nbytes + sdf.nbytes)}
+    out["reference_ms"] = {"voxelize_total": 38.6, "jfa_total": 829.6, "source": "BASELINE.md (benchmarks_v2/bunny_1348128 tiled_vox / tiled_jfa, n = 512, unstated NVIDIA GPU)"}
+    out["note"] = "pageable host arrays over PCIe, synchronous calls; never part of `value`"
+    del words, sdf
+    return out
+
+
 def profile_json(name):
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
@@ -95,6 +230,8 @@ def profile_json(name):
     return None
 
 
+LIMITER = ("co-limited: vector-ALU issue (valu_issue_frac of the kernel's cycles) and fabric traffic (`traffic` / bytes_per_launch x "
+           "the algorithmic bytes), profiles/jfa_dense_traffic.json; DESIGN.md section 4")
 DOMINANT = "jfa_dense"
 TABLE_STEPS = 5
 
@@ -156,6 +293,9 @@ def main():
                          "abbreviation of its --nnodes / --nproc-per-node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-n1024", action="store_true", help="skip the extra n = 1024 JFA block of the default run")
+    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE config 3 block (bimba + bunny, CSG union, JFA at n = 512)")
+    ap.add_argument("--no-host-totals", action="store_true", help="skip the host-in / host-out round (reference-style totals)")
+    ap.add_argument("--no-copy-peak", action="store_true", help="skip the 1-GiB stream-copy measurement")
     ap.add_argument("--multi", choices=["ghost", "halo", "hybrid"], default="ghost",
                     help="N > 1: 'ghost' = Z-slabs with recomputed ghost planes, no data-path exchange (default: a plane costs ~1 us "
                          "to recompute and ~20 us to move over xGMI); 'halo' = Z-slabs with RCCL point-to-point halo planes before every pass; "
@@ -204,7 +344,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipe = None
+    pipe_report, pipe_desc, parity, multi_alt = None, None, None, None
     if world == 1:
         barrier()
         elapsed, live, table = run_single(eng, frame, d_xyz, d_tri, args.steps, args.warmup, ALGO_TILED)
@@ -212,23 +352,77 @@ def main():
     else:
         from cuda_mesh_voxelization_amd.slab import HostStagedDist, make_pipeline
         p2p = HostStagedDist(dist) if dist.get_backend() == "gloo" else dist        # gloo (the shared-GPU test rig) moves CPU tensors only
-        pipe = make_pipeline(args.multi, eng, frame, rank, world, p2p)
+        pw, pv = n * n // 32, n * n
 
-        def step():
-            pipe.voxelize(d_xyz, d_tri, algo=ALGO_TILED)
-            pipe.jfa(algo=ALGO_TILED)
+        def run_pipeline(kind, steps, warmup):
+            """time `steps` steps of one slab pipeline; returns (elapsed max over ranks, timers, report, this rank's slab of the
+            bitmask and of the sdf as copies) and frees the pipeline's buffers (n = 2048: two id volumes are 128 GiB)"""
+            pipe = make_pipeline(kind, eng, frame, rank, world, p2p)
 
-        elapsed, live, table = measure(eng, step, args.steps, args.warmup, barrier)
-        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            def step():
+                pipe.voxelize(d_xyz, d_tri, algo=ALGO_TILED)
+                pipe.jfa(algo=ALGO_TILED)
+
+            el, lv, tb = measure(eng, step, steps, warmup, barrier)
+            t = torch.tensor([el], dtype=torch.float64, device=eng.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = pipe.words if pipe.words.numel() == pipe.frame.words else pipe.words[pipe.z0 * pw:pipe.z1 * pw]
+            got = (w.clone(), pipe.sdf.clone(), pipe.z0, pipe.z1)
+            rep = dict(pipe.report(), describe=pipe.describe(), regions=getattr(pipe, "regions", None))
+            del pipe, step
+            torch.cuda.empty_cache()
+            return float(t.item()), lv, tb, rep, got
+
+        def same_bits(got, ref_words, ref_sdf):
+            w, s_, z0, z1 = got
+            return [bool(torch.equal(w, ref_words[z0 * pw:z1 * pw])),
+                    bool(torch.equal(s_.view(torch.int32), ref_sdf[z0 * pv:z1 * pv].view(torch.int32)))]
+
+        elapsed, live, table, pipe_report, got = run_pipeline(args.multi, args.steps, args.warmup)
+        pipe_desc = pipe_report.pop("describe")
         planes = n // world
-        regs = getattr(pipe, "regions", None)
+        regs = pipe_report.pop("regions")
         if regs:                                           # ghost planes: a dense pass covers the slab widened by the later steps
             dense = [b1 - b0 for k, b0, b1 in regs if k * 4 < n and k > 1]
             if dense:
                 planes = sum(dense) / len(dense)
+        # ---- self-check: the ONE-GPU path on this rank's own device, this rank's slab compared bit for bit.  First contact of the
+        # transports (RCCL point-to-point, peer copies) with real hardware happens on boxes the build never sees: a number printed
+        # for a wrong result would be worse than no number.
+        ref_words = eng.voxelize(frame, d_xyz, d_tri, algo=ALGO_TILED)
+        ref_sdf = eng.jfa(frame, ref_words, algo=ALGO_TILED)
+        torch.cuda.synchronize()
+        eng._work = None
+        torch.cuda.empty_cache()
+        flags = same_bits(got, ref_words, ref_sdf)
+        del got
+        # ---- the other transport in the same job, over a shorter region (so that a scaling run shows RCCL moving halos and not
+        # only barriers when the default is ghost planes, and the exchange-free figure when it is not)
+        alt_kind = "halo" if args.multi != "halo" else "ghost"
+        alt_steps = max(2, args.steps // 4)
+        a_el, _a_live, a_table, a_rep, a_got = run_pipeline(alt_kind, alt_steps, 1)
+        flags += same_bits(a_got, ref_words, ref_sdf)
+        del a_got, ref_words, ref_sdf
+        torch.cuda.empty_cache()
+        fl = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=eng.device)
+        allf = [torch.zeros_like(fl) for _ in range(world)]
+        dist.all_gather(allf, fl)
+        per_rank = [[bool(v) for v in t.tolist()] for t in allf]
+        parity = {"parity_ok": all(all(r[:2]) for r in per_rank),
+                  "per_rank": [{"rank": i, "bitmask_slab_equal": r[0], "sdf_slab_equal": r[1]} for i, r in enumerate(per_rank)],
+                  "against": "the one-GPU path (vp_voxelize + vp_jfa of the whole grid) run on each rank's own device after the timed region"}
+        recv = torch.tensor([float(a_rep.get("bytes_received_total", 0))], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(recv, op=dist.ReduceOp.SUM)
+        a_rep.pop("regions", None)
+        multi_alt = {"pipeline": alt_kind, "parallelism": a_rep.pop("describe"), "steps": alt_steps, "warmup": 1,
+                     "ms_per_step": round(a_el / alt_steps * 1e3, 4), "value": round(n ** 3 / (a_el / alt_steps) / 1e6, 2), "unit": "Mvoxels/s",
+                     "bytes_received_per_step_all_ranks": int(recv.item() / (alt_steps + 1 + TABLE_STEPS)),
+                     "parity_ok": all(all(r[2:]) for r in per_rank),
+                     "per_rank": [{"rank": i, "bitmask_slab_equal": r[2], "sdf_slab_equal": r[3]} for i, r in enumerate(per_rank)],
+                     "report_rank0": a_rep,
+                     "kernels_ms_per_step_rank0": {k: round(v["ms"] / TABLE_STEPS, 4) for k, v in a_table.items()}}
 
+    peak = copy_peak(eng) if (world == 1 and not args.no_copy_peak) else None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n ** 3 / (elapsed / args.steps) / 1e6
@@ -250,24 +444,33 @@ def main():
                                    "(border mask + %d passes, last one fused with id -> sdf), device-resident"
                                    % (refine, tri.shape[0], xyz.shape[0], n, passes),
                        "n": n, "triangles": int(tri.shape[0]), "jfa_state_bytes": S,
-                       "parallelism": "1 gpu" if world == 1 else pipe.describe(),
+                       "parallelism": "1 gpu" if world == 1 else pipe_desc,
                        "world_size_seen": world,
                        "baseline": "480 Mvoxels/s = reference tiled vox+JFA kernels-only at n=512 (BASELINE.md, unstated NVIDIA GPU)"},
+            # `bound` names the roofline the kernel is priced against (the contract: "hbm" | "mfma"); `limiter` says what the counters
+            # show actually holds it back
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": kd["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kd["frac_of_peak"], "frac_of_achievable": round(kd["GB/s"] / HBM_ACHIEVABLE_GBS, 4),
-                         "achievable": HBM_ACHIEVABLE_GBS, "traffic": traffic, "traffic_source": counters_from,
+                         "achievable": HBM_ACHIEVABLE_GBS, "achievable_source": "MI355X_MICROARCH.md (float4 copy); this box: measured_copy_GBs",
+                         "measured_copy_GBs": peak["GB/s"] if peak else None,
+                         "frac_of_measured": round(kd["GB/s"] / peak["GB/s"], 4) if peak else None,
+                         "traffic": traffic, "traffic_source": counters_from,
                          "bytes_per_launch": kd["bytes"], "avg_launch_ms": kd["avg_ms"], "launches": int(round(kd["launches_per_step"] * args.steps)),
                          "valu_issue_frac": tj.get("valu_issue_frac") if traffic else None, "valu_issue_source": counters_from,
-                         "valu_bound": True,
+                         "limiter": LIMITER,
                          "timing": "hipEvents on the kernel's stream around each of its launches inside the timed region; the other "
                                    "kernels of `kernels` are timed over %d further steps outside it" % TABLE_STEPS,
-                         "note": "the dense pass is VALU-issue bound, not HBM bound (DESIGN.md section 4): 27 exact candidate "
-                                 "evaluations per voxel; bytes = 2*S*n^2*planes"},
+                         "note": "bytes = 2*S*n^2*planes (SURVEY.md 8(d)); 27 exact candidate evaluations per voxel (DESIGN.md section 4)"},
             "kernels": kernels,
             "kernels_ms_per_step": {k: v["ms_per_step"] for k, v in kernels.items()},
         }
-        if pipe is not None:
-            out["multi"] = pipe.report()
+        if peak:
+            out["copy_peak"] = peak
+        if pipe_report is not None:
+            out["multi"] = pipe_report
+            out["parity_ok"] = parity["parity_ok"] and multi_alt["parity_ok"]
+            out["parity"] = parity
+            out["multi_alt"] = multi_alt
         if world == 1 and n == N_GRID and not args.no_n1024:
             # the north star's roofline target lives at n = 1024: same mesh, JFA only is what differs in cost per voxel
             n2 = 1024
@@ -286,17 +489,29 @@ def main():
             t2 = (tj.get("n1024") or {})
             out["roofline_n1024"] = {"kernel": "jfa_dense", "bound": "hbm", "achieved": kd2.get("GB/s"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": kd2.get("frac_of_peak"), "bytes_per_launch": kd2.get("bytes"), "avg_launch_ms": kd2.get("avg_ms"),
-                                     "traffic": t2.get("hbm_bytes_per_launch"), "valu_issue_frac": t2.get("valu_issue_frac"), "valu_bound": True,
+                                     "traffic": t2.get("hbm_bytes_per_launch"), "valu_issue_frac": t2.get("valu_issue_frac"), "limiter": LIMITER,
+                                     "measured_copy_GBs": peak["GB/s"] if peak else None,
+                                     "frac_of_measured": round(kd2.get("GB/s", 0.0) / peak["GB/s"], 4) if peak and kd2.get("GB/s") else None,
                                      "traffic_source": counters_from, "valu_issue_source": counters_from,
                                      "jfa_all_passes_frac": out["n1024"]["jfa_frac_of_peak"], "target_frac": 0.70,
                                      "timing": "hipEvents on the kernel's stream, 3 steps after the timed region of the headline workload"}
+        if world == 1 and n == N_GRID and not args.no_config3:
+            out["config3"] = run_config3(eng)
+            if "csg_words" in out["config3"]["kernels"]:
+                out["kernels"]["csg_words"] = dict(out["config3"]["kernels"]["csg_words"], measured_in="config3 (the headline step has no CSG)")
+        if world == 1 and n == N_GRID and not args.no_host_totals:
+            out["totals_incl_transfers"] = host_totals(eng, frame, xyz, tri, ALGO_TILED)
+            out["totals_incl_transfers_ms"] = out["totals_incl_transfers"]["total_ms"]
         if world == 1 and not args.no_cpu_baseline and n == N_GRID:
             out["cpu_baseline"] = cpu_baseline(xyz, tri, origin, vs, n)
         print(json.dumps(out), flush=True)
 
+    bad = parity is not None and not (parity["parity_ok"] and multi_alt["parity_ok"])
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        sys.exit("bench.py: a rank's slab differs from the one-GPU result (see `parity` / `multi_alt` in the JSON line)")
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ JFA_PASS_KEYS = ("jfa_pass", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last")
 # every symbol include/vphip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "vp_device_count", "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_stream", "vp_ctx_sync", "vp_last_error", "vp_abi_version",
-    "vp_malloc", "vp_free", "vp_memset", "vp_memcpy_d2d", "vp_ctx_workspace", "vp_ctx_release", "vp_upload", "vp_download",
+    "vp_malloc", "vp_free", "vp_memset", "vp_memcpy_d2d", "vp_stream_copy", "vp_ctx_workspace", "vp_ctx_release", "vp_upload", "vp_download",
     "vp_grid_words", "vp_grid_voxels",
     "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa", "vp_jfa_start", "vp_jfa_run", "vp_jfa_init", "vp_jfa_pass",
     "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass", "vp_jfa_can_fuse_first_two", "vp_jfa_first_two",
@@ -96,6 +96,7 @@ def lib():
         "vp_free": (ctypes.c_int, [_vp, _vp]),
         "vp_memset": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _sz]),
         "vp_memcpy_d2d": (ctypes.c_int, [_vp, _vp, _vp, _sz]),
+        "vp_stream_copy": (ctypes.c_int, [_vp, _vp, _vp, _sz]),
         "vp_ctx_workspace": (ctypes.c_int, [_vp, ctypes.c_int, _sz, ctypes.POINTER(_vp)]),
         "vp_ctx_release": (ctypes.c_int, [_vp]),
         "vp_upload": (ctypes.c_int, [_vp, _vp, _vp, _sz]),
@@ -137,7 +138,7 @@ def lib():
         "vp_multi_voxelize": (ctypes.c_int, [_vp, fp, ctypes.c_int]),
         "vp_multi_set_grid": (ctypes.c_int, [_vp, fp, _vp]),
         "vp_multi_get_grid": (ctypes.c_int, [_vp, _vp]),
-        "vp_multi_csg": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+        "vp_multi_csg": (ctypes.c_int, [_vp, _vp, _sz, ctypes.c_int]),
         "vp_multi_jfa": (ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_int, ctypes.c_int]),
         "vp_multi_get_sdf": (ctypes.c_int, [_vp, _vp]),
         "vp_multi_bytes_moved": (ctypes.c_uint64, [_vp]),
@@ -228,6 +229,10 @@ class Context:
 
     def memcpy_d2d(self, dst: int, src: int, nbytes: int):
         check(lib().vp_memcpy_d2d(self._h, _vp(dst), _vp(src), nbytes))
+
+    def stream_copy(self, dst: int, src: int, nbytes: int):
+        """the 16-bytes-per-lane copy kernel bench.py measures the box's HBM copy rate with"""
+        check(lib().vp_stream_copy(self._h, _vp(dst), _vp(src), nbytes))
 
     def workspace(self, slot: int, nbytes: int) -> int:
         p = _vp()
@@ -365,7 +370,7 @@ class Multi:
 
     def csg(self, other, op):
         other = self._np.ascontiguousarray(other, dtype=self._np.uint32)
-        check(lib().vp_multi_csg(self._h, other.ctypes.data, op))
+        check(lib().vp_multi_csg(self._h, other.ctypes.data, other.size, op))
 
     def jfa(self, fill=float("-inf"), algo=ALGO_TILED, mode=MULTI_HALO):
         check(lib().vp_multi_jfa(self._h, fill, algo, mode))

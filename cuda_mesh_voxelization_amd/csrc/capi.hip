@@ -107,9 +107,14 @@ static int bind_device(vp_ctx* ctx)
 
 // vp_extract must follow a vp_extract_count of the same grid CONTENTS; the record of that count is dropped as soon as the
 // buffer it was taken from is written through this ABI or handed out again as a workspace slot.
+// The same holds for the record of vp_jfa_start: its border mask (or init ids) was computed from the grid CONTENTS, so a write to
+// that grid -- or to the workspace itself -- between start and run invalidates it ("same grid" in the header means same contents).
 static void grid_written(vp_ctx* ctx, const void* d_ptr)
 {
-    if (d_ptr && d_ptr == (const void*)ctx->ext_words) ctx->ext_words = nullptr;
+    if (!d_ptr) return;
+    if (d_ptr == (const void*)ctx->ext_words) ctx->ext_words = nullptr;
+    if (ctx->jfa_started.valid && (d_ptr == (const void*)ctx->jfa_started.words || d_ptr == ctx->jfa_started.work))
+        ctx->jfa_started.valid = false;
 }
 
 static const char* kNames[VP_K_COUNT] = {
@@ -294,6 +299,15 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
     if (op < VP_OP_VOID || op > VP_OP_DIFFERENCE) return set_error(VP_ERR_INVALID, "vp_csg: unknown op %d", op);
     grid_written(ctx, d_a);
     return launch_csg(ctx, d_a, d_b, nwords, op);
+}
+
+int vp_stream_copy(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes)
+{
+    if (!ctx || !d_dst || !d_src || bytes == 0 || (bytes % 16) != 0 || ((uintptr_t)d_dst % 16) != 0 || ((uintptr_t)d_src % 16) != 0)
+        return set_error(VP_ERR_INVALID, "vp_stream_copy: 16-byte aligned buffers of a multiple of 16 bytes required");
+    VP_TRY(bind_device(ctx));
+    grid_written(ctx, d_dst);
+    return launch_stream_copy(ctx, d_dst, d_src, bytes);
 }
 
 size_t vp_jfa_workspace_bytes(const vp_frame* f)

@@ -35,7 +35,25 @@ csg_words(uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t nword
         a[i] = apply<OP>(a[i], b[i]);
 }
 
+// The yardstick the HBM-bound kernels are priced against on the box they run on ("measure a device stream-copy
+// peak on the box"): the same access shape as csg_words and vox_fill -- 16 bytes per lane, grid-stride -- with nothing computed.
+__global__ void __launch_bounds__(256)
+stream_copy(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t nvec)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) dst[i] = src[i];
+}
+
 }  // namespace
+
+int launch_stream_copy(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes)
+{
+    const size_t nvec = bytes / 16;
+    const unsigned blocks = (unsigned)std::min<size_t>((nvec + 255) / 256, (size_t)ctx->cus * 8);
+    hipLaunchKernelGGL(stream_copy, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)d_dst, (const uint4*)d_src, nvec);
+    VP_HIP(hipGetLastError());
+    return 0;
+}
 
 int launch_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int op)
 {

@@ -553,19 +553,24 @@ __device__ __forceinline__ void row_load(uint2& o, __amdgpu_buffer_rsrc_t r, uin
     o = make_uint2(v[0], v[1]);
 }
 __device__ __forceinline__ float lds_f32(const char* p) { return *reinterpret_cast<const float*>(p); }
+// AUX = cache policy bits of the store (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  Plain / sc0 / nt stores leave the line in the XCD's L2,
+// sc1 forms drop it (MI355X_MICROARCH.md, "stores of each flavour").
+template <int AUX = 0>
 __device__ __forceinline__ void row_store(uint32_t v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)byte_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)byte_off, 0, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void row_store(float v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void row_store(uint2 v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
 {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     const u32x2 t = {v.x, v.y};
-    __builtin_amdgcn_raw_buffer_store_b64(t, r, (int)byte_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, (int)byte_off, 0, AUX);
 }
 // A wave-uniform value made opaque to the optimiser where it is used: the 128-bit row descriptors derived from it are
 // then built right before their loads / stores (a few SALU instructions) instead of being hoisted out of the x loop,
@@ -1001,6 +1006,9 @@ template <class ID> constexpr bool final_mask_global() { return VP_FINAL_GLOBAL_
 //     48 KB and three 512-thread workgroups share a CU; "none" (all ones: its fields are real coordinates at n = 2048) gets an
 //     infinite seed x by an explicit test, once per id.
 template <class ID> constexpr bool dense_wide() { return std::is_same<ID, Id64>::value; }
+#ifndef VP_DENSE_STORE_AUX
+#define VP_DENSE_STORE_AUX 0        // cache policy of the tile kernel's output stores (see row_store)
+#endif
 // Pair mode (PM = 1, 2, 4, 8; round 3): the lanes of a wave are paired so that the voxels x and x + k sit in two lanes one DPP
 // permutation apart (quad_perm for k = 1, 2; row_half_mirror for k = 4; row_ror:8 for k >= 8 -- the map from lane to x below keeps
 // the 64 voxels of a wave inside at most two 128-byte runs).  Each lane then loads and decodes TWO ids per source row instead of
@@ -1204,8 +1212,12 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         auto load_row = [&](const Plane& pl, int rr, T (&w)[NI]) {
             const bool ok = pl.ok && yv[rr];
             if (SKIP && !ok) return;
+#if defined(VP_ABL_HOT)                                                    // every source row = row 0 of the volume: loads hit the L1 (timing only)
+            const __amdgpu_buffer_rsrc_t b = row_resource(ok ? reinterpret_cast<const char*>(in) : reinterpret_cast<const char*>(none_row), rowBytes);
+#else
             const __amdgpu_buffer_rsrc_t b =
                 row_resource(ok ? pl.base + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
+#endif
             if constexpr (PM != 0) {
                 row_load(w[rr * 2 + 0], b, xo);
                 row_load(w[rr * 2 + 1], b, xout);
@@ -1409,7 +1421,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                         if (a >= yout) continue;
                         const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (P - 1) * K) * N + (ybase + a * K);
                         const bool set = ((GM ? mw[a] : WM[(a * CH + (P - 1)) * (TAB / 32) + (x >> 5)]) >> (x & 31)) & 1u;
-                        row_store(set ? best[a][P - 1] : copysignf(best[a][P - 1], fill), row_resource(sdf + rowIdx * N, (uint32_t)N * 4u), x * 4u);
+                        row_store<VP_DENSE_STORE_AUX>(set ? best[a][P - 1] : copysignf(best[a][P - 1], fill), row_resource(sdf + rowIdx * N, (uint32_t)N * 4u), x * 4u);
                     }
                 }
             } else {
@@ -1418,7 +1430,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 #pragma unroll
                     for (int a = 0; a < RY; ++a) {
                         if (a >= yout) continue;
-                        row_store(pend[a], row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
+                        row_store<VP_DENSE_STORE_AUX>(pend[a], row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
                     }
                 }
                 if (P >= 1 && P - 1 < nout) {                      // output plane P - 1 is complete: fetch the ids of its winners
@@ -1441,6 +1453,8 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                             const uint32_t off = lo ? lo - 1u : ownOff;
 #if defined(VP_ABL_NOGATHER)
                             pend[a] = T(off);
+#elif defined(VP_ABL_HOT)
+                            pend[a] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(in) + (off & (rowBytes - 1u) & ~3u));
 #else
                             pend[a] = *reinterpret_cast<const T*>(gbase + off);
 #endif
@@ -1460,7 +1474,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 #pragma unroll
                 for (int a = 0; a < RY; ++a) {
                     if (a >= yout) continue;
-                    row_store(pend[a], row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
+                    row_store<VP_DENSE_STORE_AUX>(pend[a], row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
                 }
             }
         }

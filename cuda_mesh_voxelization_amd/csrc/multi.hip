@@ -73,6 +73,20 @@ int grow(Rank& r, Buffer& b, size_t bytes)
     return reserve(r.ctx, b, bytes ? bytes : 1);
 }
 
+// Id volumes are filled once when they are (re)allocated: the ghost regions below are rounded OUTWARDS to the 8-plane tile, and the
+// excess planes of a pass read planes the pass before it never produced (see ghost_regions).  What they read is then stale or this
+// fill -- never memory nobody wrote.  VP_MULTI_POISON=<byte> (tests) fills with that byte instead of 0 to show the results do not
+// depend on it.
+int grow_ids(Rank& r, Buffer& b, size_t bytes)
+{
+    const size_t before = b.bytes;
+    VP_TRY(grow(r, b, bytes));
+    const char* poison = getenv("VP_MULTI_POISON");
+    if (b.bytes != before || poison)
+        VP_HIP(hipMemsetAsync(b.ptr, poison ? (int)strtol(poison, nullptr, 0) & 0xFF : 0, b.bytes, r.ctx->stream));
+    return 0;
+}
+
 vp_frame slab_frame(const vp_frame& g, uint32_t z0, uint32_t z1)
 {
     vp_frame f = g;
@@ -161,8 +175,14 @@ std::vector<HaloMove> halo_plan(uint32_t n, uint32_t world, uint32_t k)
 
 struct Region { uint32_t k, b0, b1; };
 
-// Planes each pass must produce on a rank so that no exchange is needed: the slab widened by the sum of the later steps,
-// rounded outwards to the 8-plane tile and clipped to the grid.
+// Planes each pass must produce on a rank so that no exchange is needed: the slab widened by the sum of the later steps
+// (its REACH g_i), rounded outwards to the 8-plane tile and clipped to the grid.
+// Invariant (tests/test_multi_gpu.py::test_multi_ghost_ignores_unproduced_planes): a plane of region i is NEEDED iff it lies within
+// g_i of the slab; needed planes of pass i read only planes within g_i + k_i = g_(i-1) of the slab, all of which pass i - 1 produced.
+// The planes the rounding adds are computed too (whole tiles) but from planes pass i - 1 may not have produced -- their values are
+// never read by a needed plane of any later pass, so the slab is exact whatever those planes held (grow_ids gives them defined bytes).
+// Rounding the regions so that each contains the next one widened by its step instead would cost up to 16 more planes per side
+// and pass (k = 8: 24 instead of 8), i.e. time, for values nobody reads.
 std::vector<Region> ghost_regions(uint32_t n, uint32_t z0, uint32_t z1)
 {
     std::vector<uint32_t> ks;
@@ -185,7 +205,7 @@ int jfa_halo(vp_multi* m, float fill, int algo)
     const size_t S = vp_jfa_id_bytes(&G), planeIds = (size_t)n * n * S, planeWords = (size_t)n * n / 8;   // bytes
     const uint32_t H = world > 1 ? nz / 2 : 0;
     for (Rank& r : m->ranks) {
-        for (Buffer& b : r.ids) VP_TRY(grow(r, b, (size_t)(nz + 2 * H) * planeIds));
+        for (Buffer& b : r.ids) VP_TRY(grow_ids(r, b, (size_t)(nz + 2 * H) * planeIds));
         VP_TRY(grow(r, r.sdf, (size_t)nz * n * n * 4));
         if (world > 1) {
             VP_TRY(grow(r, r.minus, (size_t)nz * planeIds)); VP_TRY(grow(r, r.plus, (size_t)nz * planeIds));
@@ -251,7 +271,7 @@ int jfa_ghost(vp_multi* m, float fill, int algo)
     // all-gather of the bitmask slabs: every device ends up with the whole grid (its own slab stays where it is: plane z0)
     for (Rank& r : m->ranks) {
         VP_TRY(grow(r, r.border, (size_t)n * planeWords));
-        for (Buffer& b : r.ids) VP_TRY(grow(r, b, (size_t)n * planeIds));
+        for (Buffer& b : r.ids) VP_TRY(grow_ids(r, b, (size_t)n * planeIds));
         VP_TRY(grow(r, r.sdf, (size_t)nz * n * n * 4));
     }
     // words buffers of the ghost mode hold the whole grid with the rank's own slab at its global position (see vp_multi_set_grid /
@@ -288,8 +308,11 @@ int jfa_ghost(vp_multi* m, float fill, int algo)
             const vp_frame f = slab_frame(G, g.b0, g.b1);
             // whole volumes addressed by global plane: minus starts k planes below the region, plus at max(b1, b0 + k)
             const char* in = a + (size_t)g.b0 * planeIds;
-            const char* mi = a + ((ptrdiff_t)g.b0 - (ptrdiff_t)g.k) * (ptrdiff_t)planeIds;
-            const char* pl = a + (size_t)std::max(g.b1, g.b0 + g.k) * planeIds;
+            // (include/vphip.h, vp_jfa_pass: the halo pointers are indexed from the UNCLIPPED start z0 - k, which lies before the
+            // volume when b0 < k: formed by integer arithmetic, never dereferenced below plane 0; null where there is no plane at all)
+            const char* mi = g.b0 == 0 ? nullptr
+                                       : reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(a) + (uintptr_t)(((ptrdiff_t)g.b0 - (ptrdiff_t)g.k) * (ptrdiff_t)planeIds));
+            const char* pl = g.b1 >= n ? nullptr : a + (size_t)std::max(g.b1, g.b0 + g.k) * planeIds;
             char* out = b + (size_t)g.b0 * planeIds;
             if (i == 0 && maskStart) {
                 VP_TRY(vp_jfa_first_pass(me.ctx, &f, (const uint32_t*)me.border.ptr, out));
@@ -382,13 +405,16 @@ int vp_multi_set_mesh(vp_multi* m, const float* h_xyz, size_t nverts, const uint
 int vp_multi_voxelize(vp_multi* m, const vp_frame* f, int algo)
 {
     VP_TRY(check_split(m, f, "vp_multi_voxelize"));
+    // from here on the resident grid is being replaced: a failure below must not leave the OLD grid flagged as resident under the
+    // NEW frame and slab bounds
+    m->have_grid = false; m->have_sdf = false;
     assign_slabs(m, f);
     for (Rank& r : m->ranks) {
         VP_TRY(grow(r, r.words, vp_grid_words(f) * 4));
         const vp_frame sf = slab_frame(*f, r.z0, r.z1);
         VP_TRY(vp_voxelize(r.ctx, &sf, (uint32_t*)slab_words(m, r), (const float*)r.mesh_xyz.ptr, m->nverts, (const uint32_t*)r.mesh_tri.ptr, m->ntris, algo, 0));
     }
-    m->have_grid = true; m->have_sdf = false;
+    m->have_grid = true;
     return 0;
 }
 
@@ -396,14 +422,16 @@ int vp_multi_set_grid(vp_multi* m, const vp_frame* f, const uint32_t* h_words)
 {
     VP_TRY(check_split(m, f, "vp_multi_set_grid"));
     if (!h_words) return set_error(VP_ERR_INVALID, "vp_multi_set_grid: null argument");
+    m->have_grid = false; m->have_sdf = false;                     // see vp_multi_voxelize
     assign_slabs(m, f);
     const size_t planeWords = (size_t)f->n * f->n / 8;
     for (Rank& r : m->ranks) {
         VP_TRY(grow(r, r.words, vp_grid_words(f) * 4));
         VP_HIP(hipMemcpyAsync(slab_words(m, r), (const char*)h_words + (size_t)r.z0 * planeWords, (size_t)(r.z1 - r.z0) * planeWords, hipMemcpyHostToDevice, r.ctx->stream));
     }
-    m->have_grid = true; m->have_sdf = false;
-    return vp_multi_sync(m);
+    VP_TRY(vp_multi_sync(m));
+    m->have_grid = true;
+    return 0;
 }
 
 int vp_multi_get_grid(vp_multi* m, uint32_t* h_words)
@@ -417,9 +445,11 @@ int vp_multi_get_grid(vp_multi* m, uint32_t* h_words)
     return vp_multi_sync(m);
 }
 
-int vp_multi_csg(vp_multi* m, const uint32_t* h_other, int op)
+int vp_multi_csg(vp_multi* m, const uint32_t* h_other, size_t nwords, int op)
 {
     if (!m || !h_other || !m->have_grid) return set_error(VP_ERR_INVALID, "vp_multi_csg: no resident grid");
+    if (nwords != vp_grid_words(&m->frame))
+        return set_error(VP_ERR_INVALID, "vp_multi_csg: %zu words given, the resident grid has %zu (csg/naive.cu:30-33 requires equal grids)", nwords, vp_grid_words(&m->frame));
     const size_t planeWords = (size_t)m->frame.n * m->frame.n / 8;
     for (Rank& r : m->ranks) {
         const size_t bytes = (size_t)(r.z1 - r.z0) * planeWords;

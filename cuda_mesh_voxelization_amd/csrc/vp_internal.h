@@ -112,6 +112,7 @@ struct ProfScope {
 int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float* d_xyz, size_t nverts,
                     const uint32_t* d_tri, size_t ntris, int algo, int accumulate);
 int launch_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int op);
+int launch_stream_copy(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);   // 16 B per lane: the measured HBM copy rate
 size_t jfa_id_bytes(const Frame& f);                              // 4 (n <= 1024) or 8
 int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* below,
                     const uint32_t* above, void* d_ids, uint32_t* d_border_words);

@@ -42,6 +42,16 @@ class HipSlabBackend:
     def empty_f32(self, n):
         return torch.empty(int(n), dtype=torch.float32, device=self.device)
 
+    def ids_u32(self, n):
+        """An id volume of the ghost / hybrid pipelines: filled ONCE at allocation.  Their regions are rounded outwards to the
+        8-plane tile, and the excess planes of a pass read planes the pass before it never produced (ghost_regions): what they
+        read is then this fill or stale ids -- never memory nobody wrote.  VP_SLAB_POISON=<byte> (tests) fills with that byte
+        instead of 0 to show that the results do not depend on it."""
+        import os
+        t = torch.empty(int(n), dtype=torch.int32, device=self.device)
+        t.view(torch.uint8).fill_(int(os.environ.get("VP_SLAB_POISON", "0"), 0) & 0xFF)
+        return t
+
     def id_words(self, frame):
         """uint32 words of JFA state per voxel (1 for n <= 1024, 2 above)."""
         return self.ctx.jfa_id_bytes(frame) // 4
@@ -158,6 +168,29 @@ class HostStagedDist:
         self.dist.barrier()
 
 
+def hbm_bytes(obj) -> int:
+    """bytes of device memory held by the tensors of a pipeline object (attributes, and lists / dicts of them), each storage once"""
+    seen, total = set(), 0
+
+    def walk(v):
+        nonlocal total
+        if isinstance(v, torch.Tensor):
+            st = v.untyped_storage()
+            if st.data_ptr() not in seen:
+                seen.add(st.data_ptr())
+                total += st.nbytes()
+        elif isinstance(v, (list, tuple)):
+            for x in v:
+                walk(x)
+        elif isinstance(v, dict):
+            for x in v.values():
+                walk(x)
+
+    for v in vars(obj).values():
+        walk(v)
+    return total
+
+
 def slab_range(n: int, rank: int, world: int):
     if n % world != 0 or (n // world) % 8 != 0:
         raise ValueError("n=%d cannot be cut into %d Z-slabs of a multiple of 8 planes" % (n, world))
@@ -217,7 +250,8 @@ class SlabPipeline:
         return "z-slab x%d, RCCL p2p halo exchange before every pass" % self.world
 
     def report(self):
-        return {"pipeline": "halo", "slab_planes": self.nz, "bytes_received_total": int(self.bytes_received)}
+        return {"pipeline": "halo", "slab_planes": self.nz, "bytes_received_total": int(self.bytes_received),
+                "hbm_bytes_this_rank": hbm_bytes(self)}
 
     # -- stages ---------------------------------------------------------------------------
     def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
@@ -302,8 +336,16 @@ class SlabPipeline:
 def ghost_regions(n: int, rank: int, world: int):
     """Planes [b0, b1) each JFA pass must produce on this rank so that NO exchange is needed:
     the pass with step k_i feeds every later pass, so it has to cover the slab widened by the sum of
-    the later steps (= k_i - 1 for a halving sequence), rounded outwards to the 8-plane tile and
-    clipped to the grid.  Returns [(k, b0, b1), ...] in pass order."""
+    the later steps (= k_i - 1 for a halving sequence, its REACH g_i), rounded outwards to the 8-plane
+    tile and clipped to the grid.  Returns [(k, b0, b1), ...] in pass order.
+
+    Invariant (tests: test_ghost_ignores_unproduced_planes, CPU and GPU): a plane of region i is NEEDED iff it
+    lies within g_i of the slab; needed planes of pass i read only planes within g_i + k_i = g_(i-1) of
+    the slab, all of which pass i - 1 produced.  The planes the rounding adds are computed as well (whole
+    tiles), from planes pass i - 1 may NOT have produced; no needed plane of a later pass ever reads them,
+    so the slab is exact whatever they held (the id volumes are filled once at allocation, ids_u32, so
+    that it is never unwritten memory).  Nesting the regions instead (each containing the next one widened
+    by its step) would cost up to 16 more planes per side and pass for values nobody reads."""
     z0, z1 = slab_range(n, rank, world)
     ks = []
     k = n // 2
@@ -353,7 +395,7 @@ class GhostSlabPipeline:
         self.regions = ghost_regions(frame.n, rank, world)
         self.words = self.be.empty_u32(frame.words)                 # whole grid
         idw = self.be.id_words(frame) if hasattr(self.be, "id_words") else 1
-        self.ids = [self.be.empty_u32(frame.voxels * idw), self.be.empty_u32(frame.voxels * idw)]
+        self.ids = [(self.be.ids_u32(frame.voxels * idw) if hasattr(self.be, "ids_u32") else self.be.empty_u32(frame.voxels * idw)) for _ in range(2)]
         self.sdf = self.be.empty_f32(self.frame.voxels)             # own slab only
         self.planes_computed = sum(b1 - b0 for _, b0, b1 in self.regions)
         self.border = None
@@ -365,8 +407,9 @@ class GhostSlabPipeline:
         n, passes = self.global_frame.n, len(self.regions)
         return {"pipeline": "ghost", "slab_planes": self.z1 - self.z0, "regions": [[k, b0, b1] for k, b0, b1 in self.regions],
                 "plane_passes_this_rank": int(self.planes_computed), "plane_passes_one_gpu": n * passes,
-                "work_ceiling_speedup": round(n * passes / self.planes_computed, 3), "bytes_exchanged": 0,
-                "first_two_passes_fused_over_whole_grid": bool(getattr(self, "fused_first_two", False))}
+                "plane_pass_ratio": round(n * passes / self.planes_computed, 3), "bytes_exchanged": 0, "bytes_received_total": 0,
+                "first_two_passes_fused_over_whole_grid": bool(getattr(self, "fused_first_two", False)),
+                "hbm_bytes_this_rank": hbm_bytes(self)}
 
     def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
         out = self.words if out is None else out
@@ -477,8 +520,9 @@ class HybridSlabPipeline:
         n, passes = self.global_frame.n, len(self.wide) + len(self.narrow)
         return {"pipeline": "hybrid", "slab_planes": self.nz, "wide_regions": [[k, b0, b1] for k, b0, b1 in self.wide],
                 "narrow_steps": list(self.narrow), "plane_passes_this_rank": int(self.planes_computed),
-                "plane_passes_one_gpu": n * passes, "work_ceiling_speedup": round(n * passes / self.planes_computed, 3),
-                "bytes_received_total": int(self.bytes_received), "id_buffer_planes": getattr(self, "window", None)}
+                "plane_passes_one_gpu": n * passes, "plane_pass_ratio": round(n * passes / self.planes_computed, 3),
+                "bytes_received_total": int(self.bytes_received), "id_buffer_planes": getattr(self, "window", None),
+                "hbm_bytes_this_rank": hbm_bytes(self)}
 
     def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
         out = self.words if out is None else out
@@ -499,7 +543,7 @@ class HybridSlabPipeline:
                 lo, hi = min(lo, max(0, b0 - k)), max(hi, min(n, b1 + k))
         key = (lo, hi)
         if key not in self._bufs:
-            self._bufs = {key: [self.be.empty_u32((hi - lo) * self.plane_ids) for _ in range(2)]}
+            self._bufs = {key: [(self.be.ids_u32((hi - lo) * self.plane_ids) if hasattr(self.be, "ids_u32") else self.be.empty_u32((hi - lo) * self.plane_ids)) for _ in range(2)]}
         self.window = [lo, hi]
         return lo, hi, self._bufs[key]
 

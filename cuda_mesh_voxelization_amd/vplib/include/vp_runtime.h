@@ -42,6 +42,14 @@ enum { kSlotGridA = 0, kSlotGridB = 1, kSlotXyz = 2, kSlotTri = 3, kSlotSdf = 4,
 // PROFILING_SCOPE (profiling.h): parsers of the reference's benchmark contract must not see extra columns.
 void PrintDeviceTimes(const std::string& label);
 
+// The same for the slab driver (-g G, SetDevices): MultiProfile(true) resets and enables the timers of every rank's context,
+// MultiProfile(false) disables them; PrintMultiDeviceTimes prints, per kernel, the time of the SLOWEST rank (ranks run side by
+// side, so that is what the job waits for) as "# device-time <label> <kernel> <ms> ms <n> launches max-over-<G>-devices";
+// MultiDeviceTime returns that maximum for one kernel key.
+void MultiProfile(bool on);
+void PrintMultiDeviceTimes(const std::string& label);
+double MultiDeviceTime(int kernel);
+
 }  // namespace vplib
 
 #endif

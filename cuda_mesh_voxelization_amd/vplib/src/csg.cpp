@@ -46,7 +46,7 @@ void Device(uint32_t* a, const uint32_t* b, size_t n, int op)
         }
         {
             PROFILING_SCOPE("NaiveCSG::Processing");
-            gpuAssert(vp_multi_csg(multi, b, op));                 // uploads the slabs of b, combines, synchronises
+            gpuAssert(vp_multi_csg(multi, b, n, op));                 // uploads the slabs of b, combines, synchronises
         }
         {
             PROFILING_SCOPE("NaiveCSG::Memory");

@@ -132,11 +132,21 @@ void Device(int algo, const char* label, const uint32_t* words, size_t n, float 
             PROFILING_SCOPE(L + "::Memory");
             gpuAssert(vp_multi_set_grid(multi, &f, words));
         }
+#if PROFILING
+        vplib::MultiProfile(true);
+#endif
         {
-            PROFILING_SCOPE(L + "::Processing");                    // seeding and passes are one enqueue here
+            // seeding and passes are ONE enqueue on every device (no host synchronisation inside vp_multi_jfa), so the reference's
+            // ::Initialization / ::Processing split (jfa/tiled.cu:265-334) has no wall-clock boundary here: everything is
+            // ::Processing, and the device-time lines below give the per-kernel split (surface / jfa_init = the seeding).
+            PROFILING_SCOPE(L + "::Processing");
             gpuAssert(vp_multi_jfa(multi, fill, algo, vplib::MultiMode()));
             gpuAssert(vp_multi_sync(multi));
         }
+#if PROFILING
+        vplib::MultiProfile(false);
+        vplib::PrintMultiDeviceTimes(L);
+#endif
         {
             PROFILING_SCOPE(L + "::Memory");
             gpuAssert(vp_multi_get_sdf(multi, sdf));

@@ -67,6 +67,48 @@ void PrintDeviceTimes(const std::string& label)
     }
 }
 
+void MultiProfile(bool on)
+{
+    if (!g_multi) return;
+    for (int r = 0; r < vp_multi_count(g_multi); ++r) {
+        vp_ctx* c = vp_multi_ctx(g_multi, r);
+        if (on) gpuAssert(vp_prof_reset(c));
+        gpuAssert(vp_prof_enable(c, on ? 1 : 0));
+    }
+}
+
+namespace {
+// slowest rank of kernel k: its time and its launch count
+bool multi_time(int k, double& ms, uint64_t& launches)
+{
+    ms = 0; launches = 0;
+    if (!g_multi) return false;
+    for (int r = 0; r < vp_multi_count(g_multi); ++r) {
+        double t = 0; uint64_t c = 0;
+        if (vp_prof_get(vp_multi_ctx(g_multi, r), k, &t, &c) == 0 && c && t >= ms) { ms = t; launches = c; }
+    }
+    return launches != 0;
+}
+}  // namespace
+
+double MultiDeviceTime(int kernel)
+{
+    double ms = 0; uint64_t launches = 0;
+    multi_time(kernel, ms, launches);
+    return ms;
+}
+
+void PrintMultiDeviceTimes(const std::string& label)
+{
+    if (!g_multi) return;
+    for (int k = 0; k < VP_K_COUNT; ++k) {
+        double ms = 0; uint64_t launches = 0;
+        if (multi_time(k, ms, launches))
+            std::printf("# device-time %s %s %f ms %llu launches max-over-%d-devices\n", label.c_str(), vp_prof_name(k), ms,
+                        (unsigned long long)launches, vp_multi_count(g_multi));
+    }
+}
+
 void Shutdown()
 {
     if (g_multi) {

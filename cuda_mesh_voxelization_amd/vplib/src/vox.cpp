@@ -92,11 +92,25 @@ void Device(int algo, const char* label, uint32_t* words, size_t n, float vs, co
             PROFILING_SCOPE(L + "::Memory");
             gpuAssert(vp_multi_set_mesh(multi, reinterpret_cast<const float*>(mesh.Coords.data()), nverts, mesh.FacesCoords.data(), ntris));
         }
+#if PROFILING
+        vplib::MultiProfile(true);
+#endif
         {
             PROFILING_SCOPE(L + "::Processing");
             gpuAssert(vp_multi_voxelize(multi, &f, algo));
             gpuAssert(vp_multi_sync(multi));
         }
+#if PROFILING
+        vplib::MultiProfile(false);
+        if (algo == VP_ALGO_TILED) {                                // the TileAssignment columns of the benchmark CSV: slowest device
+            std::printf("[TiledVox::TileAssignment::CalculateOverlap]: %f ms\n", vplib::MultiDeviceTime(VP_K_VOX_SETUP));
+            std::printf("[TiledVox::TileAssignment::ExclusiveScan]: %f ms\n", vplib::MultiDeviceTime(VP_K_VOX_SCAN));
+            std::printf("[TiledVox::TileAssignment::WorkQueuePopulation]: %f ms\n", vplib::MultiDeviceTime(VP_K_VOX_SCATTER));
+            std::printf("[TiledVox::TileAssignment::WorkQueueSorting]: %f ms\n", 0.0);
+            std::printf("[TiledVox::TileAssignment::CompactResult]: %f ms\n", 0.0);
+        }
+        vplib::PrintMultiDeviceTimes(L);
+#endif
         {
             PROFILING_SCOPE(L + "::Memory");
             gpuAssert(vp_multi_get_grid(multi, words));

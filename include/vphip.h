@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 3
+#define VP_ABI_VERSION 4
 
 enum {
     VP_OK = 0,
@@ -77,6 +77,11 @@ int vp_free(vp_ctx* ctx, void* d_ptr);
 int vp_memset(vp_ctx* ctx, void* d_ptr, int byte_value, size_t bytes);           /* async */
 /* CudaPtr's copy constructor / assignment: device-to-device deep copy (cuda_ptr.h:42-53).  async */
 int vp_memcpy_d2d(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* Measurement aid (no reference counterpart; SURVEY.md 8(d) asks for a stream-copy peak measured on the box): a plain 16-bytes-
+ * per-lane grid-stride copy kernel on the context's stream -- the access shape of the CSG and prefix-XOR kernels with nothing
+ * computed.  bench.py times it over 1 GiB and reports the HBM-bound kernels against that rate beside the 8 TB/s specification.
+ * Buffers 16-byte aligned, bytes a multiple of 16.  async */
+int vp_stream_copy(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 /* Context-owned scratch: slot in [0, VP_WORKSPACE_SLOTS), grow-only, valid until the next call for the same slot
  * with a larger size, vp_ctx_release or vp_ctx_destroy.  What the Compute() wrappers use instead of the reference's
  * per-call cudaMalloc/cudaFree (vox/tiled.cu:496-575 allocates ~15 buffers per call). */
@@ -139,7 +144,9 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
  * This is the sequence JFA::Compute<NAIVE|TILED> and the CLI run -- the same kernels the benchmark times.
  * The context records what vp_jfa_start left in the workspace (grid pointer, n, algo, workspace, border mask or init ids);
  * vp_jfa_run returns VP_ERR_INVALID unless exactly that start preceded it -- one start serves one run, and the record is
- * dropped when the workspace is released, regrown or freed. */
+ * dropped when the workspace is released, regrown or freed, and when the grid buffer or the workspace is written through this ABI
+ * in between (vp_voxelize, vp_csg, vp_upload, vp_memset, vp_memcpy_d2d, vp_stream_copy into it, vp_free, or the buffer handed out
+ * again by vp_ctx_workspace): "the same grid" means the same CONTENTS -- the border mask of the start no longer describes them. */
 int vp_jfa_start(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void* d_work, size_t work_bytes, int algo);
 int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
                float* d_sdf, void* d_work, size_t work_bytes, int algo);
@@ -228,8 +235,9 @@ int vp_multi_voxelize(vp_multi* m, const vp_frame* f, int algo);
 /* scatter a host grid into the slabs / gather the slabs (blocking) */
 int vp_multi_set_grid(vp_multi* m, const vp_frame* f, const uint32_t* h_words);
 int vp_multi_get_grid(vp_multi* m, uint32_t* h_words);
-/* resident grid = resident grid op h_other (CSG::Compute's "result in the first grid", csg/naive.cu:62); blocking */
-int vp_multi_csg(vp_multi* m, const uint32_t* h_other, int op);
+/* resident grid = resident grid op h_other (CSG::Compute's "result in the first grid", csg/naive.cu:62); blocking.
+ * nwords = words of h_other; must equal the resident grid's (the reference requires equal grids, csg/naive.cu:30-33). */
+int vp_multi_csg(vp_multi* m, const uint32_t* h_other, size_t nwords, int op);
 /* JFA of the resident grid into the resident slab sdfs (async); vp_multi_get_sdf gathers them (blocking) */
 int vp_multi_jfa(vp_multi* m, float fill_unset, int algo, int mode);
 int vp_multi_get_sdf(vp_multi* m, float* h_sdf);

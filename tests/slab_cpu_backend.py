@@ -24,6 +24,12 @@ class CpuSlabBackend:
     def empty_f32(self, n):
         return torch.zeros(int(n), dtype=torch.float32)
 
+    def ids_u32(self, n):
+        """id volumes of the ghost / hybrid pipelines (slab.py: filled once at allocation).  VP_SLAB_POISON = a voxel index every
+        entry starts as: a (wrong) seed that would spoil the result if a plane nobody produced were ever consumed."""
+        import os
+        return torch.full((int(n),), int(os.environ.get("VP_SLAB_POISON", "0"), 0), dtype=torch.int32)
+
     # -- stages -------------------------------------------------------------------------------
     def voxelize(self, frame, words, d_xyz, d_tri, algo):
         xyz, tri = self.mesh_host

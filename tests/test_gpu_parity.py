@@ -226,6 +226,36 @@ def test_jfa_run_needs_its_own_start(engine):
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
     with pytest.raises(capi.VPError, match="vp_jfa_start"):
         run(256, ALGO_TILED)                                           # one start serves one run
+    # "same grid" means same CONTENTS: a write to the grid through the ABI between start and run drops the record --
+    # the border mask of the start no longer describes the bits the sign of the sdf is taken from
+    start(256, ALGO_TILED)
+    ctx.voxelize(frames[256], g[256].data_ptr(), dx.data_ptr(), dx.shape[0], dt.data_ptr(), dt.shape[0], ALGO_TILED, False)
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(256, ALGO_TILED)
+    start(256, ALGO_TILED)
+    ctx.csg(g[256].data_ptr(), g[256].data_ptr(), frames[256].words, 1)
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(256, ALGO_TILED)
+    start(256, ALGO_TILED)
+    ctx.memset(work.data_ptr(), 0, 16)                                 # ... and so does a write to the workspace itself
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(256, ALGO_TILED)
+    start(256, ALGO_TILED)
+    run(256, ALGO_TILED)                                               # an undisturbed pair still works
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+
+
+def test_stream_copy_copies_and_checks_alignment(engine):
+    """vp_stream_copy: the copy kernel bench.py measures the box's HBM rate with -- it must at least copy."""
+    src = torch.arange(1 << 20, dtype=torch.int32, device=engine.device)
+    dst = torch.zeros_like(src)
+    engine.ctx.stream_copy(dst.data_ptr(), src.data_ptr(), src.numel() * 4)
+    engine.sync()
+    assert torch.equal(src, dst)
+    with pytest.raises(capi.VPError, match="16"):
+        engine.ctx.stream_copy(dst.data_ptr() + 4, src.data_ptr(), 1024)
+    with pytest.raises(capi.VPError, match="16"):
+        engine.ctx.stream_copy(dst.data_ptr(), src.data_ptr(), 1000)
 
 
 @pytest.mark.parametrize("op", [1, 2, 3, 0])

@@ -127,6 +127,73 @@ def test_multi_config4_n1024_four_slabs(engine, mode):
         gc.collect(); torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("poison", ["0xA5", "0xFF"])
+def test_multi_ghost_ignores_unproduced_planes(engine, monkeypatch, poison):
+    """the ghost regions are rounded outwards to the 8-plane tile, so the excess planes of a pass read planes the pass
+    before it never produced.  The id volumes are refilled with a poison byte before every vp_multi_jfa (VP_MULTI_POISON): the slabs
+    must not depend on it.  n = 256 over 8 ranks: slabs of 32 planes, every pass with k < 8 has rounding excess on both sides."""
+    monkeypatch.setenv("VP_MULTI_POISON", poison)
+    xyz, tri = M.import_mesh(M.asset("bunny.obj"))
+    n, world = 256, 8
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    ref_w, ref_s = _single(engine, fr, xyz, tri)
+    m = capi.Multi([0] * world)
+    try:
+        m.set_mesh(xyz, tri)
+        m.voxelize(fr)
+        for fused in ("35", "101"):                                  # with and without the fused whole-grid first two passes
+            monkeypatch.setenv("VP_FUSED_FIRST_TWO_PCT", fused)
+            m.jfa(mode=MULTI_GHOST)
+            assert np.array_equal(m.get_sdf().view(np.uint32), ref_s.view(np.uint32)), fused
+    finally:
+        m.close()
+
+
+def test_python_ghost_and_hybrid_ignore_unproduced_planes(engine, monkeypatch):
+    """the same for the one-process-per-GPU pipelines of slab.py (VP_SLAB_POISON fills their id volumes at allocation)"""
+    from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline, HipSlabBackend, HybridSlabPipeline
+
+    class _Alone:                                                    # the hybrid pipeline of rank 0 of 1 exchanges nothing
+        pass
+
+    monkeypatch.setenv("VP_SLAB_POISON", "0xA5")
+    xyz, tri = M.import_mesh(M.asset("bunny.obj"))
+    n, world = 256, 8
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    _, ref_s = _single(engine, fr, xyz, tri)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    nzv = fr.voxels // world
+    for r in range(world):
+        pipe = GhostSlabPipeline(HipSlabBackend(engine), fr, r, world)
+        pipe.voxelize(dx, dt)
+        s = pipe.jfa().cpu().numpy()
+        assert np.array_equal(s.view(np.uint32), ref_s[r * nzv:(r + 1) * nzv].view(np.uint32)), r
+        assert pipe.report()["hbm_bytes_this_rank"] >= 2 * fr.voxels * 4 + fr.words * 4
+    pipe = HybridSlabPipeline(HipSlabBackend(engine), fr, 0, 1, _Alone())
+    pipe.voxelize(dx, dt)
+    assert np.array_equal(pipe.jfa().cpu().numpy().view(np.uint32), ref_s.view(np.uint32))
+
+
+def test_multi_csg_checks_the_operand_size(engine):
+    """vp_multi_csg takes the word count of its host operand, like vp_csg (csg/naive.cu:30-33: equal grids)."""
+    fr = Frame.make(64, 1.0, (0, 0, 0))
+    m = capi.Multi([0, 0])
+    try:
+        m.set_grid(fr, np.zeros(fr.words, np.uint32))
+        with pytest.raises(capi.VPError, match="words given"):
+            m.csg(np.zeros(fr.words // 2, np.uint32), 1)
+        m.csg(np.ones(fr.words, np.uint32), 1)
+        assert np.array_equal(m.get_grid(), np.ones(fr.words, np.uint32))
+        # a failing replacement of the grid must not leave the old one flagged as resident under the new frame
+        with pytest.raises(capi.VPError):
+            m.set_grid(Frame.make(96, 1.0, (0, 0, 0)), np.zeros(96 * 96 * 96 // 32, np.uint32)) if False else m.voxelize(Frame.make(100, 1.0, (0, 0, 0)))
+        assert np.array_equal(m.get_grid(), np.ones(fr.words, np.uint32))      # check_split fails BEFORE anything is touched
+    finally:
+        m.close()
+
+
 def test_multi_rejects_bad_splits_and_order(engine):
     fr = Frame.make(96, 1.0, (0, 0, 0))
     m = capi.Multi([0, 0, 0, 0, 0])

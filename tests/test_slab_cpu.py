@@ -132,6 +132,23 @@ def test_ghost_slab_pipeline_matches_single_domain_oracle(tmp_path, world, n, as
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
 
 
+@pytest.mark.parametrize("poison", ["0", "777", "-1"])
+def test_ghost_ignores_unproduced_planes(tmp_path, monkeypatch, poison):
+    """the ghost regions are rounded outwards to the 8-plane tile and the excess planes of a pass read planes the pass
+    before it never produced.  Whatever those planes hold -- voxel 0 as a seed, voxel 777, "none" -- the slabs must not change."""
+    sys.path.insert(0, ROOT)
+    from cuda_mesh_voxelization_amd import mesh as M
+    from oracle import oracle as O
+    monkeypatch.setenv("VP_SLAB_POISON", poison)
+    world, n, asset = 4, 64, "torus.obj"
+    mp.spawn(_ghost_worker, args=(world, _free_port(), n, asset, str(tmp_path)), nprocs=world, join=True)
+    xyz, tri = M.import_mesh(M.asset(asset))
+    origin, vs = M.frame([xyz], n)
+    exp = O.jfa(O.voxelize(xyz, tri, n, vs, origin), n, vs, origin)
+    got = np.concatenate([np.load(tmp_path / ("sdf_%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
 def test_ghost_regions_feed_each_other():
     """Each pass must produce (at least) the slab widened by the reach of all later passes, and what it
     reads there must have been produced by the previous pass.  (Regions are rounded outwards to the

@@ -206,7 +206,7 @@ def test_config5_n2048_eight_ghost_slabs(engine):
     gc.collect(); torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("world,multi", [(2, "ghost"), (4, "ghost"), (4, "hybrid")])
+@pytest.mark.parametrize("world,multi", [(2, "ghost"), (4, "ghost"), (4, "hybrid"), (2, "halo")])
 def test_bench_multi_process_launch_on_shared_gpu(world, multi):
     """The driver's multi-GPU invocation (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) end to end
     with one process per rank and the real kernels.  A one-GPU box cannot give every rank a device, so the ranks share it and
@@ -230,3 +230,16 @@ def test_bench_multi_process_launch_on_shared_gpu(world, multi):
     assert out["value"] > 0 and out["ms_per_step"] > 0
     assert out["multi"]["pipeline"] == multi
     assert out["roofline"]["kernel"] == "jfa_dense" and out["roofline"]["launches"] > 0
+    # the line verifies itself: every rank compared its slab with the one-GPU result on its own device, for the timed pipeline ...
+    assert out["parity_ok"] is True and out["parity"]["parity_ok"] is True
+    assert [r["rank"] for r in out["parity"]["per_rank"]] == list(range(world))
+    assert all(r["bitmask_slab_equal"] and r["sdf_slab_equal"] for r in out["parity"]["per_rank"])
+    # ... and for the OTHER transport, timed in the same job over a shorter region
+    alt = out["multi_alt"]
+    assert alt["pipeline"] == ("ghost" if multi == "halo" else "halo") and alt["parity_ok"] is True
+    assert alt["ms_per_step"] > 0 and alt["value"] > 0 and len(alt["per_rank"]) == world
+    if alt["pipeline"] == "halo":
+        assert alt["bytes_received_per_step_all_ranks"] > 0           # halos really moved between the ranks
+    else:
+        assert alt["bytes_received_per_step_all_ranks"] == 0
+    assert out["multi"].get("hbm_bytes_this_rank", 0) > 0              # per-rank HBM footprint of the pipeline

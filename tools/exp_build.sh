@@ -1,10 +1,23 @@
 #!/bin/bash
 # dev helper: build an experimental variant of libvphip.so into tools/exp/ (git-ignored), e.g.
 #   tools/exp_build.sh w5 -DVP_EXP_WAVES=5      then   VPHIP_LIB=tools/exp/libvphip_w5.so python tools/jfa_passes.py
+# The -D flags of a variant only reach jfa.hip (where every experiment macro lives); the other five sources are compiled once into
+# tools/exp/obj/ and shared by all variants (rebuilt when a source or header is newer).  Do not edit sources while a build runs.
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
-mkdir -p tools/exp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude "$@" \
-    cuda_mesh_voxelization_amd/csrc/{capi,vox,csg,jfa,extract,multi}.hip -o tools/exp/libvphip_$name.so
+mkdir -p tools/exp/obj
+CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude"
+(
+  flock 9
+  for s in capi vox csg extract multi; do
+    o=tools/exp/obj/$s.o
+    if [ ! -f $o ] || [ cuda_mesh_voxelization_amd/csrc/$s.hip -nt $o ] || [ cuda_mesh_voxelization_amd/csrc/vp_internal.h -nt $o ] || [ include/vphip.h -nt $o ]; then
+      $CC -c cuda_mesh_voxelization_amd/csrc/$s.hip -o $o &
+    fi
+  done
+  wait
+) 9> tools/exp/obj/.lock
+$CC "$@" -c cuda_mesh_voxelization_amd/csrc/jfa.hip -o tools/exp/obj/jfa_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/exp/obj/{capi,vox,csg,extract,multi}.o tools/exp/obj/jfa_$name.o -o tools/exp/libvphip_$name.so
 echo tools/exp/libvphip_$name.so

@@ -4,7 +4,8 @@
 
 ghost planes (no exchange): every rank of a G-GPU job is run on THIS GPU with the real kernels and timed; ranks share
   nothing, so the job time on G GPUs is the slowest rank -- a measurement, not a model.  Also printed: plane-passes per
-  rank against the single-GPU count (the work-replication ceiling of the scheme).
+  rank against the single-GPU count (the plane-pass ratio: every plane-pass counted alike -- NOT a ceiling on the speedup, since the
+  fused whole-grid launch of the first two passes is cheaper per plane than the passes it replaces).
 hybrid (ghost planes for k > nz/2, halos of the adjacent ranks for k <= nz/2): plane-passes per rank and bytes received per side are
   exact (slab.hybrid_plan); times are a MODEL: plane-passes x the measured single-GPU time per plane-pass, + the halo bytes of one
   side at an assumed per-link rate, once fully hidden under the interior planes and once not hidden at all.
@@ -40,7 +41,7 @@ t1 = timeit(single, reps)
 del g, sdf; eng._work = None; torch.cuda.empty_cache()
 print("n = %d, %d faces, id bytes S = %d, %d passes; 1 GPU: %.3f ms per job" % (n, tri.shape[0], S, passes, t1))
 print("\nghost planes (measured per rank on one GPU; job = slowest rank; nothing is exchanged)")
-print("  G   job ms  speedup  efficiency  plane-passes/rank (1 GPU: %d)  ceiling   per-rank ms" % (n * passes))
+print("  G   job ms  speedup  efficiency  plane-passes/rank (1 GPU: %d)  pp-ratio  per-rank ms" % (n * passes))
 for world in (2, 4, 8):
     ts, pp = [], []
     for r in range(world):
@@ -87,7 +88,7 @@ for world in (2, 4, 8):
     print("  %d   %8.3f          %5.2fx                            %s" % (world, max(ts), t1 / max(ts), " ".join("%.2f" % t for t in ts)))
 
 print("\nhybrid (plane-passes and bytes: exact; times: MODEL -- per plane-pass = 1-GPU job / (n x passes) = %.2f us)" % (t1 * 1e3 / (n * passes)))
-print("  G   plane-passes/rank  ceiling   id-buffer planes   GiB received per side   compute ms (measured)   + halos @150 GB/s per link: hidden .. exposed   vs 1 GPU")
+print("  G   plane-passes/rank  pp-ratio  id-buffer planes   GiB received per side   compute ms (measured)   + halos @150 GB/s per link: hidden .. exposed   vs 1 GPU")
 for world in (2, 4, 8):
     worst, win, rx = 0, 0, 0
     for r in range(world):
