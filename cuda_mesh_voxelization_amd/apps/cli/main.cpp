@@ -16,6 +16,8 @@
 //     -d, --dump PREFIX      (extension) write PREFIX.grid.u32 and PREFIX.sdf.f32 raw little-endian dumps
 //     -g, --gpus G           (extension) cut the grid into G Z-slabs, one per device 0 .. G-1 (the reference pins device 0,
 //                            apps/cli/main.cpp:22-23); --multi ghost|halo picks the JFA variant (vphip.h, vp_multi_jfa)
+//         --verify           (extension, with -g G > 1) run the job once more on device 0 alone and compare grid and sdf bit for
+//                            bit; prints "# multi-gpu ..." lines (parity, device-to-device bytes of the JFA), exit code 3 on a mismatch
 //     -h, --help
 #include <cmath>
 #include <cstdint>
@@ -57,6 +59,7 @@ struct Options {
     std::string dump;
     unsigned gpus = 1;
     std::string multi = "ghost";
+    bool verify = false;
     bool help = false;
 };
 
@@ -78,6 +81,8 @@ const char* kUsage =
     "                        <arg> must divide the side into slabs of a multiple of 8 planes\n"
     "      --multi arg       JFA on several devices: ghost = recomputed ghost planes, no exchange between passes (default);\n"
     "                        halo = halo planes copied device to device before every pass\n"
+    "      --verify          With -g > 1: run the job again on device 0 alone, compare grid and sdf bit for bit, print\n"
+    "                        '# multi-gpu' lines (parity, bytes moved between devices); exit code 3 on a mismatch (extension)\n"
     "  -h, --help            Print usage\n";
 
 // Minimal getopt-style parser: -x V, -xV, --long V, --long=V, boolean switches, positionals.
@@ -85,7 +90,7 @@ Options Parse(int argc, char** argv)
 {
     static const std::map<std::string, char> longNames = {
         {"filenames", 'i'}, {"num-voxels", 'n'}, {"type", 't'}, {"output", 'o'}, {"operation", 'p'}, {"export", 'e'},
-        {"sdf", 's'}, {"block-size", 'b'}, {"benckmark", 'm'}, {"benchmark", 'm'}, {"dump", 'd'}, {"gpus", 'g'}, {"multi", 'M'}, {"help", 'h'}};
+        {"sdf", 's'}, {"block-size", 'b'}, {"benckmark", 'm'}, {"benchmark", 'm'}, {"dump", 'd'}, {"gpus", 'g'}, {"multi", 'M'}, {"verify", 'V'}, {"help", 'h'}};
     Options o;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -106,10 +111,10 @@ Options Parse(int argc, char** argv)
             o.filenames.push_back(a);
             continue;
         }
-        const bool isSwitch = key == 'e' || key == 's' || key == 'h';
+        const bool isSwitch = key == 'e' || key == 's' || key == 'h' || key == 'V';
         if (isSwitch) {
             const bool v = !hasValue || value == "true" || value == "1";
-            if (key == 'e') o.doExport = v; else if (key == 's') o.sdf = v; else o.help = v;
+            if (key == 'e') o.doExport = v; else if (key == 's') o.sdf = v; else if (key == 'V') o.verify = v; else o.help = v;
             continue;
         }
         if (!hasValue) {
@@ -264,6 +269,36 @@ int main(int argc, char** argv)
                 cpuAssert(ExportMesh("out/sdf_point_cloud_" + typeName + "_" + opt.output, outMesh),
                           "Error in " + opt.output + " export (sdf)");
             }
+        }
+    }
+
+    if (GPU && opt.gpus > 1) {
+        // What moved between the devices during the last JFA (halo planes / the bitmask all-gather), and -- with --verify -- the
+        // same job once more on device 0 alone: the slabs must reproduce it bit for bit (first contact of the peer copies with a
+        // real multi-GPU node happens on machines the build never saw; a wrong result must not pass silently).
+        if (vp_multi* m = vplib::Multi())
+            std::printf("# multi-gpu devices %u mode %s jfa_bytes_moved %llu\n", opt.gpus, opt.multi.c_str(), (unsigned long long)vp_multi_bytes_moved(m));
+        if (opt.verify) {
+            vplib::SetDevices({}, true);                                       // back to the one-device path (device 0)
+            vplib::SetDevice(0);
+            std::vector<HostVoxelsGrid<gridType>> ref(meshes.size());
+            for (size_t i = 0; i < meshes.size(); ++i) {
+                ref[i] = HostVoxelsGrid<gridType>(N, voxelSize);
+                ref[i].View().SetOrigin(originX, originY, originZ);
+                if (TYPE == Types::NAIVE) Voxelize<Types::NAIVE>(opt.blockSize, ref[i], meshes[i]); else Voxelize<Types::TILED>(opt.blockSize, ref[i], meshes[i]);
+                if (i > 0 || BENCHMARK) Csg<Types::NAIVE>(OPERATION, ref[0], BENCHMARK ? emptyGrid : ref[i]);
+                if (BENCHMARK) break;
+            }
+            bool gridOk = std::memcmp(ref[0].View().Data(), grids[0].View().Data(), grids[0].View().StorageSize() * sizeof(gridType)) == 0;
+            bool sdfOk = true;
+            if (opt.sdf) {
+                HostGrid<float> refSdf(N, -INFINITY);
+                if (TYPE == Types::NAIVE) JFA::Compute<Types::NAIVE>(ref[0], refSdf); else JFA::Compute<Types::TILED>(ref[0], refSdf);
+                sdfOk = std::memcmp(refSdf.View().Data(), sdf.View().Data(), sdf.View().Size() * sizeof(float)) == 0;
+            }
+            std::printf("# multi-gpu parity_ok %s grid_equal %s sdf_equal %s (against the one-device path on device 0)\n",
+                        (gridOk && sdfOk) ? "true" : "false", gridOk ? "true" : "false", opt.sdf ? (sdfOk ? "true" : "false") : "n/a");
+            if (!(gridOk && sdfOk)) return 3;
         }
     }
 

@@ -353,15 +353,15 @@ class Multi:
         check(lib().vp_multi_set_mesh(self._h, xyz.ctypes.data, xyz.shape[0], tri.ctypes.data, tri.shape[0]))
 
     def voxelize(self, frame: Frame, algo=ALGO_TILED):
-        self.frame = frame
         check(lib().vp_multi_voxelize(self._h, ctypes.byref(frame), algo))
+        self.frame = frame                                         # only once the driver has taken it
 
     def set_grid(self, frame: Frame, words):
         np = self._np
-        self.frame = frame
         words = np.ascontiguousarray(words, dtype=np.uint32)
         assert words.size == frame.words
         check(lib().vp_multi_set_grid(self._h, ctypes.byref(frame), words.ctypes.data))
+        self.frame = frame
 
     def get_grid(self):
         out = self._np.empty(self.frame.words, dtype=self._np.uint32)

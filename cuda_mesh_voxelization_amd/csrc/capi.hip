@@ -405,11 +405,14 @@ int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fi
     if (!d_sdf) return set_error(VP_ERR_INVALID, "vp_jfa_run: null argument");
     VP_TRY(jfa_check(ctx, f, d_words, d_work, work_bytes, algo, "vp_jfa_run"));
     VP_TRY(check_fill(fill_unset, "vp_jfa_run"));
-    const Frame fr = make_frame(f);
+    Frame fr = make_frame(f);
     const size_t volBytes = vp_grid_voxels(f) * vp_jfa_id_bytes(f);
     char* a = (char*)d_work;
     char* b = a + volBytes;
     uint32_t k = f->n / 2;                                         // jfa/sequential.cpp:72
+    // n > 1024: the id state of this sequence lives in the compact layout (5 bytes per voxel inside the 8-byte volumes of the workspace):
+    // nobody outside this function sees the volumes
+    fr.compact = jfa_compact_applies(fr, algo) ? 1u : 0u;
     // The workspace must hold what THIS sequence starts from: the record of the matching vp_jfa_start (same grid, frame size,
     // algo and workspace).  One start serves one run: the passes overwrite the volumes.
     const bool wantMask = jfa_can_start_from_mask(fr, algo) && k > 1;

@@ -37,11 +37,22 @@ csg_words(uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t nword
 
 // The yardstick the HBM-bound kernels are priced against on the box they run on ("measure a device stream-copy
 // peak on the box"): the same access shape as csg_words and vox_fill -- 16 bytes per lane, grid-stride -- with nothing computed.
+// Shape (tools/ubench/copy.hip, profiles/r04/copy_shapes.txt): four independent loads in flight per thread before the first store,
+// nt cache policy on both sides, 16 - 32 workgroups per CU: 6.06 TB/s on the round-4 box; one load in flight and the default policy
+// (the round's first form): 4.87; hipMemcpyAsync device-to-device: 5.03.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kCopyUnroll = 4;
 __global__ void __launch_bounds__(256)
-stream_copy(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t nvec)
+stream_copy(u32x4* __restrict__ dst, const u32x4* __restrict__ src, size_t nvec)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) dst[i] = src[i];
+    const size_t stride = (size_t)gridDim.x * 256 * kCopyUnroll;
+    for (size_t i = (size_t)blockIdx.x * 256 * kCopyUnroll + threadIdx.x; i < nvec; i += stride) {
+        u32x4 v[kCopyUnroll];
+#pragma unroll
+        for (int u = 0; u < kCopyUnroll; ++u) { const size_t j = i + (size_t)u * 256; if (j < nvec) v[u] = __builtin_nontemporal_load(src + j); }
+#pragma unroll
+        for (int u = 0; u < kCopyUnroll; ++u) { const size_t j = i + (size_t)u * 256; if (j < nvec) __builtin_nontemporal_store(v[u], dst + j); }
+    }
 }
 
 }  // namespace
@@ -49,8 +60,8 @@ stream_copy(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t nvec)
 int launch_stream_copy(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes)
 {
     const size_t nvec = bytes / 16;
-    const unsigned blocks = (unsigned)std::min<size_t>((nvec + 255) / 256, (size_t)ctx->cus * 8);
-    hipLaunchKernelGGL(stream_copy, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)d_dst, (const uint4*)d_src, nvec);
+    const unsigned blocks = (unsigned)std::min<size_t>((nvec + 256 * kCopyUnroll - 1) / (256 * kCopyUnroll), (size_t)ctx->cus * 32);
+    hipLaunchKernelGGL(stream_copy, dim3(blocks), dim3(256), 0, ctx->stream, (u32x4*)d_dst, (const u32x4*)d_src, nvec);
     VP_HIP(hipGetLastError());
     return 0;
 }

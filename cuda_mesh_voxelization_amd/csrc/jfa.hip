@@ -98,6 +98,37 @@ struct Id64 {                     // n <= 2048: .x = scr(z)<<2 | x<<13, .y = scr
     __device__ static __forceinline__ T shfl(T a, int src) { return make_uint2((uint32_t)__shfl((int)a.x, src), (uint32_t)__shfl((int)a.y, src)); }
 };
 
+// Compact ids (round 4; n <= 2048, whole-grid vp_jfa only): 5 bytes per voxel in TWO planes instead of the 8 of Id64 --
+//   word plane (n^3 dwords):  x [0..10] | scr(y) [11..21] | low ten bits of scr(z) [22..31]
+//   byte plane (n^3 bytes, right behind the word plane):  "none" [bit 0] | top bit of z [bit 1]
+// 33 coordinate bits + "none" do not fit 32; the passes at this size are bound by fabric traffic, not by instruction issue
+// (profiles/r03/n2048_wide_ablation.txt), so what pays is fewer bytes: 10 instead of 16 per voxel and pass.  In registers an id is a
+// uint2 (.x = word, .y = byte).  "none" = (x field 0, byte 3): its x offset is slot 2048 of the x table (+inf), as in IdU.
+// Everything stays per lane (a dword and a byte load / store per id): no cross-lane packing of bit planes.
+struct IdC {
+    using T = uint2;
+    static constexpr int kTab = 2048;
+    static constexpr uint32_t kMask = 0x1FFCu;
+    static constexpr uint32_t kNoneWord = 0xFFFFF800u;
+    __device__ static __forceinline__ T none() { return make_uint2(kNoneWord, 3u); }
+    __device__ static __forceinline__ bool is_none(T a) { return (a.y & 1u) != 0u; }
+    __device__ static __forceinline__ T pack(uint32_t x, uint32_t y, uint32_t z)
+    {
+        const uint32_t sz = scr(z);
+        return make_uint2(x | (scr(y) << 11) | ((sz & 1023u) << 22), (sz >> 10) << 1);
+    }
+    __device__ static __forceinline__ T from64(uint2 a)           // Id64 -> compact ("none" = all ones)
+    {
+        if (a.x == 0xFFFFFFFFu) return none();
+        const uint32_t sz = (a.x >> 2) & 2047u, sy = (a.y >> 2) & 2047u;
+        return make_uint2((a.x >> 13) | (sy << 11) | ((sz & 1023u) << 22), (sz >> 10) << 1);
+    }
+    __device__ static __forceinline__ uint32_t xoff(T a) { return ((a.x & 0x7FFu) << 2) | ((a.y & 1u) << 13); }   // "none": 4 * 2048
+    __device__ static __forceinline__ uint32_t yoff(T a) { return (a.x >> 9) & kMask; }
+    __device__ static __forceinline__ uint32_t zoff(T a) { return ((a.x >> 20) & 0xFFCu) | ((a.y & 2u) << 11); }
+    __device__ static __forceinline__ uint32_t zt2(T a) { return a.y & 2u; }                   // top z bit, as it sits in the byte
+};
+
 // jfa/sequential.cpp:79-81 / :32-34 : voxel corner position along one axis
 __device__ __forceinline__ float axis_pos(float o, uint32_t i, float vs) { return o + ((float)(int)i * vs); }
 
@@ -552,6 +583,10 @@ __device__ __forceinline__ void row_load(uint2& o, __amdgpu_buffer_rsrc_t r, uin
     const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
     o = make_uint2(v[0], v[1]);
 }
+__device__ __forceinline__ uint32_t row_load_u8(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(r, (int)byte_off, 0, 0);
+}
 __device__ __forceinline__ float lds_f32(const char* p) { return *reinterpret_cast<const float*>(p); }
 // AUX = cache policy bits of the store (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  Plain / sc0 / nt stores leave the line in the XCD's L2,
 // sc1 forms drop it (MI355X_MICROARCH.md, "stores of each flavour").
@@ -571,6 +606,11 @@ __device__ __forceinline__ void row_store(uint2 v, __amdgpu_buffer_rsrc_t r, uin
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     const u32x2 t = {v.x, v.y};
     __builtin_amdgcn_raw_buffer_store_b64(t, r, (int)byte_off, 0, AUX);
+}
+template <int AUX = 0>
+__device__ __forceinline__ void row_store_u8(uint32_t v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, r, (int)byte_off, 0, AUX);
 }
 // A wave-uniform value made opaque to the optimiser where it is used: the 128-bit row descriptors derived from it are
 // then built right before their loads / stores (a few SALU instructions) instead of being hoisted out of the x loop,
@@ -623,6 +663,9 @@ __device__ __forceinline__ void pin(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(uint32_t& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(uint2& a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
 
+#ifndef VP_ZSTREAM_STORE_AUX
+#define VP_ZSTREAM_STORE_AUX 2      // cache policy of this kernel's output stores (row_store): 2 = nt (n = 2048: 430.9 -> 423.3 ms per step, profiles/r04)
+#endif
 // CZ (round 3): the tile's planes are a whole chain (CH = n / k, whole grid): the planes before the first and after the last output
 // plane lie outside the grid, and their iterations are removed at compile time (see the closed tiles of jfa_pass_dense).
 template <class ID, int TAB, int PXT, int RY, int CH, bool SKIP, bool CHECK_NONE, bool FINAL, bool CZ = false>
@@ -861,9 +904,9 @@ jfa_pass_zstream(Frame f, uint32_t k, const typename ID::T* __restrict__ in, con
                 const bool set = (WM[(a * CH + j) * (TAB / 32) + (x >> 5)] >> (x & 31)) & 1u;
                 // jfa_final's rule (sequential.cpp:55-60,106-109): set voxels carry +, unset ones the sign of the caller's fill;
                 // bestd is +inf when no seed was found, which copysign turns into the fill itself.
-                row_store(set ? bestd[a][j] : copysignf(bestd[a][j], fill), row_resource(sdf + rowIdx * N, (uint32_t)N * 4u), x * 4u);
+                row_store<VP_ZSTREAM_STORE_AUX>(set ? bestd[a][j] : copysignf(bestd[a][j], fill), row_resource(sdf + rowIdx * N, (uint32_t)N * 4u), x * 4u);
             } else {
-                row_store(best[a][j], row_resource(out + rowIdx * N, rowBytes), xo);
+                row_store<VP_ZSTREAM_STORE_AUX>(best[a][j], row_resource(out + rowIdx * N, rowBytes), xo);
             }
         };
 
@@ -1005,9 +1048,18 @@ template <class ID> constexpr bool final_mask_global() { return VP_FINAL_GLOBAL_
 //     tables of squared z differences -- (sz - pz)^2 is formed per id and output plane (2 VALU each) -- so that the footprint is
 //     48 KB and three 512-thread workgroups share a CU; "none" (all ones: its fields are real coordinates at n = 2048) gets an
 //     infinite seed x by an explicit test, once per id.
-template <class ID> constexpr bool dense_wide() { return std::is_same<ID, Id64>::value; }
+template <class ID> constexpr bool dense_wide() { return std::is_same<ID, Id64>::value || std::is_same<ID, IdC>::value; }   // 8-KB tables
+// Compact ids (IdC, round 4): the form above with the id state in a word plane and a byte plane (10 instead of 16 bytes per voxel and pass).
+// "none" goes through slot 2048 of the x table as in the 32-bit formats; the top z bit of a candidate travels in bit 1 of its rank
+// (rank = (tile row index + 1) << 14 | byte offset of the column + 1 | top z bit << 1; the own voxel: top z bit << 1 alone, below every
+// other rank), so the winner gather fetches one dword and the byte of the output is rebuilt from the winning pair (distance = +inf: "none").
 #ifndef VP_DENSE_STORE_AUX
-#define VP_DENSE_STORE_AUX 0        // cache policy of the tile kernel's output stores (see row_store)
+#define VP_DENSE_STORE_AUX 2        // cache policy of the tile kernel's output stores (see row_store): nt -- the output is not read again before
+                                    // the next pass; reads -15 % / -17 % (n = 512 / 1024: fewer source lines evicted), dense passes -1.1 % / -2.2 %,
+                                    // sc1 forms: the same bytes, -0.4 % / -0.8 % (profiles/r04/ab_store_*.txt, pmc_bytes_store_policy_and_gather.txt)
+#endif
+#ifndef VP_DENSE_XCD_MAP
+#define VP_DENSE_XCD_MAP 2          // 0: dispatch order; 1: XCD-contiguous tile ranges for every k; 2: only for k < 8 (see the kernel)
 #endif
 // Pair mode (PM = 1, 2, 4, 8; round 3): the lanes of a wave are paired so that the voxels x and x + k sit in two lanes one DPP
 // permutation apart (quad_perm for k = 1, 2; row_half_mirror for k = 4; row_ror:8 for k >= 8 -- the map from lane to x below keeps
@@ -1045,9 +1097,10 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 {
     using T = typename ID::T;
     constexpr bool WIDE = dense_wide<ID>();
-    constexpr uint32_t IDB = (uint32_t)sizeof(T);
+    constexpr bool CPT = std::is_same<ID, IdC>::value;             // word plane + byte plane (whole grids only: the byte plane follows the n^3 words)
+    constexpr uint32_t IDB = CPT ? 4u : (uint32_t)sizeof(T);       // bytes per voxel in the (word) plane the offsets below refer to
     constexpr int TAB = ID::kTab;
-    constexpr int PXT = WIDE ? TAB : TAB + 1;                      // 32-bit ids: slot TAB = the x index of "none" = +inf
+    constexpr int PXT = (WIDE && !CPT) ? TAB : TAB + 1;            // 32-bit and compact ids: slot TAB = the x index of "none" = +inf
     constexpr int EY = 1, EZ = 1;                                  // floats per table entry (wider entries: measured slower)
     constexpr int HY = (CLOSED & 1) ? 0 : 1;                       // halo rows on each side of the tile's output rows
     constexpr bool CZ = (CLOSED & 2) != 0;                         // no halo planes
@@ -1055,7 +1108,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     static_assert(!CLOSED || (!WIDE && !SKIP && !FINAL && ROLL), "closed tiles: dense 32-bit-id passes");
     constexpr int NC = PM ? 2 : 3;                                 // id columns a lane loads per source row
     constexpr int NI = NR * NC;
-    static_assert(!PM || (!SKIP && !WIDE), "pair mode: dense 32-bit-id passes");
+    static_assert(!PM || (!SKIP && (!WIDE || CPT)), "pair mode: dense passes on 32-bit or compact ids");
     constexpr int CHT = WIDE ? 1 : CH;                             // z tables: squared differences per output plane / one table of positions
     // (8-byte ids with a y table of POSITIONS too -- 24 KB of LDS, 256 threads, four workgroups per CU -- instead of RY tables of squared
     // differences -- 48 KB, 512 threads, two workgroups: measured 52.7 against 51.2 ms per pass at n = 2048, removed.)
@@ -1087,6 +1140,18 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         const uint32_t u = lin - (total - splitTiles);
         lin = total - splitTiles + (u >> 1); xpart = u & 1u; xparts = 2;
     }
+#if VP_DENSE_XCD_MAP
+    // Workgroups are dealt to the 8 XCDs by dispatch index mod 8.  Tiles that share halo ROWS are k apart in the tile sequence (y residue
+    // fastest): for k >= 8 they land on one XCD (one L2) anyway, for k = 4, 2, 1 they do not -- counters (profiles/r04/
+    // pmc_bytes_*.txt, n = 1024): reads 2.8 x the id volume at k = 4 / 2 against 1.6 x at k >= 8.  For k < 8 each XCD therefore walks one
+    // contiguous eighth of the whole-tile part of the sequence: reads at k = 4 / 2 fall to 1.57 x, the fused last pass 1.73 -> 1.36 x;
+    // time -0.6 % / -1.8 % (the passes are not traffic-bound).  For every k (mode 1) the map LOSES at k >= 8: 2.3 x instead of 1.6 x --
+    // neighbours in z are then a whole plane of tiles apart in time.
+    {
+        const uint32_t whole = total - splitTiles;                 // dispatch indices below `whole` are whole tiles, index = tile
+        if ((VP_DENSE_XCD_MAP == 1 || K < 8) && lin < whole && (whole & 7u) == 0u) lin = (lin & 7u) * (whole >> 3) + (lin >> 3);
+    }
+#endif
     if (rev) lin = total - 1u - lin;
     const int nres = min(K, nzl);
     // Tile order: y residue fastest -- consecutive tiles are adjacent rows of the volume and share nothing.  (Making the tiles of
@@ -1147,6 +1212,10 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     const char* tz = reinterpret_cast<const char*>(TZ);
     const uint32_t rowBytes = (uint32_t)N * IDB;
     const size_t planeBytes = (size_t)N * rowBytes;
+    // compact ids: byte planes of the source and the output volume (whole grids: n^3 words, then n^3 bytes) and the byte row of "none"
+    const char* inB = reinterpret_cast<const char*>(in) + (size_t)N * planeBytes;
+    char* outB = reinterpret_cast<char*>(out) + (size_t)N * planeBytes;
+    const char* noneB = reinterpret_cast<const char*>(none_row) + (size_t)TAB * 4u;
     int yout = 1, nout = 1;
 #pragma unroll
     for (int j = 1; j < RY; ++j) yout += (ybase + j * K < N) ? 1 : 0;
@@ -1192,6 +1261,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         const uint32_t xo = x * IDB, xmo = hasM ? xo - kb : xo, xpo = hasP ? xo + kb : xo;   // a column outside the grid reads the centre column
         // PM: the partner's column (always inside the grid) and the column beyond the own one
         const uint32_t xpart = upper ? xo - kb : xo + kb, xout = upper ? xpo : xmo;
+        const uint32_t xoB = xo >> 2, xmoB = xmo >> 2, xpoB = xpo >> 2, xoutB = xout >> 2;      // compact ids: the same columns in the byte plane
         // WIDE: rank of a candidate = (source row index << 14 | byte offset of the column it was read from) + 1
 
         // SKIP (wide passes, k >= n/4: half of the neighbour rows / planes / columns lie outside the grid): a source row that
@@ -1201,11 +1271,12 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         const bool anyM = !SKIP || __any(hasM), anyP = !SKIP || __any(hasP);
         // A source plane: its base address (wave-uniform, computed once per plane, right where the plane is first used) and
         // whether it exists at all (inside the grid, and needed by an output plane of this tile that exists).
-        struct Plane { const char* base; bool ok; };
+        struct Plane { const char* base; const char* baseB; bool ok; };
         auto plane_of = [&](int zg, bool needed) {
             Plane pl;
             pl.ok = needed && zg >= 0 && zg < N;
             pl.base = opaque_uniform(reinterpret_cast<const char*>(in) + ((ptrdiff_t)(pl.ok ? zg : (int)f.z0) - (ptrdiff_t)f.z0) * (ptrdiff_t)planeBytes);
+            pl.baseB = CPT ? opaque_uniform(inB + ((ptrdiff_t)(pl.ok ? zg : (int)f.z0) - (ptrdiff_t)f.z0) * (ptrdiff_t)((size_t)N * N)) : nullptr;
             return pl;
         };
         // ids of row rr of a source plane -> w[rr*3 ..]: columns {x-k, x, x+k}; "none" where outside the grid or not needed
@@ -1218,7 +1289,22 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             const __amdgpu_buffer_rsrc_t b =
                 row_resource(ok ? pl.base + ro[rr] : reinterpret_cast<const char*>(none_row), rowBytes);
 #endif
-            if constexpr (PM != 0) {
+            if constexpr (CPT) {
+                // word and byte of the three columns (a row of the byte plane is a quarter of the word row)
+                const __amdgpu_buffer_rsrc_t bb = row_resource(ok ? pl.baseB + (ro[rr] >> 2) : noneB, (uint32_t)N);
+                if constexpr (PM != 0) {
+                    uint32_t w0, w1;
+                    row_load(w0, b, xo); row_load(w1, b, xout);
+                    w[rr * 2 + 0] = make_uint2(w0, row_load_u8(bb, xoB));
+                    w[rr * 2 + 1] = make_uint2(w1, row_load_u8(bb, xoutB));
+                } else {
+                    uint32_t w0, w1, w2;
+                    row_load(w0, b, xmo); row_load(w1, b, xo); row_load(w2, b, xpo);
+                    w[rr * 3 + 0] = make_uint2(w0, row_load_u8(bb, xmoB));
+                    w[rr * 3 + 1] = make_uint2(w1, row_load_u8(bb, xoB));
+                    w[rr * 3 + 2] = make_uint2(w2, row_load_u8(bb, xpoB));
+                }
+            } else if constexpr (PM != 0) {
                 row_load(w[rr * 2 + 0], b, xo);
                 row_load(w[rr * 2 + 1], b, xout);
             } else {
@@ -1232,11 +1318,12 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 
         // What an id turns into before its candidate steps: seed x, squared y differences to the output rows it serves, squared
         // z differences to the output planes -- one LDS lookup each.
-        struct Dec { float sx; float dy2[RY]; float dz2[CH]; };
+        struct Dec { float sx; float dy2[RY]; float dz2[CH]; uint32_t zt; };     // zt (compact ids): top z bit << 1, part of the rank
         auto lookup = [&](int P, int rr, T id, Dec& d) {
             const int alo = max(rr - HY - 1, 0), ahi = min(rr - HY + 1, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
             d.sx = lds_f32(tx + ID::xoff(id));                              // 32-bit ids: "none" reads slot TAB = +inf
-            if constexpr (WIDE) d.sx = ID::is_none(id) ? INFINITY : d.sx;   // (inf - px)^2 = inf: "none" loses every '<'
+            if constexpr (WIDE && !CPT) d.sx = ID::is_none(id) ? INFINITY : d.sx;   // (inf - px)^2 = inf: "none" loses every '<'
+            if constexpr (CPT) d.zt = ID::zt2(id); else d.zt = 0u;
             const uint32_t yo = ID::yoff(id), zo = ID::zoff(id);
 #if defined(VP_ABL_NOLDS)                                                  // VP_ABL_*: ablation builds for the pipe analysis of DESIGN.md section 4 (WRONG results, timing only)
             for (int a = 0; a < RY; ++a) d.dy2[a] = __uint_as_float(yo + a);
@@ -1262,11 +1349,15 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         auto steps_col = [&](int P, int rr, int c, bool ownCol, uint32_t coloff, const Dec& d, uint32_t prank, auto dppv) {
             constexpr bool DPPV = decltype(dppv)::value;
             auto val = [&](float v) { if constexpr (DPPV) return from_partner<PM ? PM : 1>(v); else return v; };
+            auto valu = [&](uint32_t v) { if constexpr (DPPV) return __float_as_uint(from_partner<PM ? PM : 1>(__uint_as_float(v))); else return v; };
             const int alo = max(rr - HY - 1, 0), ahi = min(rr - HY + 1, RY - 1), olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
             const float dxv = val(d.sx) - px;
             const float dx2 = dxv * dxv;
             u32x2 cand;
-            if (!FINAL) cand.x = (WIDE ? (uint32_t)(((P + 1) * NR + rr) << 14) + 1u : prank + ro[rr]) + coloff;
+            if (!FINAL) {
+                if constexpr (CPT) cand.x = (uint32_t)(((P + 1) * NR + rr + 1) << 14) + 1u + coloff + valu(d.zt);
+                else cand.x = (WIDE ? (uint32_t)(((P + 1) * NR + rr) << 14) + 1u : prank + ro[rr]) + coloff;
+            }
 #pragma unroll
             for (int a = alo; a <= ahi; ++a) {
                 const float pre = val(d.dy2[a]) + dx2;
@@ -1282,7 +1373,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                         else best[a][o] = min_f32(best[a][o], dd);
                     } else {
                         u32x2 cd = cand;
-                        if (ownRow && o == P) cd.x = 0u;                   // the voxel's own state wins every tie (sequential.cpp:84,106)
+                        if (ownRow && o == P) cd.x = CPT ? d.zt : 0u;      // the voxel's own state wins every tie (sequential.cpp:84,106)
                         cd.y = __float_as_uint(dd);
 #if defined(VP_ABL_NOMIN)
                         { u32x2 t = __builtin_bit_cast(u32x2, best[a][o]); t.y = __float_as_uint(min_f32(__uint_as_float(t.y), dd)); best[a][o] = __builtin_bit_cast(double, t); }
@@ -1315,7 +1406,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             const uint32_t prank = WIDE ? 0u : (uint32_t)((zbase + P * K - zlo) * (ptrdiff_t)planeBytes) + 1u;
             const int olo = max(P - 1, 0), ohi = min(P + 1, CH - 1);
             const bool curOk = P <= nout && zbase + P * K >= 0 && zbase + P * K < N;      // SKIP: does this source plane exist
-            Plane next{nullptr, false};
+            Plane next{nullptr, nullptr, false};
             if (ROLL && P + 1 <= CH - (CZ ? 1 : 0)) next = plane_of(zbase + (P + 1) * K, P + 1 <= nout);
             if (VP_DENSE_PIPE && !SKIP) {
                 // Software pipeline over the 18 ids of the plane: the table lookups of id j + 1 are issued BEFORE the candidate
@@ -1427,10 +1518,16 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             } else {
                 if (P >= 2 && P - 2 < nout) {                      // ids gathered during the previous plane
                     const char* orow = opaque_uniform(reinterpret_cast<const char*>(out) + ((size_t)(lbase + (P - 2) * K) * N + ybase) * rowBytes);
+                    const char* orowB = CPT ? opaque_uniform(outB + ((size_t)(lbase + (P - 2) * K) * N + ybase) * (size_t)N) : nullptr;
 #pragma unroll
                     for (int a = 0; a < RY; ++a) {
                         if (a >= yout) continue;
-                        row_store<VP_DENSE_STORE_AUX>(pend[a], row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
+                        if constexpr (CPT) {
+                            row_store<VP_DENSE_STORE_AUX>(pend[a].x, row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
+                            row_store_u8<VP_DENSE_STORE_AUX>(pend[a].y, row_resource(orowB + (size_t)(a * K) * N, (uint32_t)N), xoB);
+                        } else {
+                            row_store<VP_DENSE_STORE_AUX>(pend[a], row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
+                        }
                     }
                 }
                 if (P >= 1 && P - 1 < nout) {                      // output plane P - 1 is complete: fetch the ids of its winners
@@ -1439,7 +1536,16 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                     for (int a = 0; a < RY; ++a) {
                         if (a >= yout) continue;
                         const uint32_t lo = __builtin_bit_cast(u32x2, best[a][P - 1]).x;
-                        if constexpr (WIDE) {
+                        if constexpr (CPT) {
+                            // rank = (source row index + 1) << 14 | byte offset in the word row, + 1, + top z bit << 1; the own voxel (rank < 4) sits
+                            // in row (P, a + 1) of the tile's source rows.  The byte of the output: top z bit from the rank, "none" iff nothing won.
+                            const uint32_t zt = lo & 2u;
+                            const uint32_t r = lo < 4u ? (uint32_t)((P * NR + a + 1 + 1) << 14) + xo : lo - 1u - zt;
+                            const ptrdiff_t row = (ptrdiff_t)(int)RB[(r >> 14) - 1u];
+                            const uint32_t none1 = __builtin_bit_cast(u32x2, best[a][P - 1]).y == 0x7F800000u ? 1u : 0u;
+                            pend[a] = make_uint2(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(in) + row * (ptrdiff_t)rowBytes + (ptrdiff_t)(r & 16383u)),
+                                                 zt | none1);
+                        } else if constexpr (WIDE) {
                             // rank - 1 = source row index << 14 | byte offset in the row; the own voxel (rank 0) sits in row (P, a + 1) of the tile's source rows
                             const uint32_t r = lo ? lo - 1u : (uint32_t)((P * NR + a + 1) << 14) + xo;
                             const ptrdiff_t row = (ptrdiff_t)(int)RB[r >> 14];
@@ -1471,10 +1577,16 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
         if constexpr (!FINAL) {
             if (CH - 1 < nout) {
                 const char* orow = opaque_uniform(reinterpret_cast<const char*>(out) + ((size_t)(lbase + (CH - 1) * K) * N + ybase) * rowBytes);
+                const char* orowB = CPT ? opaque_uniform(outB + ((size_t)(lbase + (CH - 1) * K) * N + ybase) * (size_t)N) : nullptr;
 #pragma unroll
                 for (int a = 0; a < RY; ++a) {
                     if (a >= yout) continue;
-                    row_store<VP_DENSE_STORE_AUX>(pend[a], row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
+                    if constexpr (CPT) {
+                        row_store<VP_DENSE_STORE_AUX>(pend[a].x, row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
+                        row_store_u8<VP_DENSE_STORE_AUX>(pend[a].y, row_resource(orowB + (size_t)(a * K) * N, (uint32_t)N), xoB);
+                    } else {
+                        row_store<VP_DENSE_STORE_AUX>(pend[a], row_resource(orow + (size_t)(a * K) * rowBytes, rowBytes), xo);
+                    }
                 }
             }
         }
@@ -1694,10 +1806,13 @@ __device__ unsigned long long g_ft_slots[kFtSlots][16];          // one row per 
 #ifndef VP_FT_POS_LDS
 #define VP_FT_POS_LDS 1
 #endif
-template <class ID, int XR, int NT, int TPW>
+// CPT (round 4): the result leaves in the compact layout of IdC (word plane + byte plane) instead of ID's own; inside the kernel the
+// ids stay ID's (Id64).
+template <class ID, int XR, int NT, int TPW, bool CPT = false>
 __global__ void __launch_bounds__(NT)
 jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out, uint32_t tilesX, uint32_t tiles, uint32_t shifts)
 {
+    static_assert(!CPT || std::is_same<ID, Id64>::value, "compact output: from 8-byte ids");
     using T = typename ID::T;
     constexpr uint32_t SLOTS = 64u * XR;                           // slot = ((plane * 4 + row) * 4 + segment) * XR + residue
     constexpr int PER = (int)(SLOTS / NT);
@@ -1839,7 +1954,14 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
             const unsigned long long key = keys[tid + (uint32_t)i * NT];
             const T id = key == kEmpty ? ID::none() : idOf[(uint32_t)key & 0x07FFFFFFu];       // stage B tags its proposals with the seed's slot
             const uint32_t rp = rpb + (uint32_t)i * G;
-            out[(size_t)((rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx] = id;
+            const size_t vox = (size_t)((rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx;
+            if constexpr (CPT) {
+                const uint2 c = IdC::from64(id);
+                reinterpret_cast<uint32_t*>(out)[vox] = c.x;
+                (reinterpret_cast<unsigned char*>(reinterpret_cast<uint32_t*>(out) + (size_t)N * N * N))[vox] = (unsigned char)c.y;
+            } else {
+                out[vox] = id;
+            }
         }
         VP_FT_STAMP(12);
         VP_FT_FLUSH(tile);
@@ -1944,6 +2066,15 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, c
 
 bool jfa_can_start_from_mask(const Frame& f, int algo) { return algo == VP_ALGO_TILED && f.n >= 256 && f.n % 128 == 0; }
 
+// Compact id state (IdC) for the whole-grid sequence of vp_jfa at n > 1024: first two passes fused from the border mask, every later
+// pass on the tile kernel -- all buffers are the call's own workspace, so the layout never meets a caller (the slab entry points keep
+// the 8-byte ids vp_jfa_id_bytes reports).  VP_JFA_COMPACT=0 (dev / tests) keeps the 8-byte ids here too.
+bool jfa_compact_applies(const Frame& f, int algo)
+{
+    static const int enabled = env_int("VP_JFA_COMPACT", 1);
+    return enabled && wide(f) && jfa_can_fuse_first_two(f, algo);
+}
+
 // Passes k = n/2 and k = n/4 of a whole grid from its border mask in one launch (jfa_first_two); timed as the first pass.
 #ifndef VP_JFA_FIRST_TWO_DEFAULT
 #define VP_JFA_FIRST_TWO_DEFAULT 1
@@ -1972,7 +2103,8 @@ int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, 
     const dim3 grid((tiles + VP_FIRST_TWO_TPW - 1) / VP_FIRST_TWO_TPW);
     auto pow2 = [](uint32_t v) { return v != 0 && (v & (v - 1)) == 0; };
     const uint32_t shifts = (pow2(tilesX) && pow2(k)) ? ((uint32_t)__builtin_ctz(tilesX) | ((uint32_t)__builtin_ctz(k) << 8) | (1u << 16)) : 0u;
-    if (wide(f))    hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles, shifts);
+    if (wide(f) && f.compact) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW, true>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles, shifts);
+    else if (wide(f)) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles, shifts);
     else if (small) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
     else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
     VP_HIP(hipGetLastError());
@@ -1998,15 +2130,18 @@ bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo)
     return algo == VP_ALGO_TILED && f.n >= 256;
 }
 
-// One row of "none" per id format for out-of-grid reads: 2048 x 8 bytes of the 64-bit "none", then 1024 x 4 of each 32-bit one.
+// One row of "none" per id format for out-of-grid reads: 2048 x 8 bytes of the 64-bit "none", then 1024 x 4 of each 32-bit one, then
+// the compact format's word row (2048 x 4) with its byte row (2048 x 1) right behind it.
 static int ensure_none_rows(vp_ctx* ctx)
 {
     if (ctx->none_row.ptr) return 0;
-    VP_TRY(reserve(ctx, ctx->none_row, 2048 * 8 + 2 * 1024 * 4));
+    VP_TRY(reserve(ctx, ctx->none_row, 2048 * 8 + 2 * 1024 * 4 + 2048 * 4 + 2048));
     char* p = (char*)ctx->none_row.ptr;
     VP_HIP(hipMemsetAsync(p, 0xFF, 2048 * 8, ctx->stream));
     VP_HIP(hipMemsetD32Async((hipDeviceptr_t)(p + 2048 * 8), (int)kNone9, 1024, ctx->stream));
     VP_HIP(hipMemsetD32Async((hipDeviceptr_t)(p + 2048 * 8 + 1024 * 4), (int)kNone10, 1024, ctx->stream));
+    VP_HIP(hipMemsetD32Async((hipDeviceptr_t)(p + 2048 * 8 + 2 * 1024 * 4), (int)IdC::kNoneWord, 2048, ctx->stream));
+    VP_HIP(hipMemsetAsync(p + 2048 * 8 + 2 * 1024 * 4 + 2048 * 4, 3, 2048, ctx->stream));
     return 0;
 }
 template <class ID>
@@ -2015,6 +2150,7 @@ static const typename ID::T* none_row_of(vp_ctx* ctx)
     const char* p = (const char*)ctx->none_row.ptr;
     if (std::is_same<ID, Id9>::value) p += 2048 * 8;
     if (std::is_same<ID, Id10>::value) p += 2048 * 8 + 1024 * 4;
+    if (std::is_same<ID, IdC>::value) p += 2048 * 8 + 2 * 1024 * 4;
     return (const typename ID::T*)p;
 }
 
@@ -2083,6 +2219,7 @@ static bool dense_applies(const Frame& f, uint32_t k, const void* d_in, const vo
     // read one to three planes earlier -- misses the L2 at this size (16-KB rows; 43.1 ms with the gather ablated).
     // VP_JFA_DENSE_WIDE=1 routes them here all the same (dev), =0 keeps even the last pass on the round-1 kernel.
     static const int wideMode = env_int("VP_JFA_DENSE_WIDE", 2);
+    if (f.compact) return true;                                    // compact ids (whole-grid vp_jfa at n > 1024): every pass k < n/4 runs here
     if (wide(f) && (wideMode == 0 || (wideMode == 2 && !fin))) return false;
     if (!enabled || (k * 4 >= f.n && !VP_JFA_DENSE_WIDEK)) return false;
     const size_t plane = (size_t)f.n * f.n * jfa_id_bytes(f);
@@ -2113,7 +2250,7 @@ static uint32_t tail_split(const vp_ctx* ctx, uint32_t tiles, uint32_t wgPerCu)
 static bool seeds_applies(const Frame& f, uint32_t k, bool fin)
 {
     static const int enabled = env_int("VP_JFA_SEEDS", VP_JFA_SEEDS_DEFAULT);
-    return enabled && !fin && k * 4u == f.n && f.z0 == 0 && f.z1 == f.n && k <= 65535u;
+    return enabled && !fin && !f.compact && k * 4u == f.n && f.z0 == 0 && f.z1 == f.n && k <= 65535u;
 }
 
 template <class ID>
@@ -2177,7 +2314,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     // pair mode where it applies: 32-bit ids, n a power of two, whole rows of NT-thread iterations; the lane permutation follows k
 #define VP_LAUNCH_DENSE(CH, NT, F, S)                                                                                              \
     do {                                                                                                                           \
-        if constexpr (!dense_wide<ID>() && !(S) && CH == 8) {    /* the 4-plane tiles of shallow slabs keep the plain form (fewer kernels to build) */ \
+        if constexpr ((!dense_wide<ID>() || std::is_same<ID, IdC>::value) && !(S) && CH == 8) {    /* the 4-plane tiles of shallow slabs keep the plain form (fewer kernels to build) */ \
             const bool pm_ = pow2 && f.n % NT == 0 && pairs >= ((F) ? 1 : 2) && ((F) || k >= 2);                                   \
             if (pm_ && (F))        { VP_LAUNCH_DENSE_PM(CH, NT, F, S, 1); break; }                                                 \
             /* k = 2 with the 2-KB tables: the plain form is 7 % faster (0.370 vs 0.396 ms; with the 4-KB tables pairs win by 3 %) */ \
@@ -2255,7 +2392,8 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
         else if (f.n <= 512) hipLaunchKernelGGL((jfa_pass_seeds<Id9, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
         else                 hipLaunchKernelGGL((jfa_pass_seeds<Id10, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
     } else if (f.n >= 256 && dense_applies(f, k, d_in, d_minus, d_plus, d_sdf != nullptr)) {
-        if (wide(f))         VP_TRY(launch_dense<Id64>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        if (f.compact)       VP_TRY(launch_dense<IdC>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        else if (wide(f))    VP_TRY(launch_dense<Id64>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
         else if (f.n <= 512) VP_TRY(launch_dense<Id9>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
         else                 VP_TRY(launch_dense<Id10>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
     } else if (f.n >= 256) {

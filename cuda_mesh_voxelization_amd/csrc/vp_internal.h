@@ -22,6 +22,7 @@ struct Frame {
     uint32_t w;        // words per x-row = n / 32
     uint32_t z0, z1;   // slab
     float vs, ox, oy, oz;
+    uint32_t compact;  // JFA id volumes of this call are in the compact layout (jfa.hip: IdC); set by vp_jfa_run only
 };
 
 inline Frame make_frame(const vp_frame* f)
@@ -29,6 +30,7 @@ inline Frame make_frame(const vp_frame* f)
     Frame r;
     r.n = f->n; r.w = f->n / 32; r.z0 = f->z0; r.z1 = f->z1;
     r.vs = f->voxel_size; r.ox = f->origin[0]; r.oy = f->origin[1]; r.oz = f->origin[2];
+    r.compact = 0;
     return r;
 }
 
@@ -124,6 +126,7 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
 bool jfa_can_start_from_mask(const Frame& f, int algo);
 int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out);
 bool jfa_can_fuse_first_two(const Frame& f, int algo);          // passes n/2 and n/4 in one launch from the border mask
+bool jfa_compact_applies(const Frame& f, int algo);             // whole-grid vp_jfa at n > 1024: 5-byte id state (jfa.hip: IdC)
 int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out);
 int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const void* d_ids,
                      float fill, float* d_sdf);

@@ -282,11 +282,17 @@ def test_cli_gpus_flag_matches_golden(cli, golden_rows, tmp_path, g, multi):
     VPLIB_SHARE_GPU=1 puts the slabs' contexts on the devices there are; results are the reference's golden rows all the same."""
     env = dict(os.environ, VPLIB_SHARE_GPU="1")
     for meshes, n, op in ((["bunny.obj"], 64, 0), (["bimba.obj", "bunny.obj"], 128, 1)):
-        args = [M.asset(m) for m in meshes] + ["-n", str(n), "-t", "2", "-s", "-g", str(g), "--multi", multi] + (["-p", str(op)] if op else [])
+        args = [M.asset(m) for m in meshes] + ["-n", str(n), "-t", "2", "-s", "-g", str(g), "--multi", multi, "--verify"] + (["-p", str(op)] if op else [])
         prefix = str(tmp_path / ("g%d%s%d" % (g, multi, n)))
         p = subprocess.run([cli] + args + ["-d", prefix], capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode == 0, p.stdout + p.stderr
         _check_row(prefix, _row(golden_rows, meshes, n, op))
+        # --verify: the job ran once more on device 0 alone and the slabs reproduced it; the JFA's device-to-device bytes are reported
+        assert "# multi-gpu parity_ok true grid_equal true sdf_equal true" in p.stdout, p.stdout
+        moved = [int(l.split()[-1]) for l in p.stdout.splitlines() if l.startswith("# multi-gpu devices %d mode %s jfa_bytes_moved" % (g, multi))]
+        assert len(moved) == 1 and moved[0] > 0
+        # device timers per kernel with -g too (ADVICE r03): the slowest rank's time
+        assert any(l.startswith("# device-time TiledJFA ") and "max-over-%d-devices" % g in l for l in p.stdout.splitlines())
         labels = {m.group("label") for m in map(LINE.match, p.stdout.splitlines()) if m}
         assert {"TiledVox::Processing", "TiledJFA::Processing", "TiledJFA::Memory"} <= labels   # same timer grammar
     # a slab count that does not cut the grid into multiples of 8 planes is refused with the reference-style assert line

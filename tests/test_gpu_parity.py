@@ -726,6 +726,38 @@ def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
     gc.collect(); torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("n,kind", [(1152, "sparse"), (1152, "mesh"), (1280, "sparse"), (2048, "sparse")])
+def test_compact_id_state_of_whole_grid_jfa_matches_naive(engine, n, kind):
+    """n > 1024, whole grid: vp_jfa keeps its id state in the compact layout of round 4 (jfa.hip: IdC -- a word plane and a byte plane,
+    5 bytes per voxel; first two passes fused from the border mask, every later pass and the fused last pass on the tile kernel, the top z
+    bit of a candidate carried in its rank).  The check is the naive sequence on 8-byte ids (one thread per voxel, the reference's scan
+    order and strict '<').  Sparse random grids are full of equidistant seeds and of voxels that stay "none" for many passes; sizes
+    that are not powers of two have odd steps, chains of 9 / 10 and a partial last x iteration."""
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    rng = np.random.default_rng(n)
+    if kind == "mesh":
+        xyz, tri = M.import_mesh(M.asset("bimba.obj"))
+        origin, vs = M.frame([xyz], n)
+        fr = Frame.make(n, vs, origin)
+        dx, dt = engine.mesh_to_device(xyz, tri)
+        g = engine.voxelize(fr, dx, dt)
+    else:
+        fr = Frame.make(n, 0.03125, (0.25, -1.0, 3.5))
+        words = (rng.random(fr.words) < 0.0005).astype(np.uint32) << rng.integers(0, 32, fr.words).astype(np.uint32)
+        g = engine.to_device(words, np.uint32)
+    assert engine.ctx.jfa_id_bytes(fr) == 8 and engine.ctx.jfa_can_fuse_first_two(fr, ALGO_TILED)
+    s_t = engine.jfa(fr, g, algo=ALGO_TILED).clone()
+    s_n = engine.jfa(fr, g, algo=ALGO_NAIVE)
+    engine.sync()
+    same = torch.equal(s_t.view(torch.int32), s_n.view(torch.int32))
+    bad = 0 if same else int((s_t.view(torch.int32) != s_n.view(torch.int32)).sum().item())
+    del s_t, s_n, g
+    engine._work = None
+    gc.collect(); torch.cuda.empty_cache()
+    assert same, (n, kind, bad)
+
+
 def test_round1_tile_kernel_path_still_matches(engine):
     """VP_JFA_DENSE=0 routes every pass of a 32-bit-id JFA through jfa_pass_zstream (the kernel that still serves 8-byte ids, the
     sparse pass and slabs whose halo buffers are not contiguous): same sdf, bit for bit, as the default path.  The switch is read

@@ -188,8 +188,8 @@ def test_multi_csg_checks_the_operand_size(engine):
         assert np.array_equal(m.get_grid(), np.ones(fr.words, np.uint32))
         # a failing replacement of the grid must not leave the old one flagged as resident under the new frame
         with pytest.raises(capi.VPError):
-            m.set_grid(Frame.make(96, 1.0, (0, 0, 0)), np.zeros(96 * 96 * 96 // 32, np.uint32)) if False else m.voxelize(Frame.make(100, 1.0, (0, 0, 0)))
-        assert np.array_equal(m.get_grid(), np.ones(fr.words, np.uint32))      # check_split fails BEFORE anything is touched
+            m.voxelize(Frame.make(100, 1.0, (0, 0, 0)))            # n % 32 != 0: refused by check_split, BEFORE anything is touched
+        assert np.array_equal(m.get_grid(), np.ones(fr.words, np.uint32))
     finally:
         m.close()
 
