@@ -335,7 +335,9 @@ def main():
     frame = Frame.make(n, vs, origin)
     eng = Engine(local_rank)
     d_xyz, d_tri = eng.mesh_to_device(xyz, tri)
-    S = eng.ctx.jfa_id_bytes(frame)
+    # S of SURVEY.md 8(d), "as implemented": what a pass really streams per voxel -- one GPU at n > 1024 keeps its state in the compact
+    # 5-byte layout; the slab pipelines exchange and address 8-byte ids there
+    S = eng.ctx.jfa_state_bytes(frame, ALGO_TILED) if world == 1 else eng.ctx.jfa_id_bytes(frame)
     passes = int(math.log2(n))
 
     def barrier():

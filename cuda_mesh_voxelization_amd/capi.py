@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("VPHIP_LIB") or os.path.join(PKG, "libvphip.so")   # V
 ALGO_NAIVE, ALGO_TILED = 1, 2
 OP_VOID, OP_UNION, OP_INTERSECTION, OP_DIFFERENCE = 0, 1, 2, 3
 EXTRACT_SET, EXTRACT_EXPOSED = 0, 1
-MULTI_HALO, MULTI_GHOST = 0, 1
+MULTI_HALO, MULTI_GHOST, MULTI_HYBRID = 0, 1, 2
 
 KERNELS = ["vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
            "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract"]
@@ -23,12 +23,12 @@ SYMBOLS = [
     "vp_device_count", "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_stream", "vp_ctx_sync", "vp_last_error", "vp_abi_version",
     "vp_malloc", "vp_free", "vp_memset", "vp_memcpy_d2d", "vp_stream_copy", "vp_ctx_workspace", "vp_ctx_release", "vp_upload", "vp_download",
     "vp_grid_words", "vp_grid_voxels",
-    "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa", "vp_jfa_start", "vp_jfa_run", "vp_jfa_init", "vp_jfa_pass",
+    "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa_state_bytes", "vp_jfa", "vp_jfa_start", "vp_jfa_run", "vp_jfa_init", "vp_jfa_pass",
     "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass", "vp_jfa_can_fuse_first_two", "vp_jfa_first_two",
     "vp_surface", "vp_extract_count", "vp_extract", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_select", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
     "vp_multi_create", "vp_multi_destroy", "vp_multi_count", "vp_multi_ctx", "vp_multi_sync", "vp_multi_set_mesh", "vp_multi_voxelize",
-    "vp_multi_set_grid", "vp_multi_get_grid", "vp_multi_csg", "vp_multi_jfa", "vp_multi_get_sdf", "vp_multi_bytes_moved",
+    "vp_multi_set_grid", "vp_multi_get_grid", "vp_multi_csg", "vp_multi_jfa", "vp_multi_get_sdf", "vp_multi_bytes_moved", "vp_multi_window",
 ]
 
 
@@ -82,6 +82,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libvphip.so is missing at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)" % LIB_PATH)
+    # Load order: torch ships its own libamdhip64.so, libvphip.so is linked against the one of /opt/rocm.  Whichever is mapped first serves
+    # both (same SONAME); if libvphip.so comes first and torch initialises the GPU afterwards, the process ends up with two HIP runtimes
+    # and vp_ctx_create finds no device (seen on the GPU box with `python __graft_entry__.py smoke`, which builds -- and loads -- first).
+    # The harness always runs beside torch, so torch goes first here.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     fp = ctypes.POINTER(Frame)
     sig = {
@@ -107,6 +115,7 @@ def lib():
         "vp_csg": (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int]),
         "vp_jfa_workspace_bytes": (_sz, [fp]),
         "vp_jfa_id_bytes": (_sz, [fp]),
+        "vp_jfa_state_bytes": (_sz, [fp, ctypes.c_int]),
         "vp_jfa": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_float, _vp, _vp, _sz, ctypes.c_int]),
         "vp_jfa_start": (ctypes.c_int, [_vp, fp, _vp, _vp, _sz, ctypes.c_int]),
         "vp_jfa_run": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_float, _vp, _vp, _sz, ctypes.c_int]),
@@ -142,6 +151,7 @@ def lib():
         "vp_multi_jfa": (ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_int, ctypes.c_int]),
         "vp_multi_get_sdf": (ctypes.c_int, [_vp, _vp]),
         "vp_multi_bytes_moved": (ctypes.c_uint64, [_vp]),
+        "vp_multi_window": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the symbol is not exported
@@ -215,6 +225,10 @@ class Context:
     def jfa_id_bytes(self, frame: Frame) -> int:
         """Bytes of JFA state per voxel: 4 for n <= 1024, 8 for n <= 2048."""
         return int(lib().vp_jfa_id_bytes(ctypes.byref(frame)))
+
+    def jfa_state_bytes(self, frame: Frame, algo: int = ALGO_TILED) -> int:
+        """Bytes of id state per voxel vp_jfa streams per pass (whole grid): 4, 5 (compact layout above n = 1024) or 8."""
+        return int(lib().vp_jfa_state_bytes(ctypes.byref(frame), algo))
 
     def jfa(self, frame: Frame, d_words: int, fill: float, d_sdf: int, d_work=None, work_bytes: int = 0,
             algo: int = ALGO_TILED):
@@ -386,3 +400,9 @@ class Multi:
     @property
     def bytes_moved(self):
         return int(lib().vp_multi_bytes_moved(self._h))
+
+    def window(self, rank: int):
+        """(lo, hi, id_bytes): global planes the rank's id volumes covered during the last jfa, and the bytes of all its id buffers"""
+        lo, hi, nb = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        check(lib().vp_multi_window(self._h, rank, ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(nb)))
+        return int(lo.value), int(hi.value), int(nb.value)

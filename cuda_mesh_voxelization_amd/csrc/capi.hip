@@ -34,13 +34,13 @@ void release(Buffer& b)
     b.ptr = nullptr; b.bytes = 0;
 }
 
-int reserve(vp_ctx* ctx, Buffer& b, size_t bytes)
+int reserve(vp_ctx* ctx, Buffer& b, size_t bytes, bool headroom)
 {
     if (bytes <= b.bytes) return 0;
     VP_HIP(hipStreamSynchronize(ctx->stream));
     if (b.ptr) VP_HIP(hipFree(b.ptr));
     b.ptr = nullptr; b.bytes = 0;
-    const size_t want = bytes + bytes / 4;                        // head-room: fewer regrows
+    const size_t want = headroom ? bytes + bytes / 4 : bytes;     // head-room: fewer regrows (not for the id volumes of the slab driver: GiBs)
     VP_HIP(hipMalloc(&b.ptr, want));
     b.bytes = want;
     return 0;
@@ -443,6 +443,13 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
     VP_TRY(check_fill(fill_unset, "vp_jfa"));
     VP_TRY(vp_jfa_start(ctx, f, d_words, d_work, work_bytes, algo));
     return vp_jfa_run(ctx, f, d_words, fill_unset, d_sdf, d_work, work_bytes, algo);
+}
+
+size_t vp_jfa_state_bytes(const vp_frame* f, int algo)
+{
+    if (!f || check_frame(f, "vp_jfa_state_bytes", false) != 0) return 0;
+    const Frame fr = make_frame(f);
+    return jfa_compact_applies(fr, algo) ? 5 : jfa_id_bytes(fr);
 }
 
 int vp_jfa_can_start_from_mask(const vp_frame* f, int algo)

@@ -13,6 +13,8 @@
 //                              the whole JFA is enqueued without a host synchronisation.  Halos of the narrow passes
 //                              (k <= nz/2) land directly below / above the slab inside one allocation, so those passes see
 //                              one contiguous volume (the dense tile kernel applies).
+//                  VP_MULTI_HYBRID (round 4) ghost planes for the passes with k > nz/2, halo copies from the two adjacent ranks for the
+//                              others; id buffers hold only the window of planes a rank touches (jfa_hybrid below).
 //                  VP_MULTI_GHOST  no exchange between passes: the bitmask slabs are all-gathered once (n^3/8 bytes), every
 //                              device runs pass i on its slab widened by the reach of the later passes and the regions shrink
 //                              to the bare slab at k = 1.  Costs two full id volumes per device.
@@ -57,6 +59,7 @@ struct vp_multi {
     size_t nverts = 0, ntris = 0;
     uint64_t bytes_moved = 0;                  // device-to-device bytes of the last vp_multi_jfa
     int last_mode = -1;
+    std::vector<uint32_t> window_lo, window_hi; // id planes each rank held during the last vp_multi_jfa
 };
 
 namespace {
@@ -80,7 +83,8 @@ int grow(Rank& r, Buffer& b, size_t bytes)
 int grow_ids(Rank& r, Buffer& b, size_t bytes)
 {
     const size_t before = b.bytes;
-    VP_TRY(grow(r, b, bytes));
+    VP_TRY(bind(r));
+    VP_TRY(reserve(r.ctx, b, bytes ? bytes : 1, /*headroom=*/false));   // exact: a window must not cost more than it saves
     const char* poison = getenv("VP_MULTI_POISON");
     if (b.bytes != before || poison)
         VP_HIP(hipMemsetAsync(b.ptr, poison ? (int)strtol(poison, nullptr, 0) & 0xFF : 0, b.bytes, r.ctx->stream));
@@ -328,6 +332,121 @@ int jfa_ghost(vp_multi* m, float fill, int algo)
     return 0;
 }
 
+// ---- VP_MULTI_HYBRID (round 4): ghost planes where planes are cheap to recompute and dear to move, halos where it is the other way
+// round -- the one-process form of slab.py's HybridSlabPipeline.  Passes with k > nz/2 ("wide": whole slabs of distant ranks would have
+// to travel) run on the slab widened by the reach of the LATER WIDE passes only; passes with k <= nz/2 ("narrow") run on the bare slab
+// behind k halo planes copied from the two adjacent ranks.  Id buffers hold the planes [lo, hi) a rank touches -- its WINDOW -- instead of
+// the whole volume (vp_multi_window reports it): G = 8 at n = 1024: 896 of 1024 planes; G = 8 at n = 2048: 1792 of 2048.
+struct HybridPlan { std::vector<Region> wide; std::vector<uint32_t> narrow; uint32_t lo, hi; };
+
+HybridPlan hybrid_plan(uint32_t n, uint32_t world, uint32_t z0, uint32_t z1, bool maskStart)
+{
+    HybridPlan p;
+    const uint32_t nz = z1 - z0, H = world > 1 ? nz / 2 : 0;
+    std::vector<uint32_t> wideK;
+    for (uint32_t k = n / 2; k >= 1; k /= 2) { if (k > H) wideK.push_back(k); else p.narrow.push_back(k); }
+    for (size_t i = 0; i < wideK.size(); ++i) {
+        uint32_t g = 0;
+        for (size_t j = i + 1; j < wideK.size(); ++j) g += wideK[j];
+        p.wide.push_back({wideK[i], z0 > g ? (z0 - g) / 8 * 8 : 0, std::min(n, (z1 + g + 7) / 8 * 8)});
+    }
+    // window: the slab with room for the narrow halos, every wide region, and what a wide pass that READS ids reads beyond its region
+    p.lo = z0 > H ? z0 - H : 0; p.hi = std::min(n, z1 + H);
+    for (size_t i = 0; i < p.wide.size(); ++i) {
+        const Region& r = p.wide[i];
+        p.lo = std::min(p.lo, r.b0); p.hi = std::max(p.hi, r.b1);
+        if (i > 0 || !maskStart) { p.lo = std::min(p.lo, r.b0 > r.k ? r.b0 - r.k : 0); p.hi = std::max(p.hi, std::min(n, r.b1 + r.k)); }
+    }
+    return p;
+}
+
+int jfa_hybrid(vp_multi* m, float fill, int algo)
+{
+    const vp_frame& G = m->frame;
+    const uint32_t n = G.n, world = (uint32_t)m->ranks.size(), nz = n / world;
+    const size_t S = vp_jfa_id_bytes(&G), planeIds = (size_t)n * n * S, planeWords = (size_t)n * n / 8;
+    const size_t slabWords = (size_t)nz * planeWords;
+    const bool maskStart = vp_jfa_can_start_from_mask(&G, algo) != 0 && n / 2 > 1;
+    std::vector<HybridPlan> plans;
+    m->window_lo.assign(world, 0); m->window_hi.assign(world, 0);
+    for (uint32_t r = 0; r < world; ++r) {
+        Rank& me = m->ranks[r];
+        plans.push_back(hybrid_plan(n, world, me.z0, me.z1, maskStart));
+        const HybridPlan& p = plans.back();
+        m->window_lo[r] = p.lo; m->window_hi[r] = p.hi;
+        VP_TRY(grow(me, me.border, (size_t)n * planeWords));
+        for (Buffer& b : me.ids) VP_TRY(grow_ids(me, b, (size_t)(p.hi - p.lo) * planeIds));
+        VP_TRY(grow(me, me.sdf, (size_t)nz * n * n * 4));
+    }
+    // the wide passes need the bitmask of the whole grid on every device (as in the ghost mode): all-gather of the slabs
+    for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
+    for (uint32_t r = 0; r < world; ++r)
+        for (uint32_t o = 0; o < world; ++o)
+            if (o != r) VP_TRY(peer_copy(m, m->ranks[r], (char*)m->ranks[r].words.ptr + (size_t)o * slabWords, m->ranks[o],
+                                         (const char*)m->ranks[o].words.ptr + (size_t)o * slabWords, slabWords));
+    if (world > 1) VP_TRY(fence_copies(m));
+    const size_t nwide = plans[0].wide.size(), nnarrow = plans[0].narrow.size();     // the same on every rank (they depend on nz only)
+    std::vector<int> cur(world, 0);
+    // plane g of rank r's id volume `which`
+    auto at = [&](uint32_t r, int which, int64_t g) {
+        return reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(m->ranks[r].ids[which].ptr) + (uintptr_t)((g - (int64_t)plans[r].lo) * (int64_t)planeIds));
+    };
+    // ---- wide passes: ghost planes inside the window, no exchange
+    for (uint32_t r = 0; r < world; ++r) {
+        Rank& me = m->ranks[r];
+        const HybridPlan& p = plans[r];
+        const uint32_t* words = (const uint32_t*)me.words.ptr;
+        size_t start = 0;
+        if (maskStart && nwide > 0) {
+            VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
+            const vp_frame f = slab_frame(G, p.wide[0].b0, p.wide[0].b1);
+            VP_TRY(vp_jfa_first_pass(me.ctx, &f, (const uint32_t*)me.border.ptr, at(r, 1, p.wide[0].b0)));
+            cur[r] = 1; start = 1;
+        } else {
+            const vp_frame f = slab_frame(G, p.lo, p.hi);
+            VP_TRY(vp_jfa_init(me.ctx, &f, words + (size_t)p.lo * (planeWords / 4), p.lo > 0 ? words + (size_t)(p.lo - 1) * (planeWords / 4) : nullptr,
+                               p.hi < n ? words + (size_t)p.hi * (planeWords / 4) : nullptr, at(r, 0, p.lo)));
+        }
+        for (size_t i = start; i < nwide; ++i) {
+            const Region& g = p.wide[i];
+            const vp_frame f = slab_frame(G, g.b0, g.b1);
+            const int c = cur[r];
+            const char* mi = g.b0 == 0 ? nullptr : at(r, c, (int64_t)g.b0 - g.k);
+            const char* pl = g.b1 >= n ? nullptr : at(r, c, std::max(g.b1, g.b0 + g.k));
+            if (i + 1 == nwide && nnarrow == 0)                     // one rank: the last pass is a wide one
+                VP_TRY(vp_jfa_last_pass(me.ctx, &f, at(r, c, g.b0), mi, pl, at(r, c ^ 1, g.b0), words + (size_t)g.b0 * (planeWords / 4), fill, (float*)me.sdf.ptr, algo));
+            else
+                VP_TRY(vp_jfa_pass(me.ctx, &f, g.k, at(r, c, g.b0), mi, pl, at(r, c ^ 1, g.b0), algo));
+            cur[r] ^= 1;
+        }
+    }
+    // ---- narrow passes: k halo planes from each adjacent rank, device to device, then the bare slab
+    for (size_t j = 0; j < nnarrow; ++j) {
+        const uint32_t k = plans[0].narrow[j];
+        if (world > 1) {
+            for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
+            for (uint32_t r = 0; r < world; ++r) {
+                Rank& me = m->ranks[r];
+                if (r > 0)         VP_TRY(peer_copy(m, me, at(r, cur[r], (int64_t)me.z0 - k), m->ranks[r - 1], at(r - 1, cur[r - 1], (int64_t)me.z0 - k), (size_t)k * planeIds));
+                if (r + 1 < world) VP_TRY(peer_copy(m, me, at(r, cur[r], me.z1), m->ranks[r + 1], at(r + 1, cur[r + 1], me.z1), (size_t)k * planeIds));
+            }
+            VP_TRY(fence_copies(m));
+        }
+        for (uint32_t r = 0; r < world; ++r) {
+            Rank& me = m->ranks[r];
+            const vp_frame f = slab_frame(G, me.z0, me.z1);
+            const int c = cur[r];
+            const char* mi = me.z0 == 0 ? nullptr : at(r, c, (int64_t)me.z0 - k);
+            const char* pl = me.z1 >= n ? nullptr : at(r, c, me.z1);
+            const uint32_t* slabW = (const uint32_t*)me.words.ptr + (size_t)me.z0 * (planeWords / 4);
+            if (j + 1 == nnarrow) VP_TRY(vp_jfa_last_pass(me.ctx, &f, at(r, c, me.z0), mi, pl, at(r, c ^ 1, me.z0), slabW, fill, (float*)me.sdf.ptr, algo));
+            else                  VP_TRY(vp_jfa_pass(me.ctx, &f, k, at(r, c, me.z0), mi, pl, at(r, c ^ 1, me.z0), algo));
+            cur[r] ^= 1;
+        }
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -466,10 +585,11 @@ int vp_multi_jfa(vp_multi* m, float fill_unset, int algo, int mode)
     if (!m || !m->have_grid) return set_error(VP_ERR_INVALID, "vp_multi_jfa: no resident grid (vp_multi_voxelize / vp_multi_set_grid first)");
     if (!std::isinf(fill_unset)) return set_error(VP_ERR_INVALID, "vp_multi_jfa: fill_unset must be +-infinity");
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_multi_jfa: algo %d", algo);
-    if (mode != VP_MULTI_HALO && mode != VP_MULTI_GHOST) return set_error(VP_ERR_INVALID, "vp_multi_jfa: mode %d", mode);
+    if (mode != VP_MULTI_HALO && mode != VP_MULTI_GHOST && mode != VP_MULTI_HYBRID) return set_error(VP_ERR_INVALID, "vp_multi_jfa: mode %d", mode);
     m->bytes_moved = 0;
     m->last_mode = mode;
     if (mode == VP_MULTI_GHOST) VP_TRY(jfa_ghost(m, fill_unset, algo));
+    else if (mode == VP_MULTI_HYBRID) VP_TRY(jfa_hybrid(m, fill_unset, algo));
     else VP_TRY(jfa_halo(m, fill_unset, algo));
     m->have_sdf = true;
     return 0;
@@ -487,5 +607,21 @@ int vp_multi_get_sdf(vp_multi* m, float* h_sdf)
 }
 
 uint64_t vp_multi_bytes_moved(const vp_multi* m) { return m ? m->bytes_moved : 0; }
+
+int vp_multi_window(const vp_multi* m, int rank, uint32_t* lo, uint32_t* hi, uint64_t* id_bytes)
+{
+    if (!m || rank < 0 || rank >= (int)m->ranks.size() || m->last_mode < 0) return set_error(VP_ERR_INVALID, "vp_multi_window: no JFA has run");
+    const uint32_t n = m->frame.n, world = (uint32_t)m->ranks.size(), nz = n / world;
+    uint32_t a = 0, b = n;                                          // ghost: whole volumes
+    if (m->last_mode == VP_MULTI_HALO) { const uint32_t H = world > 1 ? nz / 2 : 0; a = m->ranks[rank].z0 > H ? m->ranks[rank].z0 - H : 0; b = std::min(n, m->ranks[rank].z1 + H); }
+    else if (m->last_mode == VP_MULTI_HYBRID) { a = m->window_lo[(size_t)rank]; b = m->window_hi[(size_t)rank]; }
+    if (lo) *lo = a;
+    if (hi) *hi = b;
+    if (id_bytes) {
+        const Rank& r = m->ranks[(size_t)rank];
+        *id_bytes = (uint64_t)r.ids[0].bytes + r.ids[1].bytes + (m->last_mode == VP_MULTI_HALO ? (uint64_t)r.minus.bytes + r.plus.bytes : 0ull);
+    }
+    return 0;
+}
 
 }  // extern "C"

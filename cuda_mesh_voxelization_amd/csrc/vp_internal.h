@@ -100,7 +100,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
         if (rc_ != 0) return rc_;    \
     } while (0)
 
-int reserve(vp_ctx* ctx, Buffer& b, size_t bytes);
+int reserve(vp_ctx* ctx, Buffer& b, size_t bytes, bool headroom = true);
 void release(Buffer& b);
 
 // RAII-less profiling bracket: begin() before the launch, end() after.

@@ -13,6 +13,7 @@ int g_device = 0;
 vp_ctx* g_ctx = nullptr;
 std::vector<int> g_devices;
 bool g_ghost = true;
+int g_mode = -1;                                                   // SetMultiMode: overrides the ghost / halo choice of SetDevices
 vp_multi* g_multi = nullptr;
 }  // namespace
 
@@ -26,6 +27,7 @@ void SetDevices(const std::vector<int>& devices, bool ghost)
     }
     g_devices = devices;
     g_ghost = ghost;
+    g_mode = -1;
     if (!devices.empty()) g_device = devices[0];                   // exports and single-device calls use the first one
 }
 
@@ -40,7 +42,9 @@ vp_multi* Multi()
     return g_multi;
 }
 
-int MultiMode() { return g_ghost ? VP_MULTI_GHOST : VP_MULTI_HALO; }
+int MultiMode() { return g_mode >= 0 ? g_mode : (g_ghost ? VP_MULTI_GHOST : VP_MULTI_HALO); }
+
+void SetMultiMode(int mode) { g_mode = mode; }
 
 int DeviceCount()
 {

@@ -137,6 +137,11 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
  *   algo        VP_ALGO_NAIVE: direct kernel; VP_ALGO_TILED: LDS-table kernel.  Same results. */
 size_t vp_jfa_workspace_bytes(const vp_frame* f);
 size_t vp_jfa_id_bytes(const vp_frame* f);
+/* Bytes of id state per voxel that vp_jfa (whole-grid frame, its own workspace) really streams per pass -- the S of SURVEY.md 8(d)
+ * "as implemented": 4 for n <= 1024; above that 5 when the call keeps its state in the compact layout (a 32-bit word plane + a byte
+ * plane inside the 8-byte volumes of the workspace: VP_ALGO_TILED, n % 128 == 0), else 8.  Measurement only: the id buffers a caller
+ * passes to the slab entry points are always vp_jfa_id_bytes wide. */
+size_t vp_jfa_state_bytes(const vp_frame* f, int algo);
 int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
            float* d_sdf, void* d_work, size_t work_bytes, int algo);
 /* vp_jfa in the two parts the reference times separately ("::Initialization" = seeding, jfa/tiled.cu:265-290;
@@ -218,11 +223,14 @@ int vp_extract(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode
  *                    VP_MULTI_GHOST: the bitmask slabs are all-gathered once (n^3/8 bytes) and every device recomputes the
  *                                    ghost planes its later passes reach: no exchange between passes, two full id volumes
  *                                    per device
+ *                    VP_MULTI_HYBRID: ghost planes for the passes with k > nz/2 (as far as the later such passes reach), halo
+ *                                    planes from the two adjacent devices for the passes with k <= nz/2; the id volumes hold only
+ *                                    the planes a device touches (vp_multi_window): capacity, not speed
  * Results are bit-identical to the single-device calls for any G.  `devices` may name one device several times (several
  * contexts on it): that is how the parity tests run on a one-GPU box.  Grid, sdf and mesh stay resident on the devices
  * between calls; host arrays are whole-grid arrays in the reference's layout. */
 typedef struct vp_multi vp_multi;
-enum { VP_MULTI_HALO = 0, VP_MULTI_GHOST = 1 };
+enum { VP_MULTI_HALO = 0, VP_MULTI_GHOST = 1, VP_MULTI_HYBRID = 2 };
 int vp_multi_create(const int* devices, int ndev, vp_multi** out);
 int vp_multi_destroy(vp_multi* m);
 int vp_multi_count(const vp_multi* m);
@@ -243,6 +251,10 @@ int vp_multi_jfa(vp_multi* m, float fill_unset, int algo, int mode);
 int vp_multi_get_sdf(vp_multi* m, float* h_sdf);
 /* device-to-device bytes the last vp_multi_jfa enqueued (halo planes / the bitmask all-gather) */
 uint64_t vp_multi_bytes_moved(const vp_multi* m);
+/* JFA state a rank held during the last vp_multi_jfa: the global planes [lo, hi) its two id volumes cover -- the whole grid with
+ * VP_MULTI_GHOST, the slab +- nz/2 with VP_MULTI_HALO (plus two whole-slab buffers for the wide passes), the rank's WINDOW with
+ * VP_MULTI_HYBRID -- and the bytes of device memory in all its id buffers.  Any out pointer may be NULL. */
+int vp_multi_window(const vp_multi* m, int rank, uint32_t* lo, uint32_t* hi, uint64_t* id_bytes);
 
 /* ---- host-in / host-out conveniences (the reference's Compute() calling convention) -------
  * Upload, run, download, synchronise -- what every reference Compute<NAIVE|TILED> does

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from cuda_mesh_voxelization_amd import capi, mesh as M
-from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, MULTI_GHOST, MULTI_HALO, Frame
+from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, MULTI_GHOST, MULTI_HALO, MULTI_HYBRID, Frame
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -36,13 +36,23 @@ def test_multi_matches_single_and_oracle(engine, name, n, world):
         for algo in (ALGO_TILED, ALGO_NAIVE):
             m.voxelize(fr, algo)
             assert np.array_equal(m.get_grid(), exp_w)
-            for mode in (MULTI_HALO, MULTI_GHOST):
+            vp_id_bytes = 4                                             # n <= 1024
+            for mode in (MULTI_HALO, MULTI_GHOST, MULTI_HYBRID):
                 m.jfa(algo=algo, mode=mode)
                 got = m.get_sdf()
                 assert np.array_equal(got.view(np.uint32), exp_s.view(np.uint32)), (algo, mode)
-                # halo: planes really moved (bitmask planes + id planes of every pass); ghost: only the bitmask all-gather
+                # halo: planes really moved (bitmask planes + id planes of every pass); ghost: only the bitmask all-gather;
+                # hybrid: the all-gather + k planes per side and narrow pass
+                gather = world * (world - 1) * (fr.words // world) * 4
                 if mode == MULTI_GHOST:
-                    assert m.bytes_moved == world * (world - 1) * (fr.words // world) * 4
+                    assert m.bytes_moved == gather
+                elif mode == MULTI_HYBRID:
+                    nz = n // world
+                    narrow = [k for k in (n >> i for i in range(1, n.bit_length())) if 1 <= k <= nz // 2]
+                    assert m.bytes_moved == gather + 2 * (world - 1) * sum(narrow) * n * n * 4
+                    for r in range(world):                               # the id volumes hold the rank's window, not the grid
+                        lo, hi, nbytes = m.window(r)
+                        assert 0 <= lo <= r * nz and (r + 1) * nz <= hi <= n and nbytes >= 2 * (hi - lo) * n * n * vp_id_bytes
                 else:
                     assert m.bytes_moved > 2 * (world - 1) * n * n * 4
     finally:
@@ -77,7 +87,7 @@ def test_multi_csg_and_set_grid(engine):
 
 
 @pytest.mark.parametrize("world,mode,fused_pct", [(2, MULTI_HALO, None), (4, MULTI_HALO, None), (8, MULTI_HALO, None), (4, MULTI_GHOST, None),
-                                                  (8, MULTI_GHOST, None), (8, MULTI_GHOST, "101")])
+                                                  (8, MULTI_GHOST, None), (8, MULTI_GHOST, "101"), (4, MULTI_HYBRID, None), (8, MULTI_HYBRID, None)])
 def test_multi_headline_size_equals_single(engine, world, mode, fused_pct, monkeypatch):
     """n = 512 on the benchmark mesh: narrow passes land next to the slab (dense tile kernel), wide ones in the whole-slab
     buffers; ghost regions take the first two passes as the one whole-grid launch (every rank of 2 .. 8 slabs is above the 35 %
@@ -192,6 +202,43 @@ def test_multi_csg_checks_the_operand_size(engine):
         assert np.array_equal(m.get_grid(), np.ones(fr.words, np.uint32))
     finally:
         m.close()
+
+
+def test_multi_hybrid_n1024_eight_slabs_window(engine):
+    """windowed id state in the C++ slab driver.  VP_MULTI_HYBRID on eight contexts of the one device, the benchmark
+    mesh at n = 1024 (eight windows of a real node sit on eight devices; on ONE device they have to fit together, which at n = 2048
+    -- 8 x 112 GiB -- they cannot: that size is covered rank by rank with the Python pipelines, tests/test_slab_gpu.py): grid and sdf
+    bit-identical to the single-context result, every rank's id volumes cover its window only."""
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    xyz, tri = M.bunny(24)
+    n, world = 1024, 8
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    ref_w, ref_s = _single(engine, fr, xyz, tri)
+    engine._work = None
+    gc.collect(); torch.cuda.empty_cache()
+    nz = n // world
+    m = capi.Multi([0] * world)
+    try:
+        m.set_mesh(xyz, tri)
+        m.voxelize(fr)
+        assert np.array_equal(m.get_grid(), ref_w)
+        m.jfa(mode=MULTI_HYBRID)
+        assert np.array_equal(m.get_sdf().view(np.uint32), ref_s.view(np.uint32))
+        total = 0
+        for r in range(world):
+            lo, hi, nbytes = m.window(r)
+            assert lo <= r * nz and (r + 1) * nz <= hi and hi - lo <= 896, (r, lo, hi)       # 896 of 1024 planes at most (DESIGN.md section 6)
+            assert nbytes == 2 * (hi - lo) * n * n * 4                                        # exactly the window, twice
+            total += nbytes
+        assert total <= 0.875 * world * 2 * n * n * n * 4                                     # against eight pairs of whole volumes
+        m.jfa(mode=MULTI_GHOST)                                                               # the buffers grow to whole volumes and the answer stays
+        assert np.array_equal(m.get_sdf().view(np.uint32), ref_s.view(np.uint32))
+        assert m.window(3)[:2] == (0, n)
+    finally:
+        m.close()
+        gc.collect(); torch.cuda.empty_cache()
 
 
 def test_multi_rejects_bad_splits_and_order(engine):
