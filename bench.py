@@ -433,6 +433,7 @@ def main():
         dom = DOMINANT if DOMINANT in kernels else max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         kd = kernels[dom]
         tj = profile_json("jfa_dense_traffic.json") or {}
+        fl = profile_json("formulation_floor.json") or {}
         traffic = tj.get("hbm_bytes_per_launch") if (n == N_GRID and world == 1) else None
         counters_from = ("profiles/jfa_dense_traffic.json (round %s: separate rocprofv3 --pmc passes on the builder's box, "
                          "NOT this run)" % tj.get("round", "?")) if traffic else None
@@ -460,6 +461,10 @@ def main():
                          "bytes_per_launch": kd["bytes"], "avg_launch_ms": kd["avg_ms"], "launches": int(round(kd["launches_per_step"] * args.steps)),
                          "valu_issue_frac": tj.get("valu_issue_frac") if traffic else None, "valu_issue_source": counters_from,
                          "limiter": LIMITER,
+                         # what ANY exact evaluation of the 27-candidate scatter formulation could reach on this chip (tools/ubench/floor.hip:
+                         # the irreducible instructions and the two streams, nothing else); measured on the builder's box, not in this run
+                         "formulation_floor_frac": (fl.get("n%d" % n) or {}).get("formulation_floor_frac"),
+                         "formulation_floor_source": fl.get("source") if fl.get("n%d" % n) else None,
                          "timing": "hipEvents on the kernel's stream around each of its launches inside the timed region; the other "
                                    "kernels of `kernels` are timed over %d further steps outside it" % TABLE_STEPS,
                          "note": "bytes = 2*S*n^2*planes (SURVEY.md 8(d)); 27 exact candidate evaluations per voxel (DESIGN.md section 4)"},
@@ -496,6 +501,9 @@ def main():
                                      "frac_of_measured": round(kd2.get("GB/s", 0.0) / peak["GB/s"], 4) if peak and kd2.get("GB/s") else None,
                                      "traffic_source": counters_from, "valu_issue_source": counters_from,
                                      "jfa_all_passes_frac": out["n1024"]["jfa_frac_of_peak"], "target_frac": 0.70,
+                                     "formulation_floor_frac": (fl.get("n1024") or {}).get("formulation_floor_frac"),
+                                     "distance_only_floor_frac": (fl.get("n1024") or {}).get("distance_only_floor_frac"),
+                                     "formulation_floor_source": fl.get("source"),
                                      "timing": "hipEvents on the kernel's stream, 3 steps after the timed region of the headline workload"}
         if world == 1 and n == N_GRID and not args.no_config3:
             out["config3"] = run_config3(eng)

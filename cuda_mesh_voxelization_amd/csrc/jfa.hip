@@ -1086,11 +1086,17 @@ __device__ __forceinline__ float from_partner(float v)
 // are (CH = n / k).  With the 4-KB tables (n = 1024) the 8 x 8 tile takes 68 KB of LDS -- more than the 64 KB of older parts, fine on
 // gfx950 (160 KB per CU, two 512-thread workgroups = four waves per SIMD, what the 109 VGPRs allow anyway): k = 128 at n = 1024
 // 2.83 -> 2.66 ms against the planes-only form (4 x 8 tiles, CLOSED = 2) that round 3 first shipped (profiles/r03/ab_clbig_1024.txt).
-template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP, int PM, int CLOSED = 0>
+// FULL (round 4): every tile of the launch has all its RY output rows and CH output planes (n and the slab are multiples of RY k and
+// CH k -- any whole power-of-two grid): the row / plane counts of a tile become compile-time constants and the ~220 workgroup-uniform
+// branches around the stores and gathers of an x iteration (one per output row and plane, `if (a >= yout)`) disappear.
+template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP, int PM, int CLOSED = 0, bool FULL = false>
 #ifndef VP_DENSE_WIDE_WAVES
 #define VP_DENSE_WIDE_WAVES 4
 #endif
-__global__ void __launch_bounds__(NT, dense_wide<ID>() ? (NT == 256 ? VP_DENSE_WIDE_WAVES : 4) : RY > 4 ? 4 : (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (ID::kTab == 512 || NT == 512) ? 6 : 4)
+#ifndef VP_DENSE_FULL_1024
+#define VP_DENSE_FULL_1024 0        // experiment: FULL id passes with the 4-KB tables under a four-wave bound (see launch_dense)
+#endif
+__global__ void __launch_bounds__(NT, dense_wide<ID>() ? (NT == 256 ? VP_DENSE_WIDE_WAVES : 4) : RY > 4 ? 4 : (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (VP_DENSE_FULL_1024 && FULL && ID::kTab == 1024 && !FINAL) ? 4 : (ID::kTab == 512 || NT == 512) ? 6 : 4)
 jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typename ID::T* __restrict__ out,
                const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf,
                uint32_t tilesY, uint32_t tiles, uint32_t splitTiles)
@@ -1148,8 +1154,8 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     // time -0.6 % / -1.8 % (the passes are not traffic-bound).  For every k (mode 1) the map LOSES at k >= 8: 2.3 x instead of 1.6 x --
     // neighbours in z are then a whole plane of tiles apart in time.
     {
-        const uint32_t whole = total - splitTiles;                 // dispatch indices below `whole` are whole tiles, index = tile
-        if ((VP_DENSE_XCD_MAP == 1 || K < 8) && lin < whole && (whole & 7u) == 0u) lin = (lin & 7u) * (whole >> 3) + (lin >> 3);
+        const uint32_t whole8 = (total - splitTiles) & ~7u;        // dispatch indices below total - splitTiles are whole tiles, index = tile
+        if ((VP_DENSE_XCD_MAP == 1 || K < 8) && lin < whole8) lin = (lin & 7u) * (whole8 >> 3) + (lin >> 3);
     }
 #endif
     if (rev) lin = total - 1u - lin;
@@ -1217,10 +1223,13 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     char* outB = reinterpret_cast<char*>(out) + (size_t)N * planeBytes;
     const char* noneB = reinterpret_cast<const char*>(none_row) + (size_t)TAB * 4u;
     int yout = 1, nout = 1;
+    if constexpr (FULL) { yout = RY; nout = CH; }
+    else {
 #pragma unroll
-    for (int j = 1; j < RY; ++j) yout += (ybase + j * K < N) ? 1 : 0;
+        for (int j = 1; j < RY; ++j) yout += (ybase + j * K < N) ? 1 : 0;
 #pragma unroll
-    for (int j = 1; j < CH; ++j) nout += (zbase + j * K < (int)f.z1) ? 1 : 0;
+        for (int j = 1; j < CH; ++j) nout += (zbase + j * K < (int)f.z1) ? 1 : 0;
+    }
     const uint32_t kb = k * IDB;
     // 32-bit ids: ranks and the gather are relative to the first source plane of the tile that lies in the grid (zlo below): at
     // most the whole volume, 4 GiB at n = 1024, so byte offset + 1 <= 2^32 - 3 fits the low word.  8-byte ids: see the header.
@@ -2297,6 +2306,9 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 #ifndef VP_DENSE_K2_PLAIN
 #define VP_DENSE_K2_PLAIN 1
 #endif
+#ifndef VP_DENSE_FULL
+#define VP_DENSE_FULL 1           // compile-time row / plane counts where every tile is whole (see jfa_pass_dense)
+#endif
 #ifndef VP_DENSE_PAIRS_DEFAULT
 #define VP_DENSE_PAIRS_DEFAULT 2  // pair mode (see jfa_pass_dense): 0 off, 1 the fused last pass only, 2 every dense pass too (profiles/r03/ab_pairs_*.txt)
 #endif
@@ -2308,7 +2320,14 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
         const uint32_t ty_ = nresY * ((ylen + RY_ - 1) / RY_), t_ = ty_ * nres * ((zlen + CH - 1) / CH);                           \
         /* a row of <= NT voxels has no halves */                                                                                  \
         const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, dense_wide<ID>() ? (NT == 256 ? 5u : 2u) : ID::kTab == 512 ? (RY_ == 8 ? 4u : (F) && !final_mask_global<ID>() ? 5u : 6u) : NT == 512 ? ((F) && !final_mask_global<ID>() ? 2u : 3u) : 4u) : 0u;                      \
-        hipLaunchKernelGGL((jfa_pass_dense<ID, RY_, CH, NT, F, true, S, PM>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,                \
+        /* FULL tiles: compile-time row / plane counts (only the 8-plane forms of whole chains get the second instantiation) */    \
+        /* (measured, profiles/r04/ab_full_*.txt: dense -3.2 % at n = 512, -5 % at n = 2048, fused last pass -1 / -4 / -3 %; the ID PASSES */ \
+        /* with the 4-KB tables lose 4 %: 80 VGPRs + 8 spilled instead of 71 under the six-wave bound -- those keep the run-time counts)    */ \
+        constexpr bool fullOk_ = CH == 8 && !(S) && (ID::kTab != 1024 || (F) || VP_DENSE_FULL_1024);                               \
+        const bool full_ = VP_DENSE_FULL && fullOk_ && ylen % RY_ == 0 && zlen % CH == 0 && nz % k == 0 && f.n % k == 0;           \
+        if (full_) hipLaunchKernelGGL((jfa_pass_dense<ID, RY_, CH, NT, F, true, S, PM, 0, fullOk_>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k, \
+                           (const T*)d_in, (T*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                               \
+        else hipLaunchKernelGGL((jfa_pass_dense<ID, RY_, CH, NT, F, true, S, PM>), dim3(t_ + sp_), dim3(NT), 0, ctx->stream, f, k,                \
                            (const T*)d_in, (T*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);                               \
     } while (0)
     // pair mode where it applies: 32-bit ids, n a power of two, whole rows of NT-thread iterations; the lane permutation follows k
@@ -2342,7 +2361,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
             constexpr int RYC = VP_DENSE_CLOSED_ROWS ? 8 : 4, CL = VP_DENSE_CLOSED_ROWS ? 3 : 2;
             const uint32_t ty_ = nresY * ((ylen + RYC - 1) / RYC), t_ = ty_ * nres;          // one plane chain per tile
             const uint32_t sp_ = f.n > NTC ? tail_split(ctx, t_, ID::kTab == 512 ? (RYC == 8 ? 4u : 6u) : (RYC == 8 ? 2u : 3u)) : 0u;
-            hipLaunchKernelGGL((jfa_pass_dense<ID, RYC, 8, NTC, false, true, false, 8, CL>), dim3(t_ + sp_), dim3(NTC), 0, ctx->stream, f, k,
+            hipLaunchKernelGGL((jfa_pass_dense<ID, RYC, 8, NTC, false, true, false, 8, CL, (VP_DENSE_FULL != 0 && ID::kTab == 512)>), dim3(t_ + sp_), dim3(NTC), 0, ctx->stream, f, k,
                                (const T*)d_in, (T*)d_out, none_row, d_words, fill, d_sdf, ty_, t_, sp_);
             return 0;
         }

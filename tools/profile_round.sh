@@ -29,3 +29,13 @@ pmc 512 tcp TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_AC
 python3 $R/tools/traffic_json.py $O > $O/jfa_dense_traffic.json 2> $O/traffic_json.err
 rm -rf $O/stats $O/pmc_*/ $O/*.log
 ls $O
+# round 4: the other two sizes, the n = 2048 byte counters, the probes
+python3 $R/bench.py --grid-n 1024 --no-cpu-baseline > $O/bench_n1024.json 2> $O/bench_n1024.err
+python3 $R/bench.py --grid-n 2048 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_n2048.json 2> $O/bench_n2048.err
+pmc 2048 fetch FETCH_SIZE
+pmc 2048 write WRITE_SIZE
+pmc 2048 sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY
+pmc 2048 sq2 GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+[ -x $R/tools/exp/floor ] && { $R/tools/exp/floor 1024 > $O/floor_n1024.txt 2>&1; $R/tools/exp/floor 512 > $O/floor_n512.txt 2>&1; }
+rm -rf $O/pmc_*/ $O/*.log
+ls $O
