@@ -18,6 +18,7 @@ LIB = os.path.join(PKG, "libvphip.so")
 CLI = os.path.join(PKG, "vpcli")
 
 HIP_SOURCES = ["capi.hip", "vox.hip", "csg.hip", "jfa.hip", "extract.hip", "multi.hip"]
+JFA_PARTS = 5                    # jfa.hip is compiled as parts 0 .. 4 side by side (-DVP_JFA_PART=i, see the top of the file)
 # -ffp-contract=off is part of the parity contract: an FMA changes the bitmask / sdf bits.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
              "-Wall", "-Wno-unused-function"]
@@ -46,12 +47,21 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         objdir = os.path.join(PKG, "build")
         os.makedirs(objdir, exist_ok=True)
         flags = [f for f in HIP_FLAGS if f != "-shared"]
-        objs = [os.path.join(objdir, os.path.basename(s_) + ".o") for s_ in srcs]
-        cmds = [[_hipcc()] + flags + ["-c", s_, "-o", o] for s_, o in zip(srcs, objs)]
+        objs, cmds = [], []
+        for s_ in srcs:
+            if os.path.basename(s_) == "jfa.hip":               # the longest first: five parts of the tile-kernel instantiations
+                for part in range(JFA_PARTS):
+                    o = os.path.join(objdir, "jfa.hip.part%d.o" % part)
+                    objs.append(o)
+                    cmds.insert(part, [_hipcc()] + flags + ["-DVP_JFA_PART=%d" % part, "-c", s_, "-o", o])
+            else:
+                o = os.path.join(objdir, os.path.basename(s_) + ".o")
+                objs.append(o)
+                cmds.append([_hipcc()] + flags + ["-c", s_, "-o", o])
         if verbose:
             for c in cmds:
                 print(" ".join(c))
-        with ThreadPoolExecutor(max_workers=min(4, len(cmds))) as ex:
+        with ThreadPoolExecutor(max_workers=min(max(2, (os.cpu_count() or 4) - 1), len(cmds))) as ex:
             list(ex.map(subprocess.check_call, cmds))
         link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
         if verbose:

@@ -31,6 +31,17 @@
 
 #pragma clang fp contract(off)
 
+// Build parts.  The tile kernel is instantiated for four id formats x pair modes x tile shapes: one translation unit took nine minutes
+// of a single core.  The build compiles this file five times side by side (cuda_mesh_voxelization_amd/build.py, tools/exp_build.sh):
+// part 0 holds every launcher and kernel EXCEPT the instantiations of launch_dense<ID>, parts 1 .. 4 hold one launch_dense_<format>()
+// each; the kernels live in an anonymous namespace, so every part gets its own copies of what it uses and nothing else.
+// VP_JFA_PART undefined (-1): everything in one unit.
+#ifndef VP_JFA_PART
+#define VP_JFA_PART -1
+#endif
+#define VP_PART_MAIN (VP_JFA_PART <= 0)
+#define VP_PART_HAS(p) (VP_JFA_PART < 0 || VP_JFA_PART == (p))
+
 namespace vp {
 
 namespace {
@@ -2029,7 +2040,9 @@ inline bool wide(const Frame& f) { return f.n > 1024; }           // 64-bit ids
 
 }  // namespace
 
+#if VP_PART_MAIN
 size_t jfa_id_bytes(const Frame& f) { return wide(f) ? 8 : 4; }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 static int env_int(const char* name, int dflt)
@@ -2038,6 +2051,7 @@ static int env_int(const char* name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
+#if VP_PART_MAIN
 int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* below,
                     const uint32_t* above, void* d_ids, uint32_t* d_border_words)
 {
@@ -2138,6 +2152,7 @@ bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo)
     (void)k;
     return algo == VP_ALGO_TILED && f.n >= 256;
 }
+#endif  // VP_PART_MAIN
 
 // One row of "none" per id format for out-of-grid reads: 2048 x 8 bytes of the 64-bit "none", then 1024 x 4 of each 32-bit one, then
 // the compact format's word row (2048 x 4) with its byte row (2048 x 1) right behind it.
@@ -2378,6 +2393,29 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     return 0;
 }
 
+// launch_dense<ID> per id format, one build part each (see VP_JFA_PART)
+int launch_dense_id9(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf);
+int launch_dense_id10(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf);
+int launch_dense_idc(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf);
+int launch_dense_id64(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf);
+#if VP_PART_HAS(1)
+int launch_dense_id9(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
+{ return launch_dense<Id9>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf); }
+#endif
+#if VP_PART_HAS(2)
+int launch_dense_id10(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
+{ return launch_dense<Id10>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf); }
+#endif
+#if VP_PART_HAS(3)
+int launch_dense_idc(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
+{ return launch_dense<IdC>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf); }
+#endif
+#if VP_PART_HAS(4)
+int launch_dense_id64(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, void* d_out, const uint32_t* d_words, float fill, float* d_sdf)
+{ return launch_dense<Id64>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf); }
+#endif
+
+#if VP_PART_MAIN
 // d_sdf != nullptr: this is the last pass and it writes the sdf directly (only where
 // jfa_pass_can_fuse_final() says so); otherwise ids go to d_out.
 int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, const void* d_minus,
@@ -2411,10 +2449,10 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
         else if (f.n <= 512) hipLaunchKernelGGL((jfa_pass_seeds<Id9, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
         else                 hipLaunchKernelGGL((jfa_pass_seeds<Id10, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
     } else if (f.n >= 256 && dense_applies(f, k, d_in, d_minus, d_plus, d_sdf != nullptr)) {
-        if (f.compact)       VP_TRY(launch_dense<IdC>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
-        else if (wide(f))    VP_TRY(launch_dense<Id64>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
-        else if (f.n <= 512) VP_TRY(launch_dense<Id9>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
-        else                 VP_TRY(launch_dense<Id10>(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        if (f.compact)       VP_TRY(launch_dense_idc(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        else if (wide(f))    VP_TRY(launch_dense_id64(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        else if (f.n <= 512) VP_TRY(launch_dense_id9(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
+        else                 VP_TRY(launch_dense_id10(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
     } else if (f.n >= 256) {
         if (wide(f)) VP_TRY(launch_chain<Id64>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
         else if (f.n <= 512) VP_TRY(launch_chain<Id9>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
@@ -2458,6 +2496,8 @@ extern "C" int vp_dev_first_two_times(unsigned long long* out16, int reset)
     return 0;
 }
 #endif
+
+#endif  // VP_PART_MAIN
 
 }  // namespace vp
 #endif  // VP_ISA_PROBE
