@@ -25,6 +25,7 @@ SYMBOLS = [
     "vp_grid_words", "vp_grid_voxels",
     "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa_state_bytes", "vp_jfa", "vp_jfa_start", "vp_jfa_run", "vp_jfa_init", "vp_jfa_pass",
     "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass", "vp_jfa_can_fuse_first_two", "vp_jfa_first_two",
+    "vp_jfa_volume_bytes", "vp_jfa_volume_first_two", "vp_jfa_volume_pass", "vp_jfa_volume_last_pass",
     "vp_surface", "vp_extract_count", "vp_extract", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_select", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
     "vp_multi_create", "vp_multi_destroy", "vp_multi_count", "vp_multi_ctx", "vp_multi_sync", "vp_multi_set_mesh", "vp_multi_voxelize",
@@ -127,6 +128,10 @@ def lib():
         "vp_jfa_first_pass": (ctypes.c_int, [_vp, fp, _vp, _vp]),
         "vp_jfa_can_fuse_first_two": (ctypes.c_int, [fp, ctypes.c_int]),
         "vp_jfa_first_two": (ctypes.c_int, [_vp, fp, _vp, _vp]),
+        "vp_jfa_volume_bytes": (_sz, [fp]),
+        "vp_jfa_volume_first_two": (ctypes.c_int, [_vp, fp, _vp, _vp]),
+        "vp_jfa_volume_pass": (ctypes.c_int, [_vp, fp, ctypes.c_uint32, _vp, _vp]),
+        "vp_jfa_volume_last_pass": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, ctypes.c_float, _vp]),
         "vp_surface": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
         "vp_extract_count": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
         "vp_extract": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_int, _vp, _vp, _vp, _sz]),
@@ -284,6 +289,19 @@ class Context:
 
     def jfa_first_pass(self, frame: Frame, d_border_grid: int, d_out: int):
         check(lib().vp_jfa_first_pass(self._h, ctypes.byref(frame), _vp(d_border_grid), _vp(d_out)))
+
+    # -- whole-volume passes (ghost-plane pipelines): volume base + region frame, layout chosen by the library
+    def jfa_volume_bytes(self, frame: Frame) -> int:
+        return int(lib().vp_jfa_volume_bytes(ctypes.byref(frame)))
+
+    def jfa_volume_first_two(self, frame: Frame, d_border_grid: int, d_vol: int):
+        check(lib().vp_jfa_volume_first_two(self._h, ctypes.byref(frame), _vp(d_border_grid), _vp(d_vol)))
+
+    def jfa_volume_pass(self, region: Frame, k: int, d_vol_in: int, d_vol_out: int):
+        check(lib().vp_jfa_volume_pass(self._h, ctypes.byref(region), k, _vp(d_vol_in), _vp(d_vol_out)))
+
+    def jfa_volume_last_pass(self, region: Frame, d_vol_in: int, d_vol_scratch: int, d_words_region: int, fill: float, d_sdf_region: int):
+        check(lib().vp_jfa_volume_last_pass(self._h, ctypes.byref(region), _vp(d_vol_in), _vp(d_vol_scratch), _vp(d_words_region), fill, _vp(d_sdf_region)))
 
     def surface(self, frame: Frame, d_words: int, d_below, d_above, d_border: int):
         check(lib().vp_surface(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_below or None),

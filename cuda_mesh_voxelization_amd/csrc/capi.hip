@@ -3,6 +3,7 @@
 // the host-in/host-out conveniences that reproduce the reference's Compute() calling convention.
 #include "vp_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -500,6 +501,71 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
         return launch_jfa_pass_ex(ctx, fr, 1, d_in, d_minus, d_plus, d_scratch, algo, d_words, fill_unset, d_sdf);
     VP_TRY(launch_jfa_pass(ctx, fr, 1, d_in, d_minus, d_plus, d_scratch, algo));
     return launch_jfa_final(ctx, fr, d_words, d_scratch, fill_unset, d_sdf);
+}
+
+// ---- whole-volume form of the slab passes (ghost-plane pipelines) -------------------------------
+// The caller holds id volumes of the WHOLE grid and asks for a region of planes per pass; the layout inside a volume is the library's:
+// plain 4-byte ids up to n = 1024, the compact word plane + byte plane above (5 instead of 8 bytes per voxel, jfa.hip: IdC).
+static bool volume_compact(const Frame& whole) { return jfa_compact_applies(whole, VP_ALGO_TILED); }
+
+size_t vp_jfa_volume_bytes(const vp_frame* f)
+{
+    if (!f || check_frame(f, "vp_jfa_volume_bytes", false) != 0) return 0;
+    vp_frame w = *f; w.z0 = 0; w.z1 = f->n;
+    const Frame fr = make_frame(&w);
+    const size_t vox = (size_t)f->n * f->n * f->n;
+    return vox * (volume_compact(fr) ? 5 : jfa_id_bytes(fr));
+}
+
+static int volume_check(vp_ctx* ctx, const vp_frame* f, const char* who, Frame& region, Frame& whole, size_t& planeBytes)
+{
+    if (!ctx) return set_error(VP_ERR_INVALID, "%s: null ctx", who);
+    VP_TRY(bind_device(ctx));
+    VP_TRY(check_frame(f, who, false));
+    vp_frame w = *f; w.z0 = 0; w.z1 = f->n;
+    whole = make_frame(&w);
+    region = make_frame(f);
+    if (!jfa_can_fuse_first_two(whole, VP_ALGO_TILED))
+        return set_error(VP_ERR_UNSUPPORTED, "%s: the volume calls need n >= 256 and n %% 128 == 0 (VP_ALGO_TILED)", who);
+    region.compact = whole.compact = volume_compact(whole) ? 1u : 0u;
+    planeBytes = (size_t)f->n * f->n * (region.compact ? 4 : jfa_id_bytes(whole));   // of the (word) plane the passes address
+    return 0;
+}
+
+int vp_jfa_volume_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_vol)
+{
+    if (!d_border_grid || !d_vol) return set_error(VP_ERR_INVALID, "vp_jfa_volume_first_two: null argument");
+    Frame region, whole; size_t pb;
+    VP_TRY(volume_check(ctx, f, "vp_jfa_volume_first_two", region, whole, pb));
+    if (f->z0 != 0 || f->z1 != f->n) return set_error(VP_ERR_INVALID, "vp_jfa_volume_first_two: whole-grid frame required");
+    return launch_jfa_first_two(ctx, whole, d_border_grid, d_vol);
+}
+
+int vp_jfa_volume_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const void* d_vol_in, void* d_vol_out)
+{
+    if (!d_vol_in || !d_vol_out || d_vol_in == d_vol_out) return set_error(VP_ERR_INVALID, "vp_jfa_volume_pass: bad buffers");
+    Frame region, whole; size_t pb;
+    VP_TRY(volume_check(ctx, f, "vp_jfa_volume_pass", region, whole, pb));
+    if (k == 0 || k * 8 > f->n) return set_error(VP_ERR_INVALID, "vp_jfa_volume_pass: step %u (the volume passes start at n/8, after vp_jfa_volume_first_two)", k);
+    const char* in = (const char*)d_vol_in + (size_t)f->z0 * pb;
+    // halo pointers as vp_jfa_pass wants them (indexed from the unclipped start): the volume is contiguous, so they are plain offsets
+    const char* mi = f->z0 == 0 ? nullptr : reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(d_vol_in) + (uintptr_t)(((ptrdiff_t)f->z0 - (ptrdiff_t)k) * (ptrdiff_t)pb));
+    const char* pl = f->z1 >= f->n ? nullptr : (const char*)d_vol_in + (size_t)std::max(f->z1, f->z0 + k) * pb;
+    return launch_jfa_pass(ctx, region, k, in, mi, pl, (char*)d_vol_out + (size_t)f->z0 * pb, VP_ALGO_TILED);
+}
+
+int vp_jfa_volume_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_vol_in, void* d_vol_scratch, const uint32_t* d_words_region,
+                            float fill_unset, float* d_sdf_region)
+{
+    if (!d_vol_in || !d_vol_scratch || !d_words_region || !d_sdf_region || d_vol_in == d_vol_scratch)
+        return set_error(VP_ERR_INVALID, "vp_jfa_volume_last_pass: bad buffers");
+    Frame region, whole; size_t pb;
+    VP_TRY(volume_check(ctx, f, "vp_jfa_volume_last_pass", region, whole, pb));
+    VP_TRY(check_fill(fill_unset, "vp_jfa_volume_last_pass"));
+    const char* in = (const char*)d_vol_in + (size_t)f->z0 * pb;
+    const char* mi = f->z0 == 0 ? nullptr : reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(d_vol_in) + (uintptr_t)(((ptrdiff_t)f->z0 - 1) * (ptrdiff_t)pb));
+    const char* pl = f->z1 >= f->n ? nullptr : (const char*)d_vol_in + (size_t)std::max(f->z1, f->z0 + 1) * pb;
+    return launch_jfa_pass_ex(ctx, region, 1, in, mi, pl, (char*)d_vol_scratch + (size_t)f->z0 * pb, VP_ALGO_TILED, d_words_region, fill_unset, d_sdf_region);
 }
 
 // ---- export front end -------------------------------------------------------------------------

@@ -1229,9 +1229,11 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     const char* tz = reinterpret_cast<const char*>(TZ);
     const uint32_t rowBytes = (uint32_t)N * IDB;
     const size_t planeBytes = (size_t)N * rowBytes;
-    // compact ids: byte planes of the source and the output volume (whole grids: n^3 words, then n^3 bytes) and the byte row of "none"
-    const char* inB = reinterpret_cast<const char*>(in) + (size_t)N * planeBytes;
-    char* outB = reinterpret_cast<char*>(out) + (size_t)N * planeBytes;
+    // compact ids: byte planes of the source and the output volume and the byte row of "none".  `in` / `out` point at plane z0 of WHOLE
+    // volumes (n^3 words, then n^3 bytes): byte plane z0 sits (n - z0) word planes + z0 byte planes further on.
+    const size_t toBytes = (size_t)(N - (int)f.z0) * planeBytes + (size_t)f.z0 * ((size_t)N * N);
+    const char* inB = reinterpret_cast<const char*>(in) + toBytes;
+    char* outB = reinterpret_cast<char*>(out) + toBytes;
     const char* noneB = reinterpret_cast<const char*>(none_row) + (size_t)TAB * 4u;
     int yout = 1, nout = 1;
     if constexpr (FULL) { yout = RY; nout = CH; }

@@ -272,10 +272,23 @@ int jfa_ghost(vp_multi* m, float fill, int algo)
     const uint32_t n = G.n, world = (uint32_t)m->ranks.size(), nz = n / world;
     const size_t S = vp_jfa_id_bytes(&G), planeIds = (size_t)n * n * S, planeWords = (size_t)n * n / 8;
     const size_t slabWords = (size_t)nz * planeWords;
+    // Whole-volume calls (round 4; vp_jfa_volume_*) where the first two passes run as the one whole-grid launch anyway -- every rank of
+    // 2 .. 8 slabs -- and always above n = 1024, where the library then keeps the volumes in its compact 5-byte layout (2 x 40 instead of
+    // 2 x 64 GiB per device at n = 2048).  VP_GHOST_VOLUME=0 (dev / tests) keeps the caller-addressed planes.
+    const char* pctEnv = getenv("VP_FUSED_FIRST_TWO_PCT");
+    const uint64_t fuseThreshold = pctEnv ? strtoull(pctEnv, nullptr, 10) : 35ull;
+    const char* volEnv = getenv("VP_GHOST_VOLUME");
+    bool volume = algo == VP_ALGO_TILED && !(volEnv && volEnv[0] == '0') && n >= 16 && vp_jfa_can_fuse_first_two(&G, algo) != 0;
+    if (volume && n <= 1024)
+        for (Rank& r : m->ranks) {
+            const std::vector<Region> regs = ghost_regions(n, r.z0, r.z1);
+            if ((uint64_t)(regs[1].b1 - regs[1].b0) * 100 < fuseThreshold * n) volume = false;
+        }
+    const size_t volBytes = volume ? vp_jfa_volume_bytes(&G) : (size_t)n * planeIds;
     // all-gather of the bitmask slabs: every device ends up with the whole grid (its own slab stays where it is: plane z0)
     for (Rank& r : m->ranks) {
         VP_TRY(grow(r, r.border, (size_t)n * planeWords));
-        for (Buffer& b : r.ids) VP_TRY(grow_ids(r, b, (size_t)n * planeIds));
+        for (Buffer& b : r.ids) VP_TRY(grow_ids(r, b, volBytes));
         VP_TRY(grow(r, r.sdf, (size_t)nz * n * n * 4));
     }
     // words buffers of the ghost mode hold the whole grid with the rank's own slab at its global position (see vp_multi_set_grid /
@@ -293,6 +306,18 @@ int jfa_ghost(vp_multi* m, float fill, int algo)
         char* a = (char*)me.ids[0].ptr;
         char* b = (char*)me.ids[1].ptr;
         const uint32_t* words = (const uint32_t*)me.words.ptr;
+        if (volume) {
+            VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
+            VP_TRY(vp_jfa_volume_first_two(me.ctx, &G, (const uint32_t*)me.border.ptr, a));
+            for (size_t i = 2; i < regs.size(); ++i) {
+                const Region& g = regs[i];
+                const vp_frame f = slab_frame(G, g.b0, g.b1);
+                if (i == last) { VP_TRY(vp_jfa_volume_last_pass(me.ctx, &f, a, b, words + (size_t)g.b0 * (planeWords / 4), fill, (float*)me.sdf.ptr)); break; }
+                VP_TRY(vp_jfa_volume_pass(me.ctx, &f, g.k, a, b));
+                std::swap(a, b);
+            }
+            continue;
+        }
         const bool maskStart = last > 0 && vp_jfa_can_start_from_mask(&G, algo);
         if (maskStart) VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
         else           VP_TRY(vp_jfa_init(me.ctx, &G, words, nullptr, nullptr, a));
@@ -300,8 +325,7 @@ int jfa_ghost(vp_multi* m, float fill, int algo)
         // the first two passes as ONE whole-grid launch where the second pass covers at least 35 % of the grid: break-even of the
         // measured kernel times (jfa_first_two 0.30 / 2.13 ms against first pass + fraction x second pass), as in slab.py:
         // fused_first_two_threshold(); every rank of 2 .. 8 slabs is above it
-        const char* pct = getenv("VP_FUSED_FIRST_TWO_PCT");       // dev / tests: 101 forces the two region passes
-        const uint64_t threshold = pct ? strtoull(pct, nullptr, 10) : 35ull;
+        const uint64_t threshold = fuseThreshold;                 // VP_FUSED_FIRST_TWO_PCT (dev / tests): 101 forces the two region passes
         if (maskStart && last >= 2 && vp_jfa_can_fuse_first_two(&G, algo) && (uint64_t)(regs[1].b1 - regs[1].b0) * 100 >= threshold * n) {
             VP_TRY(vp_jfa_first_two(me.ctx, &G, (const uint32_t*)me.border.ptr, b));
             std::swap(a, b);

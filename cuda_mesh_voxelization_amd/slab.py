@@ -128,6 +128,20 @@ class HipSlabBackend:
         src, minus, plus, scratch = self._global_ptrs(region, 1, src_full, scratch_full)
         self.ctx.jfa_last_pass(region, src, minus, plus, scratch, words_region.data_ptr(), fill, sdf.data_ptr(), algo)
 
+    # -- whole-volume calls (vp_jfa_volume_*): volume base + region frame, the library picks the layout (compact above n = 1024)
+    def volume_words(self, frame):
+        """uint32 words of one id volume of the whole grid in the library's layout"""
+        return (self.ctx.jfa_volume_bytes(frame) + 3) // 4
+
+    def jfa_volume_first_two(self, frame, border_full, vol):
+        self.ctx.jfa_volume_first_two(frame, border_full.data_ptr(), vol.data_ptr())
+
+    def jfa_volume_pass(self, region, k, vol_in, vol_out):
+        self.ctx.jfa_volume_pass(region, k, vol_in.data_ptr(), vol_out.data_ptr())
+
+    def jfa_volume_last_pass(self, region, vol_in, vol_scratch, words_region, fill, sdf):
+        self.ctx.jfa_volume_last_pass(region, vol_in.data_ptr(), vol_scratch.data_ptr(), words_region.data_ptr(), fill, sdf.data_ptr())
+
 
 class HostStagedDist:
     """Test rigs only (bench.py with VP_BENCH_SHARE_GPU=1: ranks share a GPU and rendezvous over gloo, whose send / recv take CPU
@@ -395,7 +409,15 @@ class GhostSlabPipeline:
         self.regions = ghost_regions(frame.n, rank, world)
         self.words = self.be.empty_u32(frame.words)                 # whole grid
         idw = self.be.id_words(frame) if hasattr(self.be, "id_words") else 1
-        self.ids = [(self.be.ids_u32(frame.voxels * idw) if hasattr(self.be, "ids_u32") else self.be.empty_u32(frame.voxels * idw)) for _ in range(2)]
+        # Whole-volume calls (round 4) where the first two passes are fused over the whole grid anyway -- always above n = 1024, where the
+        # library then keeps the volumes in its compact 5-byte layout: 2 x 40 instead of 2 x 64 GiB at n = 2048 and 10 instead of 16 bytes
+        # per voxel and pass.  VP_GHOST_VOLUME=0 (dev / tests) keeps the caller-addressed 8-byte planes.
+        import os
+        self.volume_mode = (hasattr(self.be, "jfa_volume_pass") and os.environ.get("VP_GHOST_VOLUME", "1") != "0" and len(self.regions) > 3
+                            and self.be.can_fuse_first_two(frame, ALGO_TILED)
+                            and (frame.n > 1024 or (self.regions[1][2] - self.regions[1][1]) * 100 >= fused_first_two_threshold(frame.n) * frame.n))
+        vol_words = self.be.volume_words(frame) if self.volume_mode else frame.voxels * idw
+        self.ids = [(self.be.ids_u32(vol_words) if hasattr(self.be, "ids_u32") else self.be.empty_u32(vol_words)) for _ in range(2)]
         self.sdf = self.be.empty_f32(self.frame.voxels)             # own slab only
         self.planes_computed = sum(b1 - b0 for _, b0, b1 in self.regions)
         self.border = None
@@ -409,6 +431,7 @@ class GhostSlabPipeline:
                 "plane_passes_this_rank": int(self.planes_computed), "plane_passes_one_gpu": n * passes,
                 "plane_pass_ratio": round(n * passes / self.planes_computed, 3), "bytes_exchanged": 0, "bytes_received_total": 0,
                 "first_two_passes_fused_over_whole_grid": bool(getattr(self, "fused_first_two", False)),
+                "volume_calls": bool(self.volume_mode), "id_volume_bytes": int(self.ids[0].numel() * 4),
                 "hbm_bytes_this_rank": hbm_bytes(self)}
 
     def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
@@ -420,8 +443,35 @@ class GhostSlabPipeline:
         self.be.csg(self.words, other, op)
         return self.words
 
+    def _jfa_volume(self, fill, out):
+        """the whole-volume sequence: border mask, passes n/2 + n/4 over the whole grid in one launch, every later pass on its region"""
+        a, b = self.ids
+        G = self.global_frame
+        if self.border is None:
+            self.border = self.be.empty_u32(G.words)
+        self.be.surface(G, self.words, self.border)
+        self.be.jfa_volume_first_two(G, self.border, a)
+        self.fused_first_two = True
+        pw = G.n * G.n // 32
+        last = len(self.regions) - 1
+        for i, (k, b0, b1) in enumerate(self.regions):
+            if i < 2:
+                continue
+            region = G.slab(b0, b1)
+            if i == last:
+                self.be.jfa_volume_last_pass(region, a, b, self.words[b0 * pw:b1 * pw], fill, out)
+                return out
+            self.be.jfa_volume_pass(region, k, a, b)
+            a, b = b, a
+        return out
+
     def jfa(self, algo=ALGO_TILED, fill=-math.inf, out=None):
         out = self.sdf if out is None else out
+        if self.volume_mode and algo == ALGO_TILED:
+            return self._jfa_volume(fill, out)
+        need = self.global_frame.voxels * (self.be.id_words(self.global_frame) if hasattr(self.be, "id_words") else 1)
+        if self.ids[0].numel() < need:                            # the volumes were sized for the library's layout: caller-addressed ids need more
+            self.ids = [(self.be.ids_u32(need) if hasattr(self.be, "ids_u32") else self.be.empty_u32(need)) for _ in range(2)]
         a, b = self.ids
         last = len(self.regions) - 1
         mask_start = last > 0 and hasattr(self.be, "can_start_from_mask") and self.be.can_start_from_mask(self.global_frame, algo)

@@ -189,6 +189,21 @@ int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_g
 int vp_jfa_can_fuse_first_two(const vp_frame* f, int algo);
 int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out);
 
+/* Whole-volume form of the slab passes, for ghost-plane pipelines (every rank holds id volumes of the WHOLE grid and recomputes the
+ * planes its later passes reach: no exchange between passes).  The caller no longer offsets pointers by plane -- it passes the volume
+ * base and a frame whose [z0, z1) is the region to produce -- so the layout inside a volume is the library's: vp_jfa_volume_bytes(f)
+ * per volume, plain 4-byte ids up to n = 1024 and the compact 5-byte state above (a 32-bit word plane + a byte plane; 40 instead of
+ * 64 GiB per volume at n = 2048, and 10 instead of 16 bytes per voxel and pass).  Needs n >= 256, n % 128 == 0 (VP_ALGO_TILED).
+ *   vp_jfa_volume_first_two  passes n/2 and n/4 of the whole grid from its border mask (vp_surface on a whole-grid frame)
+ *   vp_jfa_volume_pass       one pass with step k <= n/8 over the planes [z0, z1) of f; reads the planes z0-k .. z1+k of d_vol_in
+ *   vp_jfa_volume_last_pass  step 1 fused with the id -> sdf conversion; d_words_region / d_sdf_region hold the planes [z0, z1) only
+ * Same results as the slab calls on 8-byte ids, bit for bit. */
+size_t vp_jfa_volume_bytes(const vp_frame* f);
+int vp_jfa_volume_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_vol);
+int vp_jfa_volume_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const void* d_vol_in, void* d_vol_out);
+int vp_jfa_volume_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_vol_in, void* d_vol_scratch, const uint32_t* d_words_region,
+                            float fill_unset, float* d_sdf_region);
+
 /* "Surface" output (README.md:9): the border-voxel mask that JFA seeds
  * from (jfa/sequential.cpp:24-64), as a bitmask with the grid's layout. */
 int vp_surface(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words,

@@ -139,6 +139,39 @@ def test_ghost_slabs_equal_whole_grid(engine, world, n, name, fused_pct, monkeyp
     assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
 
 
+@pytest.mark.parametrize("world,n,volume", [(4, 1152, "1"), (4, 1152, "0"), (8, 512, "1"), (8, 512, "0"), (2, 1280, "1")])
+def test_ghost_volume_calls_equal_whole_grid(engine, world, n, volume, monkeypatch):
+    """vp_jfa_volume_* (round 4): the ghost pipeline hands the library whole id volumes + a region frame instead of plane pointers it
+    offsets itself, so the library picks the layout -- plain 4-byte ids up to n = 1024, the compact word plane + byte plane above (here
+    n = 1152 / 1280: regions that are not multiples of 8 k planes, chains of 9 / 10, 4-plane and 8-plane tiles with halo planes taken from
+    the middle of a compact volume).  Every rank's slab must equal the whole-grid run, with the volume calls (default) and with the
+    caller-addressed 8-byte planes (VP_GHOST_VOLUME=0); the volumes are 5 / 8 of the size above n = 1024."""
+    import gc
+    from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
+    monkeypatch.setenv("VP_GHOST_VOLUME", volume)
+    gc.collect(); torch.cuda.empty_cache()
+    xyz, tri = M.import_mesh(M.asset("bimba.obj"))
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    ref_w = engine.voxelize(fr, dx, dt)
+    ref_s = engine.jfa(fr, ref_w)
+    nzv = fr.voxels // world
+    for r in range(world):
+        pipe = GhostSlabPipeline(HipSlabBackend(engine), fr, r, world)
+        rep = pipe.report()
+        assert rep["volume_calls"] == (volume == "1")
+        assert rep["id_volume_bytes"] == fr.voxels * ((5 if n > 1024 else 4) if volume == "1" else (8 if n > 1024 else 4))
+        pipe.voxelize(dx, dt)
+        s = pipe.jfa()
+        assert torch.equal(s.view(torch.int32), ref_s[r * nzv:(r + 1) * nzv].view(torch.int32)), (r, volume)
+        del pipe, s
+        gc.collect(); torch.cuda.empty_cache()
+    del ref_s, ref_w
+    engine._work = None
+    gc.collect(); torch.cuda.empty_cache()
+
+
 def test_config4_n1024_four_slabs(engine):
     """BASELINE config 4 at its stated shape: 1,348,128 faces, n = 1024, four Z-slabs -- all three multi-GPU pipelines (RCCL-style
     halo exchange through the loopback; ghost planes without exchange; the hybrid of the two), four emulated ranks on one GPU
