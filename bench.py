@@ -382,6 +382,8 @@ def main():
 
         elapsed, live, table, pipe_report, got = run_pipeline(args.multi, args.steps, args.warmup)
         pipe_desc = pipe_report.pop("describe")
+        if pipe_report.get("volume_calls"):                # ghost planes on whole volumes in the library's layout: 5 bytes per voxel above n = 1024
+            S = pipe_report["id_volume_bytes"] // frame.voxels
         planes = n // world
         regs = pipe_report.pop("regions")
         if regs:                                           # ghost planes: a dense pass covers the slab widened by the later steps

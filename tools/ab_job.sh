@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: interleaved A/B of the whole step per kernel for a list of experimental libraries, n = 512 and 1024 (+ optional n = 2048 bench)
-#   tools/r04_ab.sh OUTNAME name1,name2,... [2048]
+#   tools/ab_job.sh OUTNAME name1,name2,... [2048]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 O=$R/gpurun_out/$1; mkdir -p $O
