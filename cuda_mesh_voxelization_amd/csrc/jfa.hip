@@ -1069,6 +1069,11 @@ template <class ID> constexpr bool dense_wide() { return std::is_same<ID, Id64>:
                                     // the next pass; reads -15 % / -17 % (n = 512 / 1024: fewer source lines evicted), dense passes -1.1 % / -2.2 %,
                                     // sc1 forms: the same bytes, -0.4 % / -0.8 % (profiles/r04/ab_store_*.txt, pmc_bytes_store_policy_and_gather.txt)
 #endif
+#ifndef VP_DENSE_GATHER_NT
+#define VP_DENSE_GATHER_NT 0        // winner gather with the nt policy (a line fetched for one dword should not displace halo rows): measured
+                                    // +15 % / +8 % on the dense passes (n = 512 / 1024, profiles/r04/ab_gnt_ry8_*.txt): nt loads bypass the L1, where
+                                    // the gathers of neighbouring lanes and rows do hit
+#endif
 #ifndef VP_DENSE_XCD_MAP
 #define VP_DENSE_XCD_MAP 2          // 0: dispatch order; 1: XCD-contiguous tile ranges for every k; 2: only for k < 8 (see the kernel)
 #endif
@@ -1105,7 +1110,7 @@ template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP, in
 #define VP_DENSE_WIDE_WAVES 4
 #endif
 #ifndef VP_DENSE_FULL_1024
-#define VP_DENSE_FULL_1024 0        // experiment: FULL id passes with the 4-KB tables under a four-wave bound (see launch_dense)
+#define VP_DENSE_FULL_1024 0        // FULL id passes with the 4-KB tables under a four-wave bound (see launch_dense): -0.3 %, not adopted
 #endif
 __global__ void __launch_bounds__(NT, dense_wide<ID>() ? (NT == 256 ? VP_DENSE_WIDE_WAVES : 4) : RY > 4 ? 4 : (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (VP_DENSE_FULL_1024 && FULL && ID::kTab == 1024 && !FINAL) ? 4 : (ID::kTab == 512 || NT == 512) ? 6 : 4)
 jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typename ID::T* __restrict__ out,
@@ -1584,7 +1589,11 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
 #elif defined(VP_ABL_HOT)
                             pend[a] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(in) + (off & (rowBytes - 1u) & ~3u));
 #else
+#if VP_DENSE_GATHER_NT
+                            pend[a] = __builtin_nontemporal_load(reinterpret_cast<const T*>(gbase + off));
+#else
                             pend[a] = *reinterpret_cast<const T*>(gbase + off);
+#endif
 #endif
                         }
                     }
@@ -2323,6 +2332,10 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
 #ifndef VP_DENSE_K2_PLAIN
 #define VP_DENSE_K2_PLAIN 1
 #endif
+#ifndef VP_DENSE_RY8_1024
+#define VP_DENSE_RY8_1024 0       // 8-row tiles for the id passes with the 4-KB tables (68 KB of LDS, four waves per SIMD, with FULL): +-0 (21.72 vs
+                                  // 21.74 ms over the seven dense passes at n = 1024, profiles/r04/ab_gnt_ry8_1024.txt)
+#endif
 #ifndef VP_DENSE_FULL
 #define VP_DENSE_FULL 1           // compile-time row / plane counts where every tile is whole (see jfa_pass_dense)
 #endif
@@ -2333,7 +2346,7 @@ static int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_i
     const bool pow2 = (f.n & (f.n - 1)) == 0;
 #define VP_LAUNCH_DENSE_PM(CH, NT, F, S, PM)                                                                                       \
     do {                                                                                                                           \
-        constexpr int RY_ = (ID::kTab == 512 && !(F) && !(S) && CH == 8) ? VP_DENSE_RY_SMALL : VP_DENSE_RY;                         \
+        constexpr int RY_ = (ID::kTab == 512 && !(F) && !(S) && CH == 8) ? VP_DENSE_RY_SMALL : (VP_DENSE_RY8_1024 && ID::kTab == 1024 && !(F) && !(S) && CH == 8) ? 8 : VP_DENSE_RY;  \
         const uint32_t ty_ = nresY * ((ylen + RY_ - 1) / RY_), t_ = ty_ * nres * ((zlen + CH - 1) / CH);                           \
         /* a row of <= NT voxels has no halves */                                                                                  \
         const uint32_t sp_ = f.n > NT ? tail_split(ctx, t_, dense_wide<ID>() ? (NT == 256 ? 5u : 2u) : ID::kTab == 512 ? (RY_ == 8 ? 4u : (F) && !final_mask_global<ID>() ? 5u : 6u) : NT == 512 ? ((F) && !final_mask_global<ID>() ? 2u : 3u) : 4u) : 0u;                      \
