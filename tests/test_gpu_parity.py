@@ -758,6 +758,40 @@ def test_compact_id_state_of_whole_grid_jfa_matches_naive(engine, n, kind):
     assert same, (n, kind, bad)
 
 
+@pytest.mark.parametrize("kind", ["empty", "single", "corner", "full", "plane"])
+def test_compact_id_state_edge_grids(engine, kind):
+    """The compact id state on the grids where "none" matters most: no seed at all (every id stays "none", the sdf is the +-inf fill),
+    one border voxel in the middle / in the far corner (x = y = z = n - 1: every field all ones, the top z bit set -- the pattern closest
+    to "none"), a full grid (border = the six faces), one filled plane across the z = 1024 boundary of the top z bit.  n = 1152."""
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    n = 1152
+    fr = Frame.make(n, 0.5, (-3.0, 2.0, 0.25))
+    w = np.zeros(fr.words, np.uint32)
+    bit = lambda x, y, z: (x + n * (y + n * z))
+    if kind == "single":
+        i = bit(n // 2 + 3, n // 3, n // 2 + 77); w[i >> 5] |= np.uint32(1 << (i & 31))
+    elif kind == "corner":
+        i = bit(n - 1, n - 1, n - 1); w[i >> 5] |= np.uint32(1 << (i & 31))
+    elif kind == "full":
+        w[:] = 0xFFFFFFFF
+    elif kind == "plane":
+        pw = n * n // 32
+        w[1023 * pw:1025 * pw] = 0xFFFFFFFF
+    g = engine.to_device(w, np.uint32)
+    for fill in (-math.inf, math.inf):
+        s_t = engine.jfa(fr, g, fill=fill, algo=ALGO_TILED).clone()
+        s_n = engine.jfa(fr, g, fill=fill, algo=ALGO_NAIVE)
+        engine.sync()
+        assert torch.equal(s_t.view(torch.int32), s_n.view(torch.int32)), (kind, fill)
+        if kind == "empty":
+            assert bool(torch.isinf(s_t).all()) and bool(((s_t > 0) == (fill > 0)).all())
+        del s_t, s_n
+    del g
+    engine._work = None
+    gc.collect(); torch.cuda.empty_cache()
+
+
 def test_round1_tile_kernel_path_still_matches(engine):
     """VP_JFA_DENSE=0 routes every pass of a 32-bit-id JFA through jfa_pass_zstream (the kernel that still serves 8-byte ids, the
     sparse pass and slabs whose halo buffers are not contiguous): same sdf, bit for bit, as the default path.  The switch is read
