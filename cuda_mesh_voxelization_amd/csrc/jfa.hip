@@ -1837,6 +1837,9 @@ __device__ unsigned long long g_ft_slots[kFtSlots][16];          // one row per 
 #ifndef VP_FT_POS_LDS
 #define VP_FT_POS_LDS 1
 #endif
+#ifndef VP_FT_FAST
+#define VP_FT_FAST 1              // tiles whose lattices hold at most one border voxel each are written straight from a census (see the kernel)
+#endif
 // CPT (round 4): the result leaves in the compact layout of IdC (word plane + byte plane) instead of ID's own; inside the kernel the
 // ids stay ID's (Id64).
 template <class ID, int XR, int NT, int TPW, bool CPT = false>
@@ -1854,6 +1857,7 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
     __shared__ uint32_t list[SLOTS];                               // entries: slot | slot of the seed it holds << 16
     __shared__ float posX[4 * XR], posY[4], posZ[4];
     __shared__ uint32_t cnt[2];
+    __shared__ uint32_t latCnt[TPW][XR], latSeed[TPW][XR];         // VP_FT_FAST: border voxels per lattice of each tile, the slot of one of them
     const uint32_t tid = threadIdx.x, lane = tid & 63u, N = f.n, k = N / 4u;
     // slot tid + i NT = row-plane (rpb + i G) x column `col` (see jfa_pass_seeds): row addresses are scalar work
     constexpr uint32_t RPW = 4u * XR;
@@ -1905,6 +1909,10 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
             mw[u][i] = xin ? border[(z * N + y) * f.w + (myx >> 5)] : 0u;          // < 2^28 words at n = 2048: 32-bit index arithmetic
         }
     }
+    if (VP_FT_FAST) {                                              // lattice census of every tile of this workgroup (see below); the border words are in flight
+        for (uint32_t i = tid; i < (uint32_t)(TPW * XR); i += NT) (&latCnt[0][0])[i] = 0;
+        __syncthreads();
+    }
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
         const uint32_t tile = tile0 + u;
@@ -1914,6 +1922,47 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
         const uint32_t myx = rx0 + col % XR + __umul24(col / XR, k);
         const bool xin = rx0 + col % XR < k;
         VP_FT_STAMP(0);
+#if VP_FT_FAST
+        // The 64 voxels of one residue class (x, y, z mod k) -- a LATTICE, 4 x 4 x 4 chain positions -- only ever see each other in these
+        // two passes.  A lattice without a border voxel stays "none"; a lattice with exactly ONE ends with that seed in all 64 voxels
+        // whatever the distances are (after the step of two chain positions the seed sits at {s, s ^ 2} along every axis, and every
+        // position 0 .. 3 has one of those within one step).  Only lattices with two or more border voxels need the proposals -- 7 % of
+        // them at n = 512 on the benchmark mesh, and 61 % of the tiles have none (profiles/r04/first_two_lattices.txt): those tiles write
+        // their result straight from the census below: one barrier, no lists, keys or proposals.  With that much less to issue the wait
+        // for the border words shows again, and two tiles per workgroup (all loads up front) pay: 0.305 -> 0.269 -> 0.239 ms at n = 512,
+        // 2.17 -> 1.77 -> 1.59 ms at n = 1024, 22.3 -> 17.2 ms at n = 2048 (profiles/r04/ab_ftfast_*.txt, ab_fttpw_*.txt).
+        {
+            const uint32_t res = col % XR;
+            uint32_t mine = 0, mySlot = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+                if (xin && ((mw[u][i] >> (myx & 31u)) & 1u)) { ++mine; mySlot = tid + (uint32_t)i * NT; }
+            bool multi = false;
+            if (mine) {
+                multi = atomicAdd(&latCnt[u][res], mine) + mine >= 2u;   // whoever adds last to a lattice of two or more sees it
+                latSeed[u][res] = mySlot;
+            }
+            if (!__syncthreads_or(multi ? 1 : 0)) {
+                const uint32_t sSlot = latSeed[u][res];               // valid where latCnt[u][res] == 1
+                const T one = ID::pack(rx0 + res + __umul24((sSlot / XR) & 3u, k), ry + ((sSlot / (4u * XR)) & 3u) * k, rz + (sSlot / (16u * XR)) * k);
+                const T id = latCnt[u][res] ? one : ID::none();
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    if (!xin) continue;
+                    const uint32_t rp = rpb + (uint32_t)i * G;
+                    const size_t vox = (size_t)((rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx;
+                    if constexpr (CPT) {
+                        const uint2 c = IdC::from64(id);
+                        reinterpret_cast<uint32_t*>(out)[vox] = c.x;
+                        (reinterpret_cast<unsigned char*>(reinterpret_cast<uint32_t*>(out) + (size_t)N * N * N))[vox] = (unsigned char)c.y;
+                    } else {
+                        out[vox] = id;
+                    }
+                }
+                continue;                                              // next tile of the workgroup (uniform)
+            }
+        }
+#endif
         if (tid < 2) cnt[tid] = 0;
         if (VP_FT_POS_LDS) {                                       // positions of the tile's 4 XR columns, 4 rows, 4 planes (see ChainPosLds)
             if (tid < RPW) posX[tid] = axis_pos(f.ox, myx, f.vs);  // tid < RPW: col == tid
@@ -1984,6 +2033,9 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
             if (!xin) continue;
             const unsigned long long key = keys[tid + (uint32_t)i * NT];
             const T id = key == kEmpty ? ID::none() : idOf[(uint32_t)key & 0x07FFFFFFu];       // stage B tags its proposals with the seed's slot
+            // (Answering the lattices of at most one border voxel from the census in THESE tiles as well -- two thirds of their border voxels --
+            // was measured: -1 % at n = 512, +4 % at n = 1024, profiles/r04/ab_ft3_*.txt: such a tile is bound by its fixed stages, not by
+            // the number of proposals.)
             const uint32_t rp = rpb + (uint32_t)i * G;
             const size_t vox = (size_t)((rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx;
             if constexpr (CPT) {
@@ -2120,7 +2172,7 @@ bool jfa_can_fuse_first_two(const Frame& f, int algo)
 }
 
 #ifndef VP_FIRST_TWO_TPW
-#define VP_FIRST_TWO_TPW 1        // tiles per workgroup.  Measured (profiles/r03/ab_tpw_*.txt): 1 / 2 / 4 / 8 tiles = 0.371 / 0.373 / 0.370 / 0.406 ms
+#define VP_FIRST_TWO_TPW 2        // tiles per workgroup.  Round 3, without the census fast path (profiles/r03/ab_tpw_*.txt): 1 / 2 / 4 / 8 tiles = 0.371 / 0.373 / 0.370 / 0.406 ms
                                   // at n = 512, 2.78 / 2.81 / 2.74 / 3.23 at n = 1024 -- the other resident workgroups already cover the load
                                   // latency; what did pay is the ONE-dimensional launch these forms share: 0.405 -> 0.371 ms, 2.92 -> 2.78
 #endif
