@@ -2183,7 +2183,14 @@ int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, 
     // tile = 4 x 4 x 4 chain positions x XR residues.  Measured (profiles/r02/ab33.txt): 16 residues x 256 threads is the best
     // shape at n = 512 (0.404 ms against 0.183 + 0.307 for the two separate kernels; 32 x 512: 0.436), 32 x 512 at n = 1024
     // (2.94 ms against 1.39 + 2.12; 16 x 256: 3.41).  A workgroup takes VP_FIRST_TWO_TPW consecutive tiles.
-    const bool small = f.n <= 512;
+#ifndef VP_FT_SMALL_XR32
+#define VP_FT_SMALL_XR32 0        // 32 residues x 512 threads at n <= 512 too (128-byte row segments instead of 64): 0.238 -> 0.297 ms with the census
+                                  // (fewer tiles without a contested lattice), profiles/r04/ab_ftxr_*.txt
+#endif
+#ifndef VP_FT_BIG_XR16
+#define VP_FT_BIG_XR16 0          // 16 residues x 256 threads at n = 1024 too: 1.60 -> 1.69 ms (profiles/r04/ab_ftxr_*.txt)
+#endif
+    const bool small = (f.n <= 512 && !VP_FT_SMALL_XR32) || (VP_FT_BIG_XR16 && f.n <= 1024);
     const uint32_t xr = small ? 16u : 32u;
     const uint32_t tilesX = (k + xr - 1) / xr, tiles = tilesX * k * k;
     const dim3 grid((tiles + VP_FIRST_TWO_TPW - 1) / VP_FIRST_TWO_TPW);
@@ -2191,7 +2198,13 @@ int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, 
     const uint32_t shifts = (pow2(tilesX) && pow2(k)) ? ((uint32_t)__builtin_ctz(tilesX) | ((uint32_t)__builtin_ctz(k) << 8) | (1u << 16)) : 0u;
     if (wide(f) && f.compact) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW, true>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles, shifts);
     else if (wide(f)) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles, shifts);
-    else if (small) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
+    else if (small && f.n <= 512) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
+#if VP_FT_BIG_XR16
+    else if (small) hipLaunchKernelGGL((jfa_first_two<Id10, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
+#endif
+#if VP_FT_SMALL_XR32
+    else if (f.n <= 512) hipLaunchKernelGGL((jfa_first_two<Id9, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
+#endif
     else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
     VP_HIP(hipGetLastError());
     return 0;
