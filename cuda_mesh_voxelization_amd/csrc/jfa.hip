@@ -111,18 +111,28 @@ struct Id64 {                     // n <= 2048: .x = scr(z)<<2 | x<<13, .y = scr
 
 // Compact ids (round 4; n <= 2048, whole-grid vp_jfa only): 5 bytes per voxel in TWO planes instead of the 8 of Id64 --
 //   word plane (n^3 dwords):  x [0..10] | scr(y) [11..21] | low ten bits of scr(z) [22..31]
-//   byte plane (n^3 bytes, right behind the word plane):  "none" [bit 0] | top bit of z [bit 1]
+//   byte plane (n^3 bytes, right behind the word plane):  top bit of scr(z) [bit 1] | "none" [bit 2]     (values 0, 2, 4)
 // 33 coordinate bits + "none" do not fit 32; the passes at this size are bound by fabric traffic, not by instruction issue
 // (profiles/r03/n2048_wide_ablation.txt), so what pays is fewer bytes: 10 instead of 16 per voxel and pass.  In registers an id is a
-// uint2 (.x = word, .y = byte).  "none" = (x field 0, byte 3): its x offset is slot 2048 of the x table (+inf), as in IdU.
+// uint2 (.x = word, .y = byte).  The byte shifted left by 11 IS the high part of the z table offset: 2 -> slot 1024 + .., 4 ("none") ->
+// slots 2048 .. 3071, which hold +inf (the tile kernel's z table has 3072 entries for this format): "none" gets an infinite distance
+// through the ordinary lookup, as it does through slot TAB of the x table in IdU.
 // Everything stays per lane (a dword and a byte load / store per id): no cross-lane packing of bit planes.
+#ifndef VP_IDC_NONE_Z
+#define VP_IDC_NONE_Z 1             // 0: the first form of round 4 -- "none" in bit 0 of the byte, merged into the x offset (slot 2048 of the x table):
+                                    // 3 more VALU per decoded id (5340 -> 4987 per 32 outputs); dense pass at n = 2048 34.8 -> 34.0 ms, step 327.2 ->
+                                    // 320.7 ms (profiles/r04/ab_idcz_2048.txt: two alternating bench runs of each build on one box)
+#endif
 struct IdC {
     using T = uint2;
     static constexpr int kTab = 2048;
+    static constexpr int kTabZ = VP_IDC_NONE_Z ? 3072 : 2048;      // entries of the z table
     static constexpr uint32_t kMask = 0x1FFCu;
     static constexpr uint32_t kNoneWord = 0xFFFFF800u;
-    __device__ static __forceinline__ T none() { return make_uint2(kNoneWord, 3u); }
-    __device__ static __forceinline__ bool is_none(T a) { return (a.y & 1u) != 0u; }
+    static constexpr uint32_t kNoneBit = VP_IDC_NONE_Z ? 4u : 1u;  // in the byte; bit 1 = top bit of scr(z)
+    static constexpr uint32_t kNoneByte = VP_IDC_NONE_Z ? 4u : 3u;
+    __device__ static __forceinline__ T none() { return make_uint2(kNoneWord, kNoneByte); }
+    __device__ static __forceinline__ bool is_none(T a) { return (a.y & kNoneBit) != 0u; }
     __device__ static __forceinline__ T pack(uint32_t x, uint32_t y, uint32_t z)
     {
         const uint32_t sz = scr(z);
@@ -134,9 +144,14 @@ struct IdC {
         const uint32_t sz = (a.x >> 2) & 2047u, sy = (a.y >> 2) & 2047u;
         return make_uint2((a.x >> 13) | (sy << 11) | ((sz & 1023u) << 22), (sz >> 10) << 1);
     }
+#if VP_IDC_NONE_Z
+    __device__ static __forceinline__ uint32_t xoff(T a) { return (a.x & 0x7FFu) << 2; }
+    __device__ static __forceinline__ uint32_t zoff(T a) { return ((a.x >> 20) & 0xFFCu) | (a.y << 11); }   // byte 2: slot 1024 + .., 4 ("none"): 2048 + ..
+#else
     __device__ static __forceinline__ uint32_t xoff(T a) { return ((a.x & 0x7FFu) << 2) | ((a.y & 1u) << 13); }   // "none": 4 * 2048
-    __device__ static __forceinline__ uint32_t yoff(T a) { return (a.x >> 9) & kMask; }
     __device__ static __forceinline__ uint32_t zoff(T a) { return ((a.x >> 20) & 0xFFCu) | ((a.y & 2u) << 11); }
+#endif
+    __device__ static __forceinline__ uint32_t yoff(T a) { return (a.x >> 9) & kMask; }
     __device__ static __forceinline__ uint32_t zt2(T a) { return a.y & 2u; }                   // top z bit, as it sits in the byte
 };
 
@@ -1061,7 +1076,7 @@ template <class ID> constexpr bool final_mask_global() { return VP_FINAL_GLOBAL_
 //     infinite seed x by an explicit test, once per id.
 template <class ID> constexpr bool dense_wide() { return std::is_same<ID, Id64>::value || std::is_same<ID, IdC>::value; }   // 8-KB tables
 // Compact ids (IdC, round 4): the form above with the id state in a word plane and a byte plane (10 instead of 16 bytes per voxel and pass).
-// "none" goes through slot 2048 of the x table as in the 32-bit formats; the top z bit of a candidate travels in bit 1 of its rank
+// "none" goes through the slots beyond 2048 of the z table (see IdC); the top z bit of a candidate travels in bit 1 of its rank
 // (rank = (tile row index + 1) << 14 | byte offset of the column + 1 | top z bit << 1; the own voxel: top z bit << 1 alone, below every
 // other rank), so the winner gather fetches one dword and the byte of the output is rebuilt from the winning pair (distance = +inf: "none").
 #ifndef VP_DENSE_STORE_AUX
@@ -1109,10 +1124,14 @@ template <class ID, int RY, int CH, int NT, bool FINAL, bool ROLL, bool SKIP, in
 #ifndef VP_DENSE_WIDE_WAVES
 #define VP_DENSE_WIDE_WAVES 4
 #endif
+#ifndef VP_DENSE_IDC_WAVES
+#define VP_DENSE_IDC_WAVES 4      // compact ids, 512 threads: 6 (three workgroups per CU fit the LDS) leaves 80 VGPRs -- the fused last pass fits (78) and
+                                   // gains nothing (31.0 against 30.9 - 32.1 ms), the id passes spill 50 registers: 34.0 -> 46.2 ms (gpurun r04z)
+#endif
 #ifndef VP_DENSE_FULL_1024
 #define VP_DENSE_FULL_1024 0        // FULL id passes with the 4-KB tables under a four-wave bound (see launch_dense): -0.3 %, not adopted
 #endif
-__global__ void __launch_bounds__(NT, dense_wide<ID>() ? (NT == 256 ? VP_DENSE_WIDE_WAVES : 4) : RY > 4 ? 4 : (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (VP_DENSE_FULL_1024 && FULL && ID::kTab == 1024 && !FINAL) ? 4 : (ID::kTab == 512 || NT == 512) ? 6 : 4)
+__global__ void __launch_bounds__(NT, dense_wide<ID>() ? (NT == 256 ? VP_DENSE_WIDE_WAVES : (std::is_same<ID, IdC>::value ? VP_DENSE_IDC_WAVES : 4)) : RY > 4 ? 4 : (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (VP_DENSE_FULL_1024 && FULL && ID::kTab == 1024 && !FINAL) ? 4 : (ID::kTab == 512 || NT == 512) ? 6 : 4)
 jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typename ID::T* __restrict__ out,
                const typename ID::T* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf,
                uint32_t tilesY, uint32_t tiles, uint32_t splitTiles)
@@ -1122,7 +1141,8 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     constexpr bool CPT = std::is_same<ID, IdC>::value;             // word plane + byte plane (whole grids only: the byte plane follows the n^3 words)
     constexpr uint32_t IDB = CPT ? 4u : (uint32_t)sizeof(T);       // bytes per voxel in the (word) plane the offsets below refer to
     constexpr int TAB = ID::kTab;
-    constexpr int PXT = (WIDE && !CPT) ? TAB : TAB + 1;            // 32-bit and compact ids: slot TAB = the x index of "none" = +inf
+    constexpr int PXT = (WIDE && (!CPT || VP_IDC_NONE_Z)) ? TAB : TAB + 1;   // 32-bit ids: slot TAB = the x index of "none" = +inf
+    constexpr int TABZ = (CPT && VP_IDC_NONE_Z) ? IdC::kTabZ : TAB;      // compact ids: "none" indexes the z table beyond its 2048 real slots: z position +inf
     constexpr int EY = 1, EZ = 1;                                  // floats per table entry (wider entries: measured slower)
     constexpr int HY = (CLOSED & 1) ? 0 : 1;                       // halo rows on each side of the tile's output rows
     constexpr bool CZ = (CLOSED & 2) != 0;                         // no halo planes
@@ -1137,7 +1157,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
     using B = typename std::conditional<FINAL, float, double>::type;
     __shared__ float PX[PXT];
     __shared__ __attribute__((aligned(16))) float TY[RY / EY][TAB][EY];
-    __shared__ __attribute__((aligned(16))) float TZ[CHT / EZ][TAB][EZ];
+    __shared__ __attribute__((aligned(16))) float TZ[CHT / EZ][TABZ][EZ];
     __shared__ uint32_t RB[WIDE ? (CH + 2) * NR : 1];              // WIDE: row number (inside the id buffer) of every source row of the tile
     constexpr bool GM = final_mask_global<ID>();
     __shared__ uint32_t WM[(FINAL && !GM) ? RY * CH * (TAB / 32) : 1];
@@ -1210,6 +1230,8 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
             for (int j = 0; j < CHT; ++j) TZ[j / EZ][i][j % EZ] = 0.0f;
         }
     }
+    if constexpr (TABZ > TAB)
+        for (uint32_t i = (uint32_t)TAB + tid; i < (uint32_t)TABZ; i += NT) TZ[0][i][0] = INFINITY;
     if (WIDE) {
         // row numbers of the tile's source rows: entry pj * NR + rr = plane zbase + (pj - 1) k, row ybase + (rr - 1) k (0 where outside)
         for (uint32_t i = tid; i < (uint32_t)((CH + 2) * NR); i += NT) {
@@ -1569,7 +1591,7 @@ jfa_pass_dense(Frame f, uint32_t k, const typename ID::T* __restrict__ in, typen
                             const uint32_t zt = lo & 2u;
                             const uint32_t r = lo < 4u ? (uint32_t)((P * NR + a + 1 + 1) << 14) + xo : lo - 1u - zt;
                             const ptrdiff_t row = (ptrdiff_t)(int)RB[(r >> 14) - 1u];
-                            const uint32_t none1 = __builtin_bit_cast(u32x2, best[a][P - 1]).y == 0x7F800000u ? 1u : 0u;
+                            const uint32_t none1 = __builtin_bit_cast(u32x2, best[a][P - 1]).y == 0x7F800000u ? IdC::kNoneBit : 0u;
                             pend[a] = make_uint2(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(in) + row * (ptrdiff_t)rowBytes + (ptrdiff_t)(r & 16383u)),
                                                  zt | none1);
                         } else if constexpr (WIDE) {
@@ -2241,7 +2263,7 @@ static int ensure_none_rows(vp_ctx* ctx)
     VP_HIP(hipMemsetD32Async((hipDeviceptr_t)(p + 2048 * 8), (int)kNone9, 1024, ctx->stream));
     VP_HIP(hipMemsetD32Async((hipDeviceptr_t)(p + 2048 * 8 + 1024 * 4), (int)kNone10, 1024, ctx->stream));
     VP_HIP(hipMemsetD32Async((hipDeviceptr_t)(p + 2048 * 8 + 2 * 1024 * 4), (int)IdC::kNoneWord, 2048, ctx->stream));
-    VP_HIP(hipMemsetAsync(p + 2048 * 8 + 2 * 1024 * 4 + 2048 * 4, 3, 2048, ctx->stream));
+    VP_HIP(hipMemsetAsync(p + 2048 * 8 + 2 * 1024 * 4 + 2048 * 4, (int)IdC::kNoneByte, 2048, ctx->stream));
     return 0;
 }
 template <class ID>

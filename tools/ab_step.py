@@ -36,7 +36,7 @@ for r in range(a.rounds + 1):
             L.vp_jfa(ctx, fr, g.data_ptr(), -math.inf, sdf.data_ptr(), None, 0, 2)
         L.vp_prof_enable(ctx, 0)
         if r == 0:
-            L.vp_ctx_sync(ctx); chk[nm] = int(sdf.view(torch.int32).to(torch.int64).sum().item()); continue
+            L.vp_ctx_sync(ctx); chk[nm] = sum(int(c.to(torch.int64).sum().item()) for c in sdf.view(torch.int32).split(1 << 28)); continue   # in chunks: 8.6 G voxels at n = 2048
         for kern in range(20):
             ms, cnt = ctypes.c_double(), ctypes.c_uint64()
             if L.vp_prof_get(ctx, kern, ctypes.byref(ms), ctypes.byref(cnt)) == 0 and cnt.value:
