@@ -25,7 +25,9 @@ Rank 0 prints ONE JSON line (DESIGN.md "Measurement"):
 N > 1: strong scaling of the same n^3 job over N Z-slabs, one process per GPU (cuda_mesh_voxelization_amd/slab.py).  After the
 timed region every rank runs the ONE-GPU path on its own device and compares its slab of the bitmask and of the sdf bit for
 bit (`parity_ok`; a mismatch on any rank makes the run exit non-zero), then times the OTHER transport (`multi_alt`: RCCL halos
-when the job ran ghost planes and vice versa) over a shorter region, checked the same way.
+when the job ran ghost planes and vice versa) over a shorter region, checked the same way -- under a watchdog
+(VP_BENCH_ALT_TIMEOUT, default 180 s): if that transport hangs, rank 0 prints the line of the timed pipeline as it stands, with the
+time-out recorded in `multi_alt`, and the job ends.
 """
 from __future__ import annotations
 
@@ -400,45 +402,50 @@ def main():
         torch.cuda.empty_cache()
         flags = same_bits(got, ref_words, ref_sdf)
         del got
+        # the timed pipeline's parity is gathered BEFORE the other transport is touched: whatever happens there, this stands
+        fl0 = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=eng.device)
+        all0 = [torch.zeros_like(fl0) for _ in range(world)]
+        dist.all_gather(all0, fl0)
+        per_rank0 = [[bool(v) for v in t.tolist()] for t in all0]
+        parity = {"parity_ok": all(all(r) for r in per_rank0),
+                  "per_rank": [{"rank": i, "bitmask_slab_equal": r[0], "sdf_slab_equal": r[1]} for i, r in enumerate(per_rank0)],
+                  "against": "the one-GPU path (vp_voxelize + vp_jfa of the whole grid) run on each rank's own device after the timed region"}
         # ---- the other transport in the same job, over a shorter region (so that a scaling run shows RCCL moving halos and not
         # only barriers when the default is ghost planes, and the exchange-free figure when it is not)
         alt_kind = "halo" if args.multi != "halo" else "ghost"
         alt_steps = max(2, args.steps // 4)
-        alt_error = None
-        try:
-            # the secondary measurement must not cost the primary one: an exception here (first contact of a transport with real
-            # hardware) is reported in the line, the timed pipeline's figures and its parity check stand
-            a_el, _a_live, a_table, a_rep, a_got = run_pipeline(alt_kind, alt_steps, 1)
-            flags += same_bits(a_got, ref_words, ref_sdf)
-            del a_got
-        except Exception as e:                                   # noqa: BLE001 -- reported, not swallowed
-            alt_error = "%s: %s" % (type(e).__name__, e)
-            a_el, a_table, a_rep = float("nan"), {}, {"describe": alt_kind, "error": alt_error}
-            flags += [False, False]
-        del ref_words, ref_sdf
-        torch.cuda.empty_cache()
-        fl = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=eng.device)
-        allf = [torch.zeros_like(fl) for _ in range(world)]
-        dist.all_gather(allf, fl)
-        per_rank = [[bool(v) for v in t.tolist()] for t in allf]
-        parity = {"parity_ok": all(all(r[:2]) for r in per_rank),
-                  "per_rank": [{"rank": i, "bitmask_slab_equal": r[0], "sdf_slab_equal": r[1]} for i, r in enumerate(per_rank)],
-                  "against": "the one-GPU path (vp_voxelize + vp_jfa of the whole grid) run on each rank's own device after the timed region"}
-        recv = torch.tensor([float(a_rep.get("bytes_received_total", 0))], dtype=torch.float64, device=eng.device)
-        dist.all_reduce(recv, op=dist.ReduceOp.SUM)
-        a_rep.pop("regions", None)
-        any_err = torch.tensor([1 if alt_error else 0], dtype=torch.int32, device=eng.device)
-        dist.all_reduce(any_err, op=dist.ReduceOp.MAX)
-        alt_failed = bool(any_err.item())                        # on ANY rank: then the region's figures mean nothing
-        multi_alt = {"pipeline": alt_kind, "parallelism": a_rep.pop("describe"), "steps": alt_steps, "warmup": 1,
-                     "ms_per_step": None if alt_failed else round(a_el / alt_steps * 1e3, 4),
-                     "value": None if alt_failed else round(n ** 3 / (a_el / alt_steps) / 1e6, 2), "unit": "Mvoxels/s",
-                     "bytes_received_per_step_all_ranks": int(recv.item() / (alt_steps + 1 + TABLE_STEPS)),
-                     "error": alt_error if alt_error else ("another rank failed" if alt_failed else None),
-                     "parity_ok": None if alt_failed else all(all(r[2:]) for r in per_rank),
-                     "per_rank": [{"rank": i, "bitmask_slab_equal": r[2], "sdf_slab_equal": r[3]} for i, r in enumerate(per_rank)],
-                     "report_rank0": a_rep,
-                     "kernels_ms_per_step_rank0": {k: round(v["ms"] / TABLE_STEPS, 4) for k, v in a_table.items()}}
+
+        def alt_region():
+            """every rank: time the other pipeline, compare its slab, agree on the outcome; returns the `multi_alt` object"""
+            alt_error, aflags = None, [False, False]
+            try:
+                # the secondary measurement must not cost the primary one: an exception here (first contact of a transport with real
+                # hardware) is reported in the line, the timed pipeline's figures and its parity check stand
+                a_el, _a_live, a_table, a_rep, a_got = run_pipeline(alt_kind, alt_steps, 1)
+                aflags = same_bits(a_got, ref_words, ref_sdf)
+                del a_got
+            except Exception as e:                                   # noqa: BLE001 -- reported, not swallowed
+                alt_error = "%s: %s" % (type(e).__name__, e)
+                a_el, a_table, a_rep = float("nan"), {}, {"describe": alt_kind, "error": alt_error}
+            fl = torch.tensor([1 if f else 0 for f in aflags], dtype=torch.int32, device=eng.device)
+            allf = [torch.zeros_like(fl) for _ in range(world)]
+            dist.all_gather(allf, fl)
+            per_rank = [[bool(v) for v in t.tolist()] for t in allf]
+            recv = torch.tensor([float(a_rep.get("bytes_received_total", 0))], dtype=torch.float64, device=eng.device)
+            dist.all_reduce(recv, op=dist.ReduceOp.SUM)
+            a_rep.pop("regions", None)
+            any_err = torch.tensor([1 if alt_error else 0], dtype=torch.int32, device=eng.device)
+            dist.all_reduce(any_err, op=dist.ReduceOp.MAX)
+            alt_failed = bool(any_err.item())                        # on ANY rank: then the region's figures mean nothing
+            return {"pipeline": alt_kind, "parallelism": a_rep.pop("describe"), "steps": alt_steps, "warmup": 1,
+                    "ms_per_step": None if alt_failed else round(a_el / alt_steps * 1e3, 4),
+                    "value": None if alt_failed else round(n ** 3 / (a_el / alt_steps) / 1e6, 2), "unit": "Mvoxels/s",
+                    "bytes_received_per_step_all_ranks": int(recv.item() / (alt_steps + 1 + TABLE_STEPS)),
+                    "error": alt_error if alt_error else ("another rank failed" if alt_failed else None),
+                    "parity_ok": None if alt_failed else all(all(r) for r in per_rank),
+                    "per_rank": [{"rank": i, "bitmask_slab_equal": r[0], "sdf_slab_equal": r[1]} for i, r in enumerate(per_rank)],
+                    "report_rank0": a_rep,
+                    "kernels_ms_per_step_rank0": {k: round(v["ms"] / TABLE_STEPS, 4) for k, v in a_table.items()}}
 
     peak = copy_peak(eng) if (world == 1 and not args.no_copy_peak) else None
     if rank == 0:
@@ -491,9 +498,8 @@ def main():
             out["copy_peak"] = peak
         if pipe_report is not None:
             out["multi"] = pipe_report
-            out["parity_ok"] = parity["parity_ok"] and multi_alt["parity_ok"] is not False   # a transport that RAN and disagreed fails the line
+            out["parity_ok"] = parity["parity_ok"]
             out["parity"] = parity
-            out["multi_alt"] = multi_alt
         if world == 1 and n == N_GRID and not args.no_n1024:
             # the north star's roofline target lives at n = 1024: same mesh, JFA only is what differs in cost per voxel
             n2 = 1024
@@ -530,6 +536,39 @@ def main():
             out["totals_incl_transfers_ms"] = out["totals_incl_transfers"]["total_ms"]
         if world == 1 and not args.no_cpu_baseline and n == N_GRID:
             out["cpu_baseline"] = cpu_baseline(xyz, tri, origin, vs, n)
+    if world > 1:
+        # The other transport runs under a watchdog: a transport that HANGS on hardware the build never saw (a point-to-point pair that
+        # never completes cannot be cancelled) must not take the timed pipeline's line with it.  After VP_BENCH_ALT_TIMEOUT seconds
+        # (default 180) rank 0 prints the line it already has, with the time-out recorded in `multi_alt`, and every rank leaves.
+        import threading
+        limit = float(os.environ.get("VP_BENCH_ALT_TIMEOUT", "180"))
+        lock, finished = threading.Lock(), [False]
+
+        def give_up():
+            with lock:
+                if finished[0]:
+                    return
+                if rank == 0:
+                    out["multi_alt"] = {"pipeline": alt_kind, "steps": alt_steps, "ms_per_step": None, "value": None, "parity_ok": None,
+                                        "error": "no result within %.0f s (VP_BENCH_ALT_TIMEOUT): the transport hung; the timed "
+                                                 "pipeline's figures and parity above stand" % limit}
+                    print(json.dumps(out), flush=True)
+                sys.stdout.flush()
+                os._exit(0 if parity["parity_ok"] else 1)
+
+        timer = threading.Timer(limit, give_up)
+        timer.daemon = True
+        timer.start()
+        multi_alt = alt_region()
+        with lock:
+            finished[0] = True
+        timer.cancel()
+        del ref_words, ref_sdf
+        torch.cuda.empty_cache()
+        if rank == 0:
+            out["multi_alt"] = multi_alt
+            out["parity_ok"] = parity["parity_ok"] and multi_alt["parity_ok"] is not False   # a transport that RAN and disagreed fails the line
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     bad = parity is not None and not (parity["parity_ok"] and multi_alt["parity_ok"] is not False)

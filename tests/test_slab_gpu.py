@@ -276,3 +276,23 @@ def test_bench_multi_process_launch_on_shared_gpu(world, multi):
     else:
         assert alt["bytes_received_per_step_all_ranks"] == 0
     assert out["multi"].get("hbm_bytes_this_rank", 0) > 0              # per-rank HBM footprint of the pipeline
+
+
+def test_bench_other_transport_hang_does_not_take_the_line_with_it():
+    """bench.py runs the second transport of an N > 1 job under a watchdog: a transport that never returns (first contact with
+    hardware the build never saw) must leave the timed pipeline's line and parity intact.  A limit of 1 ms stands in for the hang."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, VP_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", VP_BENCH_ALT_TIMEOUT="0.001")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid-n", "256"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["parity_ok"] is True and out["parity"]["parity_ok"] is True
+    assert out["multi_alt"]["parity_ok"] is None and "VP_BENCH_ALT_TIMEOUT" in out["multi_alt"]["error"]
