@@ -41,6 +41,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC: without this RCCL's device-memory sharing between the ranks of one node fails with
+# `hipIpcGetMemHandle: invalid argument`.  Exported on the boxes already; kept here for any environment that launches this file bare.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
