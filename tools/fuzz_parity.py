@@ -1,0 +1,129 @@
+"""Dev tool (GPU box): randomized parity campaign, many seeds of the families the GPU suite pins at fixed seeds.
+  python tools/fuzz_parity.py [--seconds 600] [--seed0 1000]
+Per seed, one of
+  soup   random triangle soup (size classes, slivers, snapped vertices, in-plane triangles, outside the frame): tiled and naive
+         voxelizer against the oracle's scanline, bit for bit (n = 32 .. 384)
+  ids    random grid (noise of a random density, axis-aligned slabs / bars / boxes = tie-rich, balls): the ids of EVERY pass, tile
+         kernels against the one-thread-per-voxel kernel on the same input state, plus the from-the-mask forms (n = 64 .. 640)
+  sdf    the same grids through vp_jfa, tiled against naive, both fill signs (n up to 1280: compact ids above 1024)
+Prints one line per case; exits non-zero on the first mismatch with the seed that reproduces it."""
+import argparse, math, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, Frame
+from cuda_mesh_voxelization_amd.pipeline import Engine
+from oracle import oracle as O
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=600.0); ap.add_argument("--seed0", type=int, default=1000)
+a = ap.parse_args()
+eng = Engine(0)
+
+
+def soup(rng, n, vs, origin):
+    side, tris = n * vs, []
+    for _ in range(int(rng.integers(50, 500))):
+        c = origin + rng.random(3) * side
+        tris.append(c + (rng.random((3, 3)) - 0.5) * side * 10.0 ** rng.uniform(-3.2, 0.0))
+    for _ in range(int(rng.integers(0, 100))):
+        c = origin + rng.random(3) * side; d = (rng.random(3) - 0.5) * side * 0.5
+        tris.append(np.stack([c, c + d, c + d * 0.5 + (rng.random(3) - 0.5) * vs * 0.01]))
+    for _ in range(int(rng.integers(0, 100))):
+        tris.append(origin + (rng.integers(0, n, (3, 3)) + rng.choice([0.0, 0.5], (3, 3))) * vs)
+    for ax in range(3):
+        for _ in range(int(rng.integers(0, 30))):
+            v = origin + rng.random((3, 3)) * side
+            v[:, ax] = origin[ax] + (rng.integers(0, n) + rng.choice([0.0, 0.5])) * vs
+            tris.append(v)
+    for _ in range(int(rng.integers(0, 60))):
+        c = origin + (rng.random(3) * 1.6 - 0.3) * side
+        tris.append(c + (rng.random((3, 3)) - 0.5) * side * 0.8)
+    xyz = np.concatenate(tris).astype(np.float32)
+    return xyz, np.arange(xyz.shape[0], dtype=np.uint32).reshape(-1, 3)
+
+
+def grid(rng, n):
+    """bit-packed n^3 occupancy as a device tensor + a short description"""
+    kind = rng.choice(["noise", "sparse", "boxes", "balls", "mixed"])
+    occ = torch.zeros((n, n, n), dtype=torch.bool, device=eng.device)
+    g = torch.Generator(device=eng.device); g.manual_seed(int(rng.integers(1 << 31)))
+    if kind in ("noise", "sparse", "mixed"):
+        p = 10.0 ** rng.uniform(-5.0, -2.0) if kind == "sparse" else rng.uniform(0.02, 0.9)
+        occ |= torch.rand((n, n, n), device=eng.device, generator=g) < p
+    if kind in ("boxes", "mixed"):
+        for _ in range(int(rng.integers(1, 12))):                 # slabs, bars, boxes, single voxels: equidistant seeds everywhere
+            lo = rng.integers(0, n, 3); ext = np.where(rng.random(3) < 0.4, n, rng.integers(1, max(2, n // 3), 3))
+            hi = np.minimum(n, lo + ext); lo = np.where(ext == n, 0, lo)
+            occ[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]] ^= True
+    if kind == "balls":
+        ax = torch.arange(n, device=eng.device, dtype=torch.float32)
+        for _ in range(int(rng.integers(1, 6))):
+            c = rng.random(3) * n; r = rng.uniform(1.0, n / 2.5)
+            occ ^= ((ax[None, None, :] - c[0]) ** 2 + (ax[None, :, None] - c[1]) ** 2 + (ax[:, None, None] - c[2]) ** 2) < r * r
+    bits = occ.view(n * n * n // 32, 32).to(torch.int64)
+    words = (bits << torch.arange(32, device=eng.device, dtype=torch.int64)).sum(dim=1).to(torch.int32)   # wraps to the u32 bit pattern
+    del occ, bits
+    return words, kind
+
+
+def check_ids(fr, g, n):
+    idb = eng.ctx.jfa_id_bytes(fr)
+    cur = torch.empty(fr.voxels, dtype=torch.int32 if idb == 4 else torch.int64, device=eng.device)
+    eng.ctx.jfa_init(fr, g.data_ptr(), None, None, cur.data_ptr())
+    x, y = torch.empty_like(cur), torch.empty_like(cur)
+    k = n // 2
+    while k >= 1:
+        eng.ctx.jfa_pass(fr, k, cur.data_ptr(), None, None, x.data_ptr(), ALGO_TILED)
+        eng.ctx.jfa_pass(fr, k, cur.data_ptr(), None, None, y.data_ptr(), ALGO_NAIVE)
+        eng.sync()
+        if not torch.equal(x, y): return "pass k=%d: %d ids differ" % (k, int((x != y).sum().item()))
+        for first, can, fn in ((n // 2, eng.ctx.jfa_can_start_from_mask, eng.ctx.jfa_first_pass), (n // 4, eng.ctx.jfa_can_fuse_first_two, eng.ctx.jfa_first_two)):
+            if k == first and can(fr, ALGO_TILED):
+                border = torch.empty(fr.words, dtype=torch.int32, device=eng.device)
+                eng.ctx.surface(fr, g.data_ptr(), None, None, border.data_ptr())
+                fn(fr, border.data_ptr(), x.data_ptr()); eng.sync()
+                if not torch.equal(x, y): return "from-the-mask form at k=%d: %d ids differ" % (k, int((x != y).sum().item()))
+        cur, x = x, cur
+        k //= 2
+    return None
+
+
+t_end, seed, ncase = time.time() + a.seconds, a.seed0, {"soup": 0, "ids": 0, "sdf": 0}
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    what = ["soup", "ids", "sdf"][seed % 3]
+    vs = float(np.float32(10.0 ** rng.uniform(-2.5, 0.5)))
+    origin = ((rng.random(3) - 0.5) * 20.0).astype(np.float32)
+    err = None
+    if what == "soup":
+        n = int(rng.choice([32, 64, 96, 128, 160, 224, 256, 384]))
+        fr = Frame.make(n, vs, tuple(float(v) for v in origin))
+        xyz, tri = soup(rng, n, vs, origin)
+        exp = O.voxelize(xyz, tri, n, vs, origin)
+        dx, dt = eng.mesh_to_device(xyz, tri)
+        for algo in (ALGO_TILED, ALGO_NAIVE):
+            bad = int(np.count_nonzero(eng.words_to_numpy(eng.voxelize(fr, dx, dt, algo=algo)) != exp))
+            if bad: err = "algo %d: %d words differ" % (algo, bad)
+        desc = "n=%d tris=%d" % (n, tri.shape[0])
+    else:
+        n = int(rng.choice([64, 96, 128, 160, 256, 288, 384, 512, 640] if what == "ids" else [64, 128, 224, 256, 384, 512, 768, 1024, 1152, 1280]))
+        fr = Frame.make(n, vs, tuple(float(v) for v in origin))
+        g, kind = grid(rng, n)
+        desc = "n=%d %s" % (n, kind)
+        if what == "ids":
+            err = check_ids(fr, g, n)
+        else:
+            for fill in (-math.inf, math.inf):
+                s_t = eng.jfa(fr, g, fill=fill, algo=ALGO_TILED).clone()
+                s_n = eng.jfa(fr, g, fill=fill, algo=ALGO_NAIVE)
+                if not torch.equal(s_t.view(torch.int32), s_n.view(torch.int32)):
+                    err = "fill %s: %d sdf values differ" % (fill, int((s_t.view(torch.int32) != s_n.view(torch.int32)).sum().item()))
+                del s_t, s_n
+        del g
+        torch.cuda.empty_cache()
+    ncase[what] += 1
+    print("seed %d %-4s %-22s %s" % (seed, what, desc, "ok" if err is None else "MISMATCH " + err), flush=True)
+    if err is not None:
+        sys.exit(1)
+    seed += 1
+print("cases:", ncase, "mismatches: 0")
