@@ -1862,6 +1862,15 @@ __device__ unsigned long long g_ft_slots[kFtSlots][16];          // one row per 
 #ifndef VP_FT_FAST
 #define VP_FT_FAST 1              // tiles whose lattices hold at most one border voxel each are written straight from a census (see the kernel)
 #endif
+#ifndef VP_FT_STORE_NT
+#define VP_FT_STORE_NT 1          // the id volume leaves with the nt policy (it is read again only by the next pass, after all of it has been written):
+                                  // jfa_first_two 0.238 -> 0.222 ms at n = 512, 1.61 -> 1.50 ms at n = 1024 (profiles/r04/ab_ftnt_*.txt)
+#endif
+template <class T> __device__ __forceinline__ void ft_store(T* p, T v) { if (VP_FT_STORE_NT) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ void ft_store(uint2* p, uint2 v)
+{
+    if (VP_FT_STORE_NT) __builtin_nontemporal_store(__builtin_bit_cast(unsigned long long, v), reinterpret_cast<unsigned long long*>(p)); else *p = v;
+}
 // CPT (round 4): the result leaves in the compact layout of IdC (word plane + byte plane) instead of ID's own; inside the kernel the
 // ids stay ID's (Id64).
 template <class ID, int XR, int NT, int TPW, bool CPT = false>
@@ -1975,10 +1984,10 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
                     const size_t vox = (size_t)((rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx;
                     if constexpr (CPT) {
                         const uint2 c = IdC::from64(id);
-                        reinterpret_cast<uint32_t*>(out)[vox] = c.x;
-                        (reinterpret_cast<unsigned char*>(reinterpret_cast<uint32_t*>(out) + (size_t)N * N * N))[vox] = (unsigned char)c.y;
+                        ft_store(reinterpret_cast<uint32_t*>(out) + vox, c.x);
+                        ft_store(reinterpret_cast<unsigned char*>(reinterpret_cast<uint32_t*>(out) + (size_t)N * N * N) + vox, (unsigned char)c.y);
                     } else {
-                        out[vox] = id;
+                        ft_store(out + vox, id);
                     }
                 }
                 continue;                                              // next tile of the workgroup (uniform)
@@ -2062,10 +2071,10 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
             const size_t vox = (size_t)((rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx;
             if constexpr (CPT) {
                 const uint2 c = IdC::from64(id);
-                reinterpret_cast<uint32_t*>(out)[vox] = c.x;
-                (reinterpret_cast<unsigned char*>(reinterpret_cast<uint32_t*>(out) + (size_t)N * N * N))[vox] = (unsigned char)c.y;
+                ft_store(reinterpret_cast<uint32_t*>(out) + vox, c.x);
+                ft_store(reinterpret_cast<unsigned char*>(reinterpret_cast<uint32_t*>(out) + (size_t)N * N * N) + vox, (unsigned char)c.y);
             } else {
-                out[vox] = id;
+                ft_store(out + vox, id);
             }
         }
         VP_FT_STAMP(12);
