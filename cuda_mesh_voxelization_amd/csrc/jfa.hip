@@ -1864,7 +1864,8 @@ __device__ unsigned long long g_ft_slots[kFtSlots][16];          // one row per 
 #endif
 #ifndef VP_FT_STORE_NT
 #define VP_FT_STORE_NT 1          // the id volume leaves with the nt policy (it is read again only by the next pass, after all of it has been written):
-                                  // jfa_first_two 0.238 -> 0.222 ms at n = 512, 1.61 -> 1.50 ms at n = 1024 (profiles/r04/ab_ftnt_*.txt)
+                                  // jfa_first_two 0.238 -> 0.222 ms at n = 512, 1.61 -> 1.50 ms at n = 1024 (two boxes); at n = 2048 16.3 -> 12.5 ms on
+                                  // one box and 17.6 -> 17.9 on another (profiles/r04/ab_ftnt_*.txt)
 #endif
 template <class T> __device__ __forceinline__ void ft_store(T* p, T v) { if (VP_FT_STORE_NT) __builtin_nontemporal_store(v, p); else *p = v; }
 __device__ __forceinline__ void ft_store(uint2* p, uint2 v)
