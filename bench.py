@@ -60,7 +60,7 @@ def kernel_bytes(n, planes, S, ntris, nverts):
     vox = n * n * planes
     return {
         "vox_setup": 12 * ntris + 12 * nverts, "vox_scan": 0, "vox_scatter": 0, "vox_tile": 0, "vox_naive": 12 * ntris + 12 * nverts,
-        "vox_fill": 2 * vox // 8, "csg_words": 3 * vox // 8,
+        "vox_zero": vox // 8, "vox_fill": 2 * vox // 8, "csg_words": 3 * vox // 8,
         "surface": 2 * vox // 8, "jfa_init": vox // 8 + S * vox,
         "jfa_first": S * vox + vox // 8,                 # pure store stream + the border mask
         "jfa_sparse": 2 * S * vox, "jfa_dense": 2 * S * vox, "jfa_pass": 2 * S * vox,

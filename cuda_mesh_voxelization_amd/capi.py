@@ -15,7 +15,7 @@ EXTRACT_SET, EXTRACT_EXPOSED = 0, 1
 MULTI_HALO, MULTI_GHOST, MULTI_HYBRID = 0, 1, 2
 
 KERNELS = ["vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
-           "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract"]
+           "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract", "vox_zero"]
 JFA_PASS_KEYS = ("jfa_pass", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last")
 
 # every symbol include/vphip.h declares (tests check the library exports all of them)

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 
 namespace vp {
 
@@ -120,7 +121,7 @@ static void grid_written(vp_ctx* ctx, const void* d_ptr)
 
 static const char* kNames[VP_K_COUNT] = {
     "vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
-    "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract"
+    "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract", "vox_zero"
 };
 
 }  // namespace vp
@@ -280,12 +281,21 @@ int vp_download(vp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 size_t vp_grid_words(const vp_frame* f) { return f ? (size_t)f->n * f->n * (f->z1 - f->z0) / 32 : 0; }
 size_t vp_grid_voxels(const vp_frame* f) { return f ? (size_t)f->n * f->n * (f->z1 - f->z0) : 0; }
 
+// Every grid / id / sdf buffer handed in must be 16-byte aligned (include/vphip.h): the kernels move them as 16-byte vectors.
+static int check_aligned(const char* who, std::initializer_list<const void*> ptrs)
+{
+    for (const void* p : ptrs)
+        if (reinterpret_cast<uintptr_t>(p) & 15u) return set_error(VP_ERR_INVALID, "%s: device buffer %p is not 16-byte aligned", who, p);
+    return 0;
+}
+
 int vp_voxelize(vp_ctx* ctx, const vp_frame* f, uint32_t* d_words, const float* d_xyz, size_t nverts,
                 const uint32_t* d_tri, size_t ntris, int algo, int accumulate)
 {
     if (!ctx || !d_words) return set_error(VP_ERR_INVALID, "vp_voxelize: null argument");
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_voxelize", false));
+    VP_TRY(check_aligned("vp_voxelize", {d_words}));
     if (ntris && (!d_xyz || !d_tri || !nverts)) return set_error(VP_ERR_INVALID, "vp_voxelize: null mesh arrays");
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_voxelize: algo %d", algo);
     if (ntris > 0xFFFFFFFFull / 3) return set_error(VP_ERR_UNSUPPORTED, "vp_voxelize: too many triangles");
@@ -298,6 +308,7 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
     if (!ctx || ((!d_a || !d_b) && nwords)) return set_error(VP_ERR_INVALID, "vp_csg: null argument");
     VP_TRY(bind_device(ctx));
     if (op < VP_OP_VOID || op > VP_OP_DIFFERENCE) return set_error(VP_ERR_INVALID, "vp_csg: unknown op %d", op);
+    VP_TRY(check_aligned("vp_csg", {d_a, d_b}));
     grid_written(ctx, d_a);
     return launch_csg(ctx, d_a, d_b, nwords, op);
 }
@@ -331,6 +342,7 @@ int vp_jfa_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const u
     if (!ctx || !d_words || !d_ids) return set_error(VP_ERR_INVALID, "vp_jfa_init: null argument");
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_init", false));
+    VP_TRY(check_aligned("vp_jfa_init", {d_words, d_plane_below, d_plane_above, d_ids}));
     return launch_jfa_init(ctx, make_frame(f), d_words, d_plane_below, d_plane_above, d_ids, nullptr);
 }
 
@@ -340,6 +352,7 @@ int vp_surface(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const ui
     if (!ctx || !d_words || !d_border_words) return set_error(VP_ERR_INVALID, "vp_surface: null argument");
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_surface", false));
+    VP_TRY(check_aligned("vp_surface", {d_words, d_plane_below, d_plane_above, d_border_words}));
     return launch_jfa_init(ctx, make_frame(f), d_words, d_plane_below, d_plane_above, nullptr, d_border_words);
 }
 
@@ -349,6 +362,7 @@ int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const void* d_in, co
     if (!ctx || !d_in || !d_out || d_in == d_out) return set_error(VP_ERR_INVALID, "vp_jfa_pass: bad buffers");
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_pass", false));
+    VP_TRY(check_aligned("vp_jfa_pass", {d_in, d_minus, d_plus, d_out}));
     if (k == 0 || k >= f->n) return set_error(VP_ERR_INVALID, "vp_jfa_pass: step %u out of range", k);
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_jfa_pass: algo %d", algo);
     // halos are mandatory wherever a neighbour plane exists outside the slab
@@ -374,6 +388,7 @@ static int jfa_check(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, vo
     if (!ctx || !d_words) return set_error(VP_ERR_INVALID, "%s: null argument", who);
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, who, true));
+    VP_TRY(check_aligned(who, {d_words, d_work}));
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "%s: algo %d", who, algo);
     if (!d_work) {                                                 // context-owned workspace (grow-only, reused by later calls)
         const void* before = ctx->jfa_work.ptr;
@@ -404,6 +419,7 @@ int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fi
                void* d_work, size_t work_bytes, int algo)
 {
     if (!d_sdf) return set_error(VP_ERR_INVALID, "vp_jfa_run: null argument");
+    VP_TRY(check_aligned("vp_jfa_run", {d_sdf}));
     VP_TRY(jfa_check(ctx, f, d_words, d_work, work_bytes, algo, "vp_jfa_run"));
     VP_TRY(check_fill(fill_unset, "vp_jfa_run"));
     Frame fr = make_frame(f);
@@ -441,6 +457,7 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
            void* d_work, size_t work_bytes, int algo)
 {
     if (!d_sdf) return set_error(VP_ERR_INVALID, "vp_jfa: null argument");
+    VP_TRY(check_aligned("vp_jfa", {d_sdf}));
     VP_TRY(check_fill(fill_unset, "vp_jfa"));
     VP_TRY(vp_jfa_start(ctx, f, d_words, d_work, work_bytes, algo));
     return vp_jfa_run(ctx, f, d_words, fill_unset, d_sdf, d_work, work_bytes, algo);
@@ -463,6 +480,7 @@ int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_g
     if (!ctx || !d_border_grid || !d_out) return set_error(VP_ERR_INVALID, "vp_jfa_first_pass: null argument");
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_first_pass", false));
+    VP_TRY(check_aligned("vp_jfa_first_pass", {d_border_grid, d_out}));
     const Frame fr = make_frame(f);
     if (!jfa_can_start_from_mask(fr, VP_ALGO_TILED))
         return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_pass: needs n >= 256 and n %% 128 == 0");
@@ -479,6 +497,7 @@ int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_gr
     if (!ctx || !d_border_grid || !d_out) return set_error(VP_ERR_INVALID, "vp_jfa_first_two: null argument");
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_first_two", false));
+    VP_TRY(check_aligned("vp_jfa_first_two", {d_border_grid, d_out}));
     const Frame fr = make_frame(f);
     if (!jfa_can_fuse_first_two(fr, VP_ALGO_TILED))
         return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_two: needs a whole-grid frame with n >= 256 and n %% 128 == 0");
@@ -492,6 +511,7 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
         return set_error(VP_ERR_INVALID, "vp_jfa_last_pass: bad buffers");
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_last_pass", false));
+    VP_TRY(check_aligned("vp_jfa_last_pass", {d_in, d_minus, d_plus, d_words, d_sdf}));
     VP_TRY(check_fill(fill_unset, "vp_jfa_last_pass"));
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_jfa_last_pass: algo %d", algo);
     if (f->z0 > 0 && !d_minus) return set_error(VP_ERR_INVALID, "vp_jfa_last_pass: slab needs d_minus");

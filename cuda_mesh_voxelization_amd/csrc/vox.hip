@@ -397,6 +397,17 @@ vox_fill_row(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_
     }
 }
 
+// The toggle grid and the tile histogram start from zero: one launch for both (two hipMemsetAsync calls were two runtime fill kernels,
+// ~21 us for the 16 MiB grid of n = 512 and a launch for the 64 KiB histogram: profiles/r04/bench_kernel_stats.csv).
+__global__ void __launch_bounds__(256)
+vox_zero(uint4* __restrict__ grid, size_t nvec, uint32_t* __restrict__ cnt, uint32_t ncnt)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = t0; i < nvec; i += stride) grid[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = t0; i < ncnt; i += stride) cnt[i] = 0u;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -441,9 +452,16 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
         VP_TRY(reserve(ctx, ctx->scratch, nwords * 4));
         tog = (uint32_t*)ctx->scratch.ptr;
     }
-    VP_HIP(hipMemsetAsync(tog, 0, nwords * 4, st));
+    // nwords is a multiple of 8 n (n % 32 == 0): whole uint4s; d_words is 16-byte aligned (checked at the ABI), the scratch grid is ours
+    auto zero = [&](uint32_t* cnt, uint32_t ncnt) {
+        const size_t nvec = nwords / 4;
+        const unsigned blocks = (unsigned)std::min<size_t>((nvec + 255) / 256, 256 * 16);
+        ProfScope p(ctx, VP_K_VOX_ZERO);
+        hipLaunchKernelGGL(vox_zero, dim3(blocks), dim3(256), 0, st, (uint4*)tog, nvec, cnt, ncnt);
+    };
 
     if (algo == VP_ALGO_NAIVE) {
+        zero(nullptr, 0);
         if (ntris) {
             ProfScope p(ctx, VP_K_VOX_NAIVE);
             hipLaunchKernelGGL(vox_naive, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, tog);
@@ -485,7 +503,7 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
         uint32_t* pairs = (uint32_t*)ctx->pairs.ptr;
         uint32_t pcap = (uint32_t)std::min<size_t>(ctx->pairs.bytes / 4, 0xFFFFFFFFu);
         if (const char* e = getenv("VP_VOX_QUEUE_CAP")) pcap = std::min<uint32_t>(pcap, (uint32_t)strtoul(e, nullptr, 10));   // tests: force the overflow path
-        VP_HIP(hipMemsetAsync(cnt, 0, ((size_t)numTiles + 1) * 4, st));
+        zero(cnt, numTiles + 1u);
         {
             ProfScope p(ctx, VP_K_VOX_SETUP);
             hipLaunchKernelGGL(vox_setup, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, rec, rcap,
@@ -514,6 +532,8 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
             ProfScope p(ctx, VP_K_VOX_TILE);
             hipLaunchKernelGGL(vox_tile, dim3(numTiles), dim3(256), 0, st, f, rec, d_nbig, rcap, off, pairs, pcap, tog);
         }
+    } else {
+        zero(nullptr, 0);                                          // no triangles: an empty grid (or nothing to XOR in)
     }
     VP_TRY(launch_fill(ctx, f, tog, d_words, accumulate));
     VP_HIP(hipGetLastError());

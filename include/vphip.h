@@ -71,7 +71,10 @@ int vp_ctx_sync(vp_ctx* ctx);
 const char* vp_last_error(void);
 int vp_abi_version(void);
 
-/* ---- device memory (CudaPtr<T> equivalent, vplib/src/cuda_ptr.h:24-93) --------------------- */
+/* ---- device memory (CudaPtr<T> equivalent, vplib/src/cuda_ptr.h:24-93) ---------------------
+ * Alignment contract: every grid, id, sdf and workspace buffer handed to the entry points below must be 16-byte aligned -- what
+ * hipMalloc, vp_malloc and the usual framework allocators return; the kernels move these buffers as 16-byte vectors.  A pointer
+ * that is not is refused with VP_ERR_INVALID (slab planes inside such a buffer are aligned by construction: n % 32 == 0). */
 int vp_malloc(vp_ctx* ctx, size_t bytes, void** d_out);
 int vp_free(vp_ctx* ctx, void* d_ptr);
 int vp_memset(vp_ctx* ctx, void* d_ptr, int byte_value, size_t bytes);           /* async */
@@ -293,6 +296,7 @@ enum {
     VP_K_JFA_DENSE,     /* k <  n/4: 2 S n^3 */
     VP_K_JFA_LAST,      /* k = 1 fused with the id -> sdf conversion: S n^3 + 4 n^3 + n^3/8 */
     VP_K_EXTRACT,       /* vp_extract_count / vp_extract: 2 n^3/8 + records */
+    VP_K_VOX_ZERO,      /* the voxelizer's zero-fill of the toggle grid (+ the tile histogram): n^3/8 */
     VP_K_COUNT
 };
 int vp_prof_enable(vp_ctx* ctx, int on);

@@ -245,6 +245,26 @@ def test_jfa_run_needs_its_own_start(engine):
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
 
 
+def test_misaligned_device_buffers_are_refused(engine):
+    """include/vphip.h: grid / id / sdf buffers must be 16-byte aligned (the kernels move them as 16-byte vectors); a pointer that is
+    not comes back as VP_ERR_INVALID instead of a memory fault."""
+    import torch
+    n = 128
+    fr = Frame.make(n, 0.1, (0.0, 0.0, 0.0))
+    xyz, tri = M.import_mesh(M.asset("d20.obj"))
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    g = torch.zeros(fr.words + 4, dtype=torch.int32, device=engine.device)
+    s = torch.empty(fr.voxels + 4, dtype=torch.float32, device=engine.device)
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        engine.ctx.voxelize(fr, g.data_ptr() + 4, dx.data_ptr(), dx.shape[0], dt.data_ptr(), dt.shape[0], ALGO_TILED, 0)
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        engine.ctx.jfa(fr, g.data_ptr(), -math.inf, s.data_ptr() + 4, None, 0, ALGO_TILED)
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        engine.ctx.csg(g.data_ptr() + 8, g.data_ptr(), 16, 1)
+    engine.ctx.voxelize(fr, g.data_ptr(), dx.data_ptr(), dx.shape[0], dt.data_ptr(), dt.shape[0], ALGO_TILED, 0)   # aligned: fine
+    engine.sync()
+
+
 def test_stream_copy_copies_and_checks_alignment(engine):
     """vp_stream_copy: the copy kernel bench.py measures the box's HBM rate with -- it must at least copy."""
     src = torch.arange(1 << 20, dtype=torch.int32, device=engine.device)
