@@ -483,7 +483,7 @@ int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_g
     VP_TRY(check_aligned("vp_jfa_first_pass", {d_border_grid, d_out}));
     const Frame fr = make_frame(f);
     if (!jfa_can_start_from_mask(fr, VP_ALGO_TILED))
-        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_pass: needs n >= 256 and n %% 128 == 0");
+        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_pass: needs n %% 128 == 0");
     return launch_jfa_first_pass(ctx, fr, d_border_grid, d_out);
 }
 
@@ -500,7 +500,7 @@ int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_gr
     VP_TRY(check_aligned("vp_jfa_first_two", {d_border_grid, d_out}));
     const Frame fr = make_frame(f);
     if (!jfa_can_fuse_first_two(fr, VP_ALGO_TILED))
-        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_two: needs a whole-grid frame with n >= 256 and n %% 128 == 0");
+        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_two: needs a whole-grid frame with n %% 128 == 0");
     return launch_jfa_first_two(ctx, fr, d_border_grid, d_out);
 }
 
@@ -546,7 +546,7 @@ static int volume_check(vp_ctx* ctx, const vp_frame* f, const char* who, Frame& 
     whole = make_frame(&w);
     region = make_frame(f);
     if (!jfa_can_fuse_first_two(whole, VP_ALGO_TILED))
-        return set_error(VP_ERR_UNSUPPORTED, "%s: the volume calls need n >= 256 and n %% 128 == 0 (VP_ALGO_TILED)", who);
+        return set_error(VP_ERR_UNSUPPORTED, "%s: the volume calls need n %% 128 == 0 (VP_ALGO_TILED)", who);
     region.compact = whole.compact = volume_compact(whole) ? 1u : 0u;
     planeBytes = (size_t)f->n * f->n * (region.compact ? 4 : jfa_id_bytes(whole));   // of the (word) plane the passes address
     return 0;

@@ -18,7 +18,7 @@
 //                   stores after a wave shuffle transposes word-per-lane into voxels-per-lane.
 //   jfa_first_pass  step k = n/2 straight from the border bitmask (no init id volume).
 //   jfa_pass_direct (VP_ALGO_NAIVE) one thread per voxel, everything recomputed inline.
-//   jfa_pass_zstream (VP_ALGO_TILED, n >= 256) LDS coordinate tables; a workgroup owns a tile of rows x planes that
+//   jfa_pass_zstream (VP_ALGO_TILED, n >= 96) LDS coordinate tables; a workgroup owns a tile of rows x planes that
 //                   are k apart, reads every source plane once and scatters each id into the outputs it is a
 //                   candidate for; jfa_pass_table is the small-n variant.
 //   jfa_final       ids + bitmask -> float sdf.
@@ -118,6 +118,12 @@ struct Id64 {                     // n <= 2048: .x = scr(z)<<2 | x<<13, .y = scr
 // slots 2048 .. 3071, which hold +inf (the tile kernel's z table has 3072 entries for this format): "none" gets an infinite distance
 // through the ordinary lookup, as it does through slot TAB of the x table in IdU.
 // Everything stays per lane (a dword and a byte load / store per id): no cross-lane packing of bit planes.
+#ifndef VP_TILE_MIN_N
+#define VP_TILE_MIN_N 96            // VP_ALGO_TILED runs the tile kernels from this side on (n % 32 == 0: 96, 128, ...); the table kernel of round 1 below it.
+                                   // Rounds 1 - 3 drew the line at 256: whole step (voxelize + JFA, bunny) 0.294 -> 0.153 ms at n = 128, 0.65 -> 0.21 at 160,
+                                   // 0.92 -> 0.27 at 192, 1.50 -> 0.34 ms at 224; at 96 0.148 -> 0.139; at 64 / 32 the table kernel wins (0.063 / 0.061 against
+                                   // 0.117 / 0.102 ms: launch-bound) -- tools/ab_wall.py, profiles/r04/ab_tilemin.txt
+#endif
 #ifndef VP_IDC_NONE_Z
 #define VP_IDC_NONE_Z 1             // 0: the first form of round 4 -- "none" in bit 0 of the byte, merged into the x offset (slot 2048 of the x table):
                                     // 3 more VALU per decoded id (5340 -> 4987 per 32 outputs); dense pass at n = 2048 34.8 -> 34.0 ms, step 327.2 ->
@@ -459,14 +465,14 @@ jfa_first_pass(Frame f, uint32_t k, const uint32_t* __restrict__ border, typenam
 
 constexpr int kTableKernelTab = 1024;   // entries per table of jfa_pass_table (every field offset of Id9, "none" included, stays inside)
 
-// Table variant for small grids (n < 256, 32-bit ids).  Workgroup = RY consecutive x-rows of one z.
+// Table variant for small grids (n < VP_TILE_MIN_N = 96, 32-bit ids).  Workgroup = RY consecutive x-rows of one z.
 // LDS: PX[i] = ox + i*vs; TZ[i] = (PZ[i]-pz)^2 for this z; TY[r][i] = (PY[i]-py_r)^2 for row r.
 // dist = ((PX[ix]-px)^2 + TY[iy]) + TZ[iz]  -- the same float operations as seed_distance().
 __global__ void __launch_bounds__(256)
 jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint32_t* __restrict__ minus,
                const uint32_t* __restrict__ plus, uint32_t* __restrict__ out, int RY)
 {
-    using ID = Id9;                                                // n < 256
+    using ID = Id9;                                                // n < 96
     constexpr int kTab = kTableKernelTab;
     extern __shared__ float lds[];
     float* PX = lds;
@@ -549,7 +555,7 @@ jfa_pass_table(Frame f, uint32_t k, const uint32_t* __restrict__ in, const uint3
 }
 
 // ------------------------------------------------------------------------------------------ z-stream
-// Fast path for n >= 256.  A workgroup owns a TILE of RY output rows x CH output planes, both k apart:
+// Fast path for n >= VP_TILE_MIN_N.  A workgroup owns a TILE of RY output rows x CH output planes, both k apart:
 // rows y_a = y0 + a*k, planes z_j = z0 + j*k.  Output (y_a, z_j) takes its candidates from rows y_a - k, y_a,
 // y_a + k of planes z_j - k, z_j, z_j + k, i.e. from the tile's own rows / planes and one halo row / plane on each
 // side.  Every source plane of the tile is therefore read ONCE -- (RY+2) rows x columns {x-k, x, x+k} per thread --
@@ -2182,7 +2188,7 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, c
     return launch_jfa_pass_ex(ctx, f, k, d_in, d_minus, d_plus, d_out, algo, nullptr, 0.0f, nullptr);
 }
 
-bool jfa_can_start_from_mask(const Frame& f, int algo) { return algo == VP_ALGO_TILED && f.n >= 256 && f.n % 128 == 0; }
+bool jfa_can_start_from_mask(const Frame& f, int algo) { return algo == VP_ALGO_TILED && f.n >= VP_TILE_MIN_N && f.n % 128 == 0; }
 
 // Compact id state (IdC) for the whole-grid sequence of vp_jfa at n > 1024: first two passes fused from the border mask, every later
 // pass on the tile kernel -- all buffers are the call's own workspace, so the layout never meets a caller (the slab entry points keep
@@ -2258,7 +2264,7 @@ int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border,
 bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo)
 {
     (void)k;
-    return algo == VP_ALGO_TILED && f.n >= 256;
+    return algo == VP_ALGO_TILED && f.n >= VP_TILE_MIN_N;
 }
 #endif  // VP_PART_MAIN
 
@@ -2535,7 +2541,7 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
 {
     const uint32_t nz = f.z1 - f.z0;
     // timing key: the tile kernels are reported per variant (their algorithmic bytes differ)
-    const bool tile = algo != VP_ALGO_NAIVE && f.n >= 256;
+    const bool tile = algo != VP_ALGO_NAIVE && f.n >= VP_TILE_MIN_N;
     ProfScope p(ctx, !tile ? VP_K_JFA_PASS : d_sdf ? VP_K_JFA_LAST : k * 4 >= f.n ? VP_K_JFA_SPARSE : VP_K_JFA_DENSE);
     if (algo == VP_ALGO_NAIVE) {
         const dim3 blocks(f.n * f.n / 256, nz);
@@ -2548,7 +2554,7 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
         else
             hipLaunchKernelGGL(jfa_pass_direct<Id10>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
                                (const uint32_t*)d_minus, (const uint32_t*)d_plus, (uint32_t*)d_out);
-    } else if (f.n >= 256 && seeds_applies(f, k, d_sdf != nullptr)) {
+    } else if (f.n >= VP_TILE_MIN_N && seeds_applies(f, k, d_sdf != nullptr)) {
         // tile = 4 x 4 x 4 chain positions x 32 residues = 2,048 voxels (28 KB of LDS), 512 threads = 4 voxels each.  Measured
         // (profiles/r02/ab28.txt, ab29.txt): 16 x 256 -14 %, 32 x 512 -16 % (n = 512) / -28 % (n = 1024) against
         // jfa_pass_zstream<SKIP>; 2 or 8 voxels per thread, 64-byte and 256-byte segments are all slower than that
@@ -2560,12 +2566,12 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
         if (wide(f))         hipLaunchKernelGGL((jfa_pass_seeds<Id64, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint2*)d_in, (uint2*)d_out);
         else if (f.n <= 512) hipLaunchKernelGGL((jfa_pass_seeds<Id9, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
         else                 hipLaunchKernelGGL((jfa_pass_seeds<Id10, VP_SEEDS_XR, VP_SEEDS_NT>), grid, dim3(VP_SEEDS_NT), 0, ctx->stream, f, k, (const uint32_t*)d_in, (uint32_t*)d_out);
-    } else if (f.n >= 256 && dense_applies(f, k, d_in, d_minus, d_plus, d_sdf != nullptr)) {
+    } else if (f.n >= VP_TILE_MIN_N && dense_applies(f, k, d_in, d_minus, d_plus, d_sdf != nullptr)) {
         if (f.compact)       VP_TRY(launch_dense_idc(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
         else if (wide(f))    VP_TRY(launch_dense_id64(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
         else if (f.n <= 512) VP_TRY(launch_dense_id9(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
         else                 VP_TRY(launch_dense_id10(ctx, f, k, d_in, d_out, d_words, fill, d_sdf));
-    } else if (f.n >= 256) {
+    } else if (f.n >= VP_TILE_MIN_N) {
         if (wide(f)) VP_TRY(launch_chain<Id64>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
         else if (f.n <= 512) VP_TRY(launch_chain<Id9>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));
         else         VP_TRY(launch_chain<Id10>(ctx, f, k, d_in, d_minus, d_plus, d_out, d_words, fill, d_sdf));

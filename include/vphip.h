@@ -179,7 +179,7 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
                      const void* d_plus, void* d_scratch, const uint32_t* d_words, float fill_unset,
                      float* d_sdf, int algo);
 
-/* Sparse start (n >= 256, n % 128 == 0, VP_ALGO_TILED; vp_jfa uses it internally).  Before any pass a border
+/* Sparse start (n % 128 == 0, VP_ALGO_TILED; vp_jfa uses it internally).  Before any pass a border
  * voxel's seed is itself and nothing else has one (jfa/sequential.cpp:55-60), so the first pass (k = n/2) can run
  * straight from the border bitmask of the WHOLE grid (vp_surface on a whole-grid frame): no init id volume is
  * written or read.  vp_jfa_first_pass produces the ids after step n/2 for the planes of f; the result is
@@ -196,7 +196,7 @@ int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_gr
  * planes its later passes reach: no exchange between passes).  The caller no longer offsets pointers by plane -- it passes the volume
  * base and a frame whose [z0, z1) is the region to produce -- so the layout inside a volume is the library's: vp_jfa_volume_bytes(f)
  * per volume, plain 4-byte ids up to n = 1024 and the compact 5-byte state above (a 32-bit word plane + a byte plane; 40 instead of
- * 64 GiB per volume at n = 2048, and 10 instead of 16 bytes per voxel and pass).  Needs n >= 256, n % 128 == 0 (VP_ALGO_TILED).
+ * 64 GiB per volume at n = 2048, and 10 instead of 16 bytes per voxel and pass).  Needs n % 128 == 0 (VP_ALGO_TILED).
  *   vp_jfa_volume_first_two  passes n/2 and n/4 of the whole grid from its border mask (vp_surface on a whole-grid frame)
  *   vp_jfa_volume_pass       one pass with step k <= n/8 over the planes [z0, z1) of f; reads the planes z0-k .. z1+k of d_vol_in
  *   vp_jfa_volume_last_pass  step 1 fused with the id -> sdf conversion; d_words_region / d_sdf_region hold the planes [z0, z1) only
@@ -288,9 +288,9 @@ int vp_jfa_host(vp_ctx* ctx, const vp_frame* f, const uint32_t* h_words, float f
 enum {
     VP_K_VOX_SETUP = 0, VP_K_VOX_SCAN, VP_K_VOX_SCATTER, VP_K_VOX_TILE, VP_K_VOX_NAIVE,
     VP_K_VOX_FILL, VP_K_CSG, VP_K_JFA_INIT,
-    VP_K_JFA_PASS,      /* direct kernel (VP_ALGO_NAIVE) and the small-grid table kernel (n < 256) */
+    VP_K_JFA_PASS,      /* direct kernel (VP_ALGO_NAIVE) and the small-grid table kernel (n < 96) */
     VP_K_JFA_FINAL, VP_K_SURFACE,
-    /* the tile kernels of VP_ALGO_TILED (n >= 256), one key per variant -- their algorithmic bytes differ: */
+    /* the tile kernels of VP_ALGO_TILED (n >= 96), one key per variant -- their algorithmic bytes differ: */
     VP_K_JFA_FIRST,     /* k = n/2 straight from the border mask: 4 n^3 + n^3/8 bytes (S = 4) */
     VP_K_JFA_SPARSE,    /* k >= n/4: 2 S n^3 */
     VP_K_JFA_DENSE,     /* k <  n/4: 2 S n^3 */

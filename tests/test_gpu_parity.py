@@ -503,12 +503,13 @@ def test_headline_size_properties(engine):
     assert float(np.abs(s).max()) <= 3.0 * (512 * float(vs)) ** 2
 
 
-@pytest.mark.parametrize("n,against_oracle", [(288, True), (352, False), (544, False)])
+@pytest.mark.parametrize("n,against_oracle", [(96, True), (128, True), (160, False), (224, True), (288, True), (352, False), (544, False)])
 def test_jfa_tile_kernel_ragged_sizes(engine, n, against_oracle):
-    """n >= 256 that are not powers of two: the row x plane tiles of jfa_pass_zstream are ragged (n / k is not a
+    """sizes that are not powers of two: the row x plane tiles of jfa_pass_zstream are ragged (n / k is not a
     multiple of the tile, for n = 352 not even an integer), the first pass from the mask does not apply (n % 128 != 0)
-    and n = 544 runs the 1024-entry tables without the explicit none check.  Tiled against the naive kernel, and for
-    n = 288 against the oracle."""
+    and n = 544 runs the 1024-entry tables without the explicit none check; n = 96 ... 224 (round 4: the tile kernels start at n = 96, the
+    table kernel of round 1 serves 32 and 64 only) have rows shorter than a workgroup.  Tiled against the naive kernel, and against the
+    oracle where marked."""
     xyz, tri = M.bunny(1)
     fr, origin, vs = _frame([(xyz, tri)], n)
     dx, dt = engine.mesh_to_device(xyz, tri)
@@ -691,7 +692,8 @@ def test_extract_records_match_numpy(engine):
                 assert np.array_equal(r2[:10].view(np.uint64), exp[:10]) and (r2[10:] == -1).all()
 
 
-@pytest.mark.parametrize("n,kind", [(512, "noise"), (512, "sparse"), (512, "mesh"), (1024, "sparse"), (288, "noise"), (1152, "noise"), (256, "noise"), (1024, "noise")])
+@pytest.mark.parametrize("n,kind", [(512, "noise"), (512, "sparse"), (512, "mesh"), (1024, "sparse"), (288, "noise"), (1152, "noise"), (256, "noise"), (1024, "noise"),
+                                    (96, "noise"), (128, "noise"), (128, "sparse"), (160, "sparse"), (224, "noise")])
 def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
     """Pass by pass, on the SAME input state: the packed seed ids the tile kernels write (sparse, dense with the
     v_min_f64 pair update, every k; and the first pass in its from-the-border-mask form) equal those of the one-thread-per-voxel kernel, which walks the 27
