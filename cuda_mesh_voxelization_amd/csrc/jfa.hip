@@ -2208,6 +2208,19 @@ bool jfa_can_fuse_first_two(const Frame& f, int algo)
     static const int enabled = env_int("VP_JFA_FIRST_TWO", VP_JFA_FIRST_TWO_DEFAULT);
     return enabled && jfa_can_start_from_mask(f, algo) && f.z0 == 0 && f.z1 == f.n && f.n / 8 >= 1;
 }
+// The whole-grid sequence of vp_jfa takes the fused start at EVERY side the tile kernels serve: the chains {r, r + n/4, r + n/2, r + 3n/4}
+// are closed for any n % 4 == 0 (every legal n), a tile whose 16 / 32 residues reach past n/4 masks the excess lanes.  The n % 128 == 0 of
+// jfa_can_fuse_first_two (what the slab pipelines and the exported predicate promise) comes from jfa_first_pass, the one-pass form they
+// fall back to.  Measured (tools/size_sweep.sh, profiles/r04/size_sweep.txt): whole step 2.89 -> 2.47 ms at n = 480, 5.95 -> 4.55 at 544, 29.3 -> 23.6 at 960.
+#ifndef VP_FIRST_TWO_ANY_N
+#define VP_FIRST_TWO_ANY_N 1
+#endif
+bool jfa_whole_first_two(const Frame& f, int algo)
+{
+    static const int enabled = env_int("VP_JFA_FIRST_TWO", VP_JFA_FIRST_TWO_DEFAULT);
+    if (jfa_can_fuse_first_two(f, algo)) return true;
+    return VP_FIRST_TWO_ANY_N && enabled && algo == VP_ALGO_TILED && f.n >= VP_TILE_MIN_N && f.z0 == 0 && f.z1 == f.n;
+}
 
 #ifndef VP_FIRST_TWO_TPW
 #define VP_FIRST_TWO_TPW 2        // tiles per workgroup.  Round 3, without the census fast path (profiles/r03/ab_tpw_*.txt): 1 / 2 / 4 / 8 tiles = 0.371 / 0.373 / 0.370 / 0.406 ms

@@ -106,7 +106,7 @@ while time.time() < t_end:
             if bad: err = "algo %d: %d words differ" % (algo, bad)
         desc = "n=%d tris=%d" % (n, tri.shape[0])
     else:
-        n = int(rng.choice([64, 96, 128, 160, 256, 288, 384, 512, 640] if what == "ids" else [64, 128, 224, 256, 384, 512, 768, 1024, 1152, 1280]))
+        n = int(rng.choice([64, 96, 128, 160, 256, 288, 384, 512, 640] if what == "ids" else [64, 96, 128, 160, 224, 256, 288, 352, 384, 480, 512, 544, 608, 768, 832, 1024, 1056, 1152, 1280]))
         fr = Frame.make(n, vs, tuple(float(v) for v in origin))
         g, kind = grid(rng, n)
         desc = "n=%d %s" % (n, kind)
