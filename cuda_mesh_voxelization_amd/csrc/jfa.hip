@@ -2196,7 +2196,7 @@ bool jfa_can_start_from_mask(const Frame& f, int algo) { return algo == VP_ALGO_
 bool jfa_compact_applies(const Frame& f, int algo)
 {
     static const int enabled = env_int("VP_JFA_COMPACT", 1);
-    return enabled && wide(f) && jfa_can_fuse_first_two(f, algo);
+    return enabled && wide(f) && jfa_whole_first_two(f, algo);      // (the volume calls of the slab pipelines ask only where n % 128 == 0: the same answer there)
 }
 
 // Passes k = n/2 and k = n/4 of a whole grid from its border mask in one launch (jfa_first_two); timed as the first pass.

@@ -16,6 +16,7 @@ from oracle import oracle as O
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=600.0); ap.add_argument("--seed0", type=int, default=1000)
+ap.add_argument("--sdf-sizes", default="", help="comma-separated grid sides for the sdf cases (default: the built-in list)")
 a = ap.parse_args()
 eng = Engine(0)
 
@@ -106,7 +107,7 @@ while time.time() < t_end:
             if bad: err = "algo %d: %d words differ" % (algo, bad)
         desc = "n=%d tris=%d" % (n, tri.shape[0])
     else:
-        n = int(rng.choice([64, 96, 128, 160, 256, 288, 384, 512, 640] if what == "ids" else [64, 96, 128, 160, 224, 256, 288, 352, 384, 480, 512, 544, 608, 768, 832, 1024, 1056, 1152, 1280]))
+        n = int(rng.choice([64, 96, 128, 160, 256, 288, 384, 512, 640] if what == "ids" else ([int(v) for v in a.sdf_sizes.split(",")] if a.sdf_sizes else [64, 96, 128, 160, 224, 256, 288, 352, 384, 480, 512, 544, 608, 768, 832, 1024, 1056, 1152, 1280])))
         fr = Frame.make(n, vs, tuple(float(v) for v in origin))
         g, kind = grid(rng, n)
         desc = "n=%d %s" % (n, kind)
