@@ -407,7 +407,7 @@ int vp_jfa_start(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void* 
     const Frame fr = make_frame(f);
     const size_t volBytes = vp_grid_voxels(f) * vp_jfa_id_bytes(f);
     char* a = (char*)d_work;
-    const bool mask = (jfa_can_start_from_mask(fr, algo) || jfa_whole_first_two(fr, algo)) && f->n / 2 > 1;
+    const bool mask = (jfa_can_start_from_mask(fr, algo) || jfa_can_fuse_first_two(fr, algo)) && f->n / 2 > 1;
     ctx->jfa_started.valid = false;
     if (mask) VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, nullptr, (uint32_t*)(a + 2 * volBytes)));   // border mask only
     else      VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, a, nullptr));
@@ -432,12 +432,12 @@ int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fi
     fr.compact = jfa_compact_applies(fr, algo) ? 1u : 0u;
     // The workspace must hold what THIS sequence starts from: the record of the matching vp_jfa_start (same grid, frame size,
     // algo and workspace).  One start serves one run: the passes overwrite the volumes.
-    const bool wantMask = (jfa_can_start_from_mask(fr, algo) || jfa_whole_first_two(fr, algo)) && k > 1;
+    const bool wantMask = (jfa_can_start_from_mask(fr, algo) || jfa_can_fuse_first_two(fr, algo)) && k > 1;
     const vp_ctx::JfaStarted st = ctx->jfa_started;
     ctx->jfa_started.valid = false;
     if (!st.valid || st.n != f->n || st.algo != algo || st.work != d_work || st.words != d_words || st.mask != wantMask)
         return set_error(VP_ERR_INVALID, "vp_jfa_run: call vp_jfa_start with the same grid, frame, algo and workspace first");
-    if (jfa_whole_first_two(fr, algo)) {
+    if (jfa_can_fuse_first_two(fr, algo)) {
         VP_TRY(launch_jfa_first_two(ctx, fr, (const uint32_t*)(b + volBytes), a));    // passes n/2 and n/4 straight from the border mask
         k /= 4;
     } else if (jfa_can_start_from_mask(fr, algo) && k > 1) {
@@ -500,7 +500,7 @@ int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_gr
     VP_TRY(check_aligned("vp_jfa_first_two", {d_border_grid, d_out}));
     const Frame fr = make_frame(f);
     if (!jfa_can_fuse_first_two(fr, VP_ALGO_TILED))
-        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_two: needs a whole-grid frame with n %% 128 == 0");
+        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_two: needs a whole-grid frame with n >= 96 (VP_ALGO_TILED)");
     return launch_jfa_first_two(ctx, fr, d_border_grid, d_out);
 }
 
@@ -546,7 +546,7 @@ static int volume_check(vp_ctx* ctx, const vp_frame* f, const char* who, Frame& 
     whole = make_frame(&w);
     region = make_frame(f);
     if (!jfa_can_fuse_first_two(whole, VP_ALGO_TILED))
-        return set_error(VP_ERR_UNSUPPORTED, "%s: the volume calls need n %% 128 == 0 (VP_ALGO_TILED)", who);
+        return set_error(VP_ERR_UNSUPPORTED, "%s: the volume calls need n >= 96 (VP_ALGO_TILED)", who);
     region.compact = whole.compact = volume_compact(whole) ? 1u : 0u;
     planeBytes = (size_t)f->n * f->n * (region.compact ? 4 : jfa_id_bytes(whole));   // of the (word) plane the passes address
     return 0;

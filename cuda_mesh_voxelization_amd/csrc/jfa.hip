@@ -2196,30 +2196,24 @@ bool jfa_can_start_from_mask(const Frame& f, int algo) { return algo == VP_ALGO_
 bool jfa_compact_applies(const Frame& f, int algo)
 {
     static const int enabled = env_int("VP_JFA_COMPACT", 1);
-    return enabled && wide(f) && jfa_whole_first_two(f, algo);      // (the volume calls of the slab pipelines ask only where n % 128 == 0: the same answer there)
+    return enabled && wide(f) && jfa_can_fuse_first_two(f, algo);
 }
 
 // Passes k = n/2 and k = n/4 of a whole grid from its border mask in one launch (jfa_first_two); timed as the first pass.
 #ifndef VP_JFA_FIRST_TWO_DEFAULT
 #define VP_JFA_FIRST_TWO_DEFAULT 1
 #endif
-bool jfa_can_fuse_first_two(const Frame& f, int algo)
-{
-    static const int enabled = env_int("VP_JFA_FIRST_TWO", VP_JFA_FIRST_TWO_DEFAULT);
-    return enabled && jfa_can_start_from_mask(f, algo) && f.z0 == 0 && f.z1 == f.n && f.n / 8 >= 1;
-}
-// The whole-grid sequence of vp_jfa takes the fused start at EVERY side the tile kernels serve: the chains {r, r + n/4, r + n/2, r + 3n/4}
-// are closed for any n % 4 == 0 (every legal n), a tile whose 16 / 32 residues reach past n/4 masks the excess lanes.  The n % 128 == 0 of
-// jfa_can_fuse_first_two (what the slab pipelines and the exported predicate promise) comes from jfa_first_pass, the one-pass form they
-// fall back to.  Measured (tools/size_sweep.sh, profiles/r04/size_sweep.txt): whole step 2.89 -> 2.47 ms at n = 480, 5.95 -> 4.55 at 544, 29.3 -> 23.6 at 960.
+// The chains {r, r + n/4, r + n/2, r + 3n/4} are closed for any n % 4 == 0 (every legal n), and a tile whose 16 / 32 residues reach past n/4
+// masks the excess lanes: the fused start serves EVERY whole grid the tile kernels serve.  (Until late in round 4 it borrowed the n % 128 == 0
+// of jfa_first_pass -- the one-pass form the slab pipelines fall back to, jfa_can_start_from_mask.)  Measured (tools/size_sweep.sh,
+// profiles/r04/size_sweep.txt): whole step 2.89 -> 2.47 ms at n = 480, 5.95 -> 4.55 at 544, 29.3 -> 23.6 at 960.
 #ifndef VP_FIRST_TWO_ANY_N
 #define VP_FIRST_TWO_ANY_N 1
 #endif
-bool jfa_whole_first_two(const Frame& f, int algo)
+bool jfa_can_fuse_first_two(const Frame& f, int algo)
 {
     static const int enabled = env_int("VP_JFA_FIRST_TWO", VP_JFA_FIRST_TWO_DEFAULT);
-    if (jfa_can_fuse_first_two(f, algo)) return true;
-    return VP_FIRST_TWO_ANY_N && enabled && algo == VP_ALGO_TILED && f.n >= VP_TILE_MIN_N && f.z0 == 0 && f.z1 == f.n;
+    return enabled && algo == VP_ALGO_TILED && f.n >= VP_TILE_MIN_N && (VP_FIRST_TWO_ANY_N || f.n % 128 == 0) && f.z0 == 0 && f.z1 == f.n;
 }
 
 #ifndef VP_FIRST_TWO_TPW

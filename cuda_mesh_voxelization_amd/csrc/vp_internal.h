@@ -126,7 +126,6 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
 bool jfa_can_start_from_mask(const Frame& f, int algo);
 int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out);
 bool jfa_can_fuse_first_two(const Frame& f, int algo);          // passes n/2 and n/4 in one launch from the border mask
-bool jfa_whole_first_two(const Frame& f, int algo);             // ... as vp_jfa's own sequence decides it (any n the tile kernels serve)
 bool jfa_compact_applies(const Frame& f, int algo);             // whole-grid vp_jfa at n > 1024: 5-byte id state (jfa.hip: IdC)
 int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out);
 int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const void* d_ids,

@@ -188,7 +188,8 @@ int vp_jfa_can_start_from_mask(const vp_frame* f, int algo);
 int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out);
 /* The passes k = n/2 AND k = n/4 of a WHOLE grid in one launch from its border bitmask (vp_jfa uses it internally): identical
  * to vp_jfa_first_pass + vp_jfa_pass(k = n/4), with the first pass never written to memory.  Whole-grid frames only
- * (z0 = 0, z1 = n); a slab driver whose second pass covers most of the grid anyway may run it instead of the two region passes. */
+ * (z0 = 0, z1 = n) of any side the tile kernels serve (n >= 96; the chains of four it works on are closed for every n % 4 == 0); a slab
+ * driver whose second pass covers most of the grid anyway may run it instead of the two region passes. */
 int vp_jfa_can_fuse_first_two(const vp_frame* f, int algo);
 int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out);
 
@@ -196,7 +197,7 @@ int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_gr
  * planes its later passes reach: no exchange between passes).  The caller no longer offsets pointers by plane -- it passes the volume
  * base and a frame whose [z0, z1) is the region to produce -- so the layout inside a volume is the library's: vp_jfa_volume_bytes(f)
  * per volume, plain 4-byte ids up to n = 1024 and the compact 5-byte state above (a 32-bit word plane + a byte plane; 40 instead of
- * 64 GiB per volume at n = 2048, and 10 instead of 16 bytes per voxel and pass).  Needs n % 128 == 0 (VP_ALGO_TILED).
+ * 64 GiB per volume at n = 2048, and 10 instead of 16 bytes per voxel and pass).  Needs vp_jfa_can_fuse_first_two (n >= 96, VP_ALGO_TILED).
  *   vp_jfa_volume_first_two  passes n/2 and n/4 of the whole grid from its border mask (vp_surface on a whole-grid frame)
  *   vp_jfa_volume_pass       one pass with step k <= n/8 over the planes [z0, z1) of f; reads the planes z0-k .. z1+k of d_vol_in
  *   vp_jfa_volume_last_pass  step 1 fused with the id -> sdf conversion; d_words_region / d_sdf_region hold the planes [z0, z1) only

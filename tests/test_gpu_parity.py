@@ -506,7 +506,7 @@ def test_headline_size_properties(engine):
 @pytest.mark.parametrize("n,against_oracle", [(96, True), (128, True), (160, False), (224, True), (288, True), (352, False), (544, False)])
 def test_jfa_tile_kernel_ragged_sizes(engine, n, against_oracle):
     """sizes that are not powers of two: the row x plane tiles of jfa_pass_zstream are ragged (n / k is not a
-    multiple of the tile, for n = 352 not even an integer), the first pass from the mask does not apply (n % 128 != 0)
+    multiple of the tile, for n = 352 not even an integer), the one-pass start from the mask does not apply (n % 128 != 0; the fused two-pass start does)
     and n = 544 runs the 1024-entry tables without the explicit none check; n = 96 ... 224 (round 4: the tile kernels start at n = 96, the
     table kernel of round 1 serves 32 and 64 only) have rows shorter than a workgroup.  Tiled against the naive kernel, and against the
     oracle where marked."""
