@@ -380,20 +380,29 @@ vox_fill_vec(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t nvec
     }
 }
 
-// Fallback for rows shorter than 4 words or a non-power-of-two W: one thread per row.
+// Any other row length (W words, 1 <= W <= 64: n % 128 != 0, or W / 4 not a power of two): one lane = one word, a wave = floor(64 / W) whole
+// rows, i.e. 64 - (64 % W) CONSECUTIVE words -- loads and stores are as coalesced as in the vector form.  The carry into a word is the parity
+// of the set bits of the words before it in its row: one ballot of the word parities, masked to the lanes [row start, own lane).
+// (Round 1 - 4a: one thread per row, W strided words each: 0.029 ms at n = 480 against 0.011 at n = 512.)
 template <bool ACC>
 __global__ void __launch_bounds__(256)
-vox_fill_row(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t nrows, int W)
+vox_fill_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t nwords, uint32_t W, size_t nwaves)
 {
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    uint32_t carry = 0;
-    for (int w = 0; w < W; ++w) {
-        const uint32_t v = src[r * W + w];
-        uint32_t o = word_prefix_xor(v) ^ (0u - carry);
-        carry ^= __popc(v) & 1u;
-        if (ACC) o ^= dst[r * W + w];
-        dst[r * W + w] = o;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t perWave = (64u / W) * W;                        // words a wave handles: whole rows only
+    const uint32_t w = lane % W, start = lane - w;                 // word index in its row, first lane of the row
+    const size_t wavesPerGrid = (size_t)gridDim.x * (blockDim.x / 64u);
+    for (size_t wv = (size_t)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6); wv < nwaves; wv += wavesPerGrid) {
+        const size_t i = wv * perWave + lane;
+        const bool in = lane < perWave && i < nwords;
+        const uint32_t v = in ? src[i] : 0u;
+        const unsigned long long odd = __builtin_amdgcn_ballot_w64((__popc(v) & 1u) != 0u);
+        const unsigned long long before = odd & (((1ull << lane) - 1ull) & ~((1ull << start) - 1ull));
+        uint32_t o = word_prefix_xor(v) ^ (0u - (uint32_t)(__popcll(before) & 1));
+        if (in) {
+            if (ACC) o ^= dst[i];
+            dst[i] = o;
+        }
     }
 }
 
@@ -417,7 +426,6 @@ static int launch_fill(vp_ctx* ctx, const Frame& f, const uint32_t* tog, uint32_
     hipStream_t st = ctx->stream;
     const size_t nz = f.z1 - f.z0;
     const size_t nwords = (size_t)f.n * f.n * nz / 32;
-    const size_t nrows = (size_t)f.n * nz;
     ProfScope p(ctx, VP_K_VOX_FILL);
     const int W = f.w;
     const bool vec = (W % 4 == 0) && ((W / 4) & (W / 4 - 1)) == 0 && (W / 4) <= 64;
@@ -429,11 +437,12 @@ static int launch_fill(vp_ctx* ctx, const Frame& f, const uint32_t* tog, uint32_
         else
             hipLaunchKernelGGL(vox_fill_vec<false>, dim3(blocks), dim3(256), 0, st, (const uint4*)tog, (uint4*)d_words, nvec, W / 4);
     } else {
-        const unsigned blocks = (unsigned)((nrows + 255) / 256);
+        const size_t perWave = (size_t)(64 / W) * W, nwaves = (nwords + perWave - 1) / perWave;      // W <= 64 (n <= 2048)
+        const unsigned blocks = (unsigned)std::min<size_t>((nwaves + 3) / 4, 256 * 16);
         if (accumulate)
-            hipLaunchKernelGGL(vox_fill_row<true>, dim3(blocks), dim3(256), 0, st, tog, d_words, nrows, W);
+            hipLaunchKernelGGL(vox_fill_words<true>, dim3(blocks), dim3(256), 0, st, tog, d_words, nwords, (uint32_t)W, nwaves);
         else
-            hipLaunchKernelGGL(vox_fill_row<false>, dim3(blocks), dim3(256), 0, st, tog, d_words, nrows, W);
+            hipLaunchKernelGGL(vox_fill_words<false>, dim3(blocks), dim3(256), 0, st, tog, d_words, nwords, (uint32_t)W, nwaves);
     }
     return 0;
 }

@@ -66,9 +66,12 @@ def test_voxelize_golden_hashes(engine, golden_rows, algo):
             assert O.fnv(got) == h
 
 
-def test_voxelize_accumulate_and_replace(engine):
+@pytest.mark.parametrize("n", [64, 96, 128, 160, 384])
+def test_voxelize_accumulate_and_replace(engine, n):
+    """n = 128: the 16-byte-per-lane prefix-XOR (rows of a power-of-two number of uint4s); the others: the one-word-per-lane form
+    (rows of 2, 3, 5, 12 words: whole rows per wave, ballot carries)."""
     m = M.import_mesh(M.asset("sphere.obj"))
-    fr, origin, vs = _frame([m], 64)
+    fr, origin, vs = _frame([m], n)
     dx, dt = engine.mesh_to_device(*m)
     for algo in (ALGO_TILED, ALGO_NAIVE):
         g = engine.voxelize(fr, dx, dt, algo=algo)
