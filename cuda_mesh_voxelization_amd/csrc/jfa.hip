@@ -60,6 +60,25 @@ __device__ __forceinline__ void udivmod(uint32_t a, uint32_t b, uint32_t& q, uin
     else { q = a / b; r = a % b; }
 }
 
+// Division by a run-time constant the HOST knows (Granlund - Montgomery, the branch-free 32-bit form): q = (t + ((a - t) >> s1)) >> s2 with
+// t = mulhi(m, a); exact for every 32-bit a.  Four instructions instead of the ~25 of a / b: jfa_first_two divides twice per 450-instruction tile.
+struct FastDiv {
+    uint32_t d, m, s1, s2;
+    __device__ __forceinline__ void divmod(uint32_t a, uint32_t& q, uint32_t& r) const
+    {
+        const uint32_t t = __umulhi(m, a);
+        q = (t + ((a - t) >> s1)) >> s2;
+        r = a - q * d;
+    }
+};
+static inline FastDiv make_fastdiv(uint32_t d)
+{
+    uint32_t l = 0;
+    while (l < 32 && (1ull << l) < d) ++l;                         // ceil(log2 d)
+    const unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1ull;
+    return FastDiv{d, (uint32_t)m, l < 1u ? l : 1u, l > 1u ? l - 1u : 0u};
+}
+
 // Id formats.  An accessor returns a coordinate field as a BYTE offset into a table of floats (index * 4).
 //
 // 32-bit formats IdU<BITS> (BITS = 9: n <= 512, BITS = 10: n <= 1024).  x sits UNSHIFTED in the low BITS + 1 bits -- its
@@ -258,7 +277,7 @@ jfa_init(Frame f, const uint32_t* __restrict__ words, const uint32_t* __restrict
     }
 }
 
-// Border mask alone (vp_surface, the "::Initialization" half of vp_jfa), rows of a power-of-two number of words >= 4.
+// Border mask alone (vp_surface, the "::Initialization" half of vp_jfa), rows of up to 64 words (every legal n).
 // A lane owns one word column (xw, y) and MARCHES along z over `zc` planes.  Per plane it forms
 //     H(z) = AND over the rows y-1, y, y+1 of (left & word & right)            -- the 3 x 3 in-plane part of the 26-neighbourhood
 // from three word loads (the left / right words come from the neighbouring lanes: v_mov_b32_dpp wave_shr / wave_shl, a VALU
@@ -274,9 +293,14 @@ jfa_border_march(Frame f, const uint32_t* __restrict__ words, const uint32_t* __
                  const uint32_t* __restrict__ above, uint32_t* __restrict__ border_words, uint32_t zc)
 {
     const int W = (int)f.w, N = (int)f.n;
-    const uint32_t wi = blockIdx.x * 256u + threadIdx.x;           // word index inside a plane (n w is a multiple of 256)
-    const int xw = (int)(wi & (uint32_t)(W - 1));
-    const int y = (int)(wi / (uint32_t)W);
+    // A wave holds floor(64 / W) WHOLE rows (all 64 lanes when W divides 64: every power-of-two side), so the left / right word of a lane
+    // is always in the neighbouring lane; the lanes past the last whole row idle.  (Until late in round 4 only power-of-two W >= 4 ran here.)
+    const uint32_t lane = threadIdx.x & 63u, rowsPerWave = 64u / (uint32_t)W;
+    const uint32_t wv = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int xw = (int)(lane % (uint32_t)W);
+    const int y = (int)(wv * rowsPerWave + lane / (uint32_t)W);
+    const bool valid = lane < rowsPerWave * (uint32_t)W && y < N;
+    const uint32_t wi = (uint32_t)y * (uint32_t)W + (uint32_t)xw;  // word index inside a plane
     const int zfirst = (int)f.z0 + (int)(blockIdx.y * zc);
     const int zlast = min(zfirst + (int)zc, (int)f.z1);           // exclusive
     const size_t planeWords = (size_t)N * W;
@@ -292,7 +316,7 @@ jfa_border_march(Frame f, const uint32_t* __restrict__ words, const uint32_t* __
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
             const int yy = y + dy;
-            r[dy + 1] = (yy >= 0 && yy < N) ? pl[(size_t)yy * W + xw] : 0u;
+            r[dy + 1] = (valid && yy >= 0 && yy < N) ? pl[(size_t)yy * W + xw] : 0u;
         }
         centre = r[1];
         uint32_t h = 0xFFFFFFFFu;
@@ -310,7 +334,7 @@ jfa_border_march(Frame f, const uint32_t* __restrict__ words, const uint32_t* __
     uint32_t hCur = inplane(zfirst, cCur);
     for (int zg = zfirst; zg < zlast; ++zg) {
         const uint32_t hNext = inplane(zg + 1, cNext);
-        border_words[(size_t)(zg - (int)f.z0) * planeWords + wi] = cCur & ~(hPrev & hCur & hNext);
+        if (valid) border_words[(size_t)(zg - (int)f.z0) * planeWords + wi] = cCur & ~(hPrev & hCur & hNext);
         hPrev = hCur; hCur = hNext; cCur = cNext;
     }
 }
@@ -1882,7 +1906,8 @@ __device__ __forceinline__ void ft_store(uint2* p, uint2 v)
 // ids stay ID's (Id64).
 template <class ID, int XR, int NT, int TPW, bool CPT = false>
 __global__ void __launch_bounds__(NT)
-jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out, uint32_t tilesX, uint32_t tiles, uint32_t shifts)
+jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out, uint32_t tilesX, uint32_t tiles, uint32_t shifts,
+              FastDiv divTilesX, FastDiv divK)
 {
     static_assert(!CPT || std::is_same<ID, Id64>::value, "compact output: from 8-byte ids");
     using T = typename ID::T;
@@ -1925,8 +1950,10 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
     auto tile_origin = [&](uint32_t t, uint32_t& rx0, uint32_t& ry, uint32_t& rz) {
         if (shifts >> 16) {
             rx0 = (t & (tilesX - 1u)) * XR; const uint32_t q = t >> (shifts & 31u); ry = q & (k - 1u); rz = q >> ((shifts >> 8) & 31u);
-        } else {
-            rx0 = (t % tilesX) * XR; const uint32_t q = t / tilesX; ry = q % k; rz = q / k;
+        } else {                                                   // sides that are not powers of two: multiply-shift division (see FastDiv)
+            uint32_t q, r;
+            divTilesX.divmod(t, q, r); rx0 = r * XR;
+            divK.divmod(q, rz, ry);
         }
     };
     // A workgroup works through TPW consecutive tiles (default 1).  Their border words -- the only thing read from memory, and 37 % of
@@ -2160,9 +2187,10 @@ int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const 
     const unsigned blocks = (unsigned)(nwords / 256);             // nwords is a multiple of 256
     ProfScope p(ctx, d_ids ? VP_K_JFA_INIT : VP_K_SURFACE);
     static const int march = env_int("VP_BORDER_MARCH", 1);       // dev switch: 0 = jfa_init for the mask as well
-    if (!d_ids && d_border_words && march && f.w >= 4 && (f.w & (f.w - 1)) == 0) {
+    if (!d_ids && d_border_words && march && f.w <= 64) {
         // border mask alone: lanes march along z (jfa_border_march); chunks of zc planes, short enough to fill the chip
-        const uint32_t inPlane = f.n * f.w / 256u, nz = f.z1 - f.z0;
+        const uint32_t rowsPerWave = 64u / f.w, wavesPerPlane = (f.n + rowsPerWave - 1) / rowsPerWave;
+        const uint32_t inPlane = (wavesPerPlane + 3u) / 4u, nz = f.z1 - f.z0;
         uint32_t zc = 32;
         while (zc > 4 && inPlane * ((nz + zc - 1) / zc) < 8u * (uint32_t)ctx->cus) zc /= 2;
         hipLaunchKernelGGL(jfa_border_march, dim3(inPlane, (nz + zc - 1) / zc), dim3(256), 0, ctx->stream, f, d_words, below, above, d_border_words, zc);
@@ -2241,16 +2269,16 @@ int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, 
     const dim3 grid((tiles + VP_FIRST_TWO_TPW - 1) / VP_FIRST_TWO_TPW);
     auto pow2 = [](uint32_t v) { return v != 0 && (v & (v - 1)) == 0; };
     const uint32_t shifts = (pow2(tilesX) && pow2(k)) ? ((uint32_t)__builtin_ctz(tilesX) | ((uint32_t)__builtin_ctz(k) << 8) | (1u << 16)) : 0u;
-    if (wide(f) && f.compact) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW, true>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles, shifts);
-    else if (wide(f)) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles, shifts);
-    else if (small && f.n <= 512) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
+    if (wide(f) && f.compact) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW, true>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k));
+    else if (wide(f)) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)d_out, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k));
+    else if (small && f.n <= 512) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k));
 #if VP_FT_BIG_XR16
-    else if (small) hipLaunchKernelGGL((jfa_first_two<Id10, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
+    else if (small) hipLaunchKernelGGL((jfa_first_two<Id10, 16, 256, VP_FIRST_TWO_TPW>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k));
 #endif
 #if VP_FT_SMALL_XR32
-    else if (f.n <= 512) hipLaunchKernelGGL((jfa_first_two<Id9, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
+    else if (f.n <= 512) hipLaunchKernelGGL((jfa_first_two<Id9, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k));
 #endif
-    else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts);
+    else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512, VP_FIRST_TWO_TPW>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)d_out, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k));
     VP_HIP(hipGetLastError());
     return 0;
 }
