@@ -142,7 +142,7 @@ size_t vp_jfa_workspace_bytes(const vp_frame* f);
 size_t vp_jfa_id_bytes(const vp_frame* f);
 /* Bytes of id state per voxel that vp_jfa (whole-grid frame, its own workspace) really streams per pass -- the S of SURVEY.md 8(d)
  * "as implemented": 4 for n <= 1024; above that 5 when the call keeps its state in the compact layout (a 32-bit word plane + a byte
- * plane inside the 8-byte volumes of the workspace: VP_ALGO_TILED, n % 128 == 0), else 8.  Measurement only: the id buffers a caller
+ * plane inside the 8-byte volumes of the workspace: VP_ALGO_TILED), else 8.  Measurement only: the id buffers a caller
  * passes to the slab entry points are always vp_jfa_id_bytes wide. */
 size_t vp_jfa_state_bytes(const vp_frame* f, int algo);
 int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
@@ -179,7 +179,7 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
                      const void* d_plus, void* d_scratch, const uint32_t* d_words, float fill_unset,
                      float* d_sdf, int algo);
 
-/* Sparse start (n % 128 == 0, VP_ALGO_TILED; vp_jfa uses it internally).  Before any pass a border
+/* Sparse start (n % 128 == 0, VP_ALGO_TILED; the halo / hybrid slab pipelines use it; vp_jfa itself starts with vp_jfa_first_two below).  Before any pass a border
  * voxel's seed is itself and nothing else has one (jfa/sequential.cpp:55-60), so the first pass (k = n/2) can run
  * straight from the border bitmask of the WHOLE grid (vp_surface on a whole-grid frame): no init id volume is
  * written or read.  vp_jfa_first_pass produces the ids after step n/2 for the planes of f; the result is
