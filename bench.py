@@ -45,6 +45,68 @@ if ROOT not in sys.path:
 # `hipIpcGetMemHandle: invalid argument`.  Exported on the boxes already; kept here for any environment that launches this file bare.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", "--grid-n", dest="n", type=int, default=512, choices=[256, 512, 1024, 2048],
+                    help="grid side; 512 = the headline configuration, 1024 / 2048 = the sizes the north star shards.  Under "
+                         "torch.distributed.run spell it --grid-n: the launcher's own parser rejects a bare --n as an ambiguous "
+                         "abbreviation of its --nnodes / --nproc-per-node")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-n1024", action="store_true", help="skip the extra n = 1024 JFA block of the default run")
+    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE config 3 block (bimba + bunny, CSG union, JFA at n = 512)")
+    ap.add_argument("--no-host-totals", action="store_true", help="skip the host-in / host-out round (reference-style totals)")
+    ap.add_argument("--no-copy-peak", action="store_true", help="skip the 1-GiB stream-copy measurement")
+    ap.add_argument("--multi", choices=["ghost", "halo", "hybrid"], default="ghost",
+                    help="N > 1: 'ghost' = Z-slabs with recomputed ghost planes, no data-path exchange (default: a plane costs ~1 us "
+                         "to recompute and ~20 us to move over xGMI); 'halo' = Z-slabs with RCCL point-to-point halo planes before every pass; "
+                         "'hybrid' = ghost planes for the wide passes (k > nz/2), halos of the adjacent ranks -- sent a pass ahead, under the "
+                         "interior planes -- for the narrow ones; id buffers hold only the planes a rank touches")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE in the environment): this process touches no GPU -- torch is not even
+    imported yet -- and starts the N ranks as a FRESH child (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+    <same arguments>`, never an exec), forwards rank 0's JSON line to its own stdout, everything else the ranks print to stderr, and
+    returns the child's exit code.  The reference hard-wires device 0 (apps/cli/main.cpp:22-23); this is what replaces it for N > 1."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--grid-n", str(args.n), "--multi", args.multi]
+    for flag in ("no_cpu_baseline", "no_n1024", "no_config3", "no_host_totals", "no_copy_peak"):
+        if getattr(args, flag):
+            argv.append("--" + flag.replace("_", "-"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            lines += 1
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write("bench.py: the ranks printed %d JSON lines, expected 1\n" % lines)
+        rc = 1
+    return rc
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _early = parse_args()
+    if _early.gpus > 1:
+        sys.exit(launch_ranks(_early))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -288,31 +350,13 @@ def run_single(eng, frame, d_xyz, d_tri, steps, warmup, algo):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", "--grid-n", dest="n", type=int, default=N_GRID, choices=[256, 512, 1024, 2048],
-                    help="grid side; 512 = the headline configuration, 1024 / 2048 = the sizes the north star shards.  Under "
-                         "torch.distributed.run spell it --grid-n: the launcher's own parser rejects a bare --n as an ambiguous "
-                         "abbreviation of its --nnodes / --nproc-per-node")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-n1024", action="store_true", help="skip the extra n = 1024 JFA block of the default run")
-    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE config 3 block (bimba + bunny, CSG union, JFA at n = 512)")
-    ap.add_argument("--no-host-totals", action="store_true", help="skip the host-in / host-out round (reference-style totals)")
-    ap.add_argument("--no-copy-peak", action="store_true", help="skip the 1-GiB stream-copy measurement")
-    ap.add_argument("--multi", choices=["ghost", "halo", "hybrid"], default="ghost",
-                    help="N > 1: 'ghost' = Z-slabs with recomputed ghost planes, no data-path exchange (default: a plane costs ~1 us "
-                         "to recompute and ~20 us to move over xGMI); 'halo' = Z-slabs with RCCL point-to-point halo planes before every pass; "
-                         "'hybrid' = ghost planes for the wide passes (k > nz/2), halos of the adjacent ranks -- sent a pass ahead, under the "
-                         "interior planes -- for the narrow ones; id buffers hold only the planes a rank touches")
-    args = ap.parse_args()
+    args = parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.gpus != world:                                  # (a bare `--gpus N` never gets here: launch_ranks above)
+        sys.exit("bench.py --gpus %d inside a job of WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
 
     from cuda_mesh_voxelization_amd import mesh as M
@@ -545,39 +589,48 @@ def main():
         # (default 180) rank 0 prints the line it already has, with the time-out recorded in `multi_alt`, and every rank leaves.
         import threading
         limit = float(os.environ.get("VP_BENCH_ALT_TIMEOUT", "180"))
-        lock, finished = threading.Lock(), [False]
+        lock, finished, printed = threading.Lock(), [False], [False]
+        # exit code of a run whose OTHER transport hung: 0 -- the line's own measurement and its parity check stand and the time-out is in
+        # the line (`multi_alt.error`) -- unless VP_BENCH_STRICT=1 asks for 2
+        hang_rc = 2 if os.environ.get("VP_BENCH_STRICT") == "1" else 0
 
         def give_up():
             with lock:
                 if finished[0]:
                     return
-                if rank == 0:
+                if rank == 0 and not printed[0]:
                     out["multi_alt"] = {"pipeline": alt_kind, "steps": alt_steps, "ms_per_step": None, "value": None, "parity_ok": None,
                                         "error": "no result within %.0f s (VP_BENCH_ALT_TIMEOUT): the transport hung; the timed "
                                                  "pipeline's figures and parity above stand" % limit}
                     print(json.dumps(out), flush=True)
                 sys.stdout.flush()
-                os._exit(0 if parity["parity_ok"] else 1)
+                sys.stderr.write("bench.py: rank %d gave up on the other transport after %.0f s\n" % (rank, limit))
+                sys.stderr.flush()
+                os._exit(hang_rc if parity["parity_ok"] else 1)
 
+        # the timer stays armed until every rank is through the LAST barrier: a rank that finished the region while another one timed out
+        # and left would otherwise wait in that barrier for ever
         timer = threading.Timer(limit, give_up)
         timer.daemon = True
         timer.start()
         multi_alt = alt_region()
+        del ref_words, ref_sdf
+        torch.cuda.empty_cache()
+        with lock:
+            if rank == 0:
+                out["multi_alt"] = multi_alt
+                out["parity_ok"] = parity["parity_ok"] and multi_alt["parity_ok"] is not False   # a transport that RAN and disagreed fails the line
+                print(json.dumps(out), flush=True)
+            printed[0] = True
+        dist.barrier()
         with lock:
             finished[0] = True
         timer.cancel()
-        del ref_words, ref_sdf
-        torch.cuda.empty_cache()
-        if rank == 0:
-            out["multi_alt"] = multi_alt
-            out["parity_ok"] = parity["parity_ok"] and multi_alt["parity_ok"] is not False   # a transport that RAN and disagreed fails the line
-    if rank == 0:
+        dist.destroy_process_group()
+    elif rank == 0:
         print(json.dumps(out), flush=True)
 
     bad = parity is not None and not (parity["parity_ok"] and multi_alt["parity_ok"] is not False)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if bad:
         sys.exit("bench.py: a rank's slab differs from the one-GPU result (see `parity` / `multi_alt` in the JSON line)")
 

@@ -92,3 +92,31 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 # the product path must never reach the CPU oracle: no import, include, dlopen or mention of it at all
                 assert "oracle" not in txt.lower(), os.path.join(dp, f)
+
+
+def test_bench_bare_multi_gpu_invocation_starts_ranks():
+    """`python bench.py --gpus 2` without a launcher starts its own ranks (bench.launch_ranks) instead of exiting with "must be launched
+    with torch.distributed.run" (VERDICT r04 #1).  No GPU here: the RANKS fail loudly ("needs a GPU"), the parent forwards their exit code
+    and prints no JSON line -- which shows the parent itself never asked for a device."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_slab_gpu.py::test_bench_bare_invocation_launches_its_own_ranks runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid-n", "256"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "must be launched" not in r.stderr and "bench.py needs a GPU" in r.stderr, r.stderr[-3000:]
+    assert r.stdout.strip() == ""
+
+
+def test_bench_argument_surface():
+    """bench.py's contract flags (--gpus / --steps / --warmup) parse before torch is imported; --n and --grid-n are one option"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = mod.parse_args(["--gpus", "4", "--steps", "7", "--warmup", "2", "--grid-n", "1024"])
+    assert (a.gpus, a.steps, a.warmup, a.n, a.multi) == (4, 7, 2, 1024, "ghost")
+    assert mod.parse_args([]).gpus == 1 and mod.parse_args(["--n", "2048"]).n == 2048
