@@ -384,9 +384,9 @@ def main():
     frame = Frame.make(n, vs, origin)
     eng = Engine(local_rank)
     d_xyz, d_tri = eng.mesh_to_device(xyz, tri)
-    # S of SURVEY.md 8(d), "as implemented": what a pass really streams per voxel -- one GPU at n > 1024 keeps its state in the compact
-    # 5-byte layout; the slab pipelines exchange and address 8-byte ids there
-    S = eng.ctx.jfa_state_bytes(frame, ALGO_TILED) if world == 1 else eng.ctx.jfa_id_bytes(frame)
+    # S of SURVEY.md 8(d), "as implemented": what a pass really streams per voxel -- 4 bytes; above n = 1024 the 5 bytes of the id windows,
+    # on one GPU and in every slab pipeline (memory and wire)
+    S = eng.ctx.jfa_state_bytes(frame, ALGO_TILED)
     passes = int(math.log2(n))
 
     def barrier():
@@ -412,7 +412,7 @@ def main():
 
             def step():
                 pipe.voxelize(d_xyz, d_tri, algo=ALGO_TILED)
-                pipe.jfa(algo=ALGO_TILED)
+                pipe.jfa()
 
             el, lv, tb = measure(eng, step, steps, warmup, barrier)
             t = torch.tensor([el], dtype=torch.float64, device=eng.device)
@@ -431,8 +431,6 @@ def main():
 
         elapsed, live, table, pipe_report, got = run_pipeline(args.multi, args.steps, args.warmup)
         pipe_desc = pipe_report.pop("describe")
-        if pipe_report.get("volume_calls"):                # ghost planes on whole volumes in the library's layout: 5 bytes per voxel above n = 1024
-            S = pipe_report["id_volume_bytes"] // frame.voxels
         planes = n // world
         regs = pipe_report.pop("regions")
         if regs:                                           # ghost planes: a dense pass covers the slab widened by the later steps
@@ -553,7 +551,7 @@ def main():
             o2, v2 = M.frame([xyz], n2)
             f2 = Frame.make(n2, v2, o2)
             e2, l2, t2 = run_single(eng, f2, d_xyz, d_tri, 3, 1, ALGO_TILED)
-            k2 = merge_tables(l2, 3, t2, kernel_bytes(n2, n2, eng.ctx.jfa_id_bytes(f2), int(tri.shape[0]), int(xyz.shape[0])))
+            k2 = merge_tables(l2, 3, t2, kernel_bytes(n2, n2, eng.ctx.jfa_state_bytes(f2, ALGO_TILED), int(tri.shape[0]), int(xyz.shape[0])))
             jfa_ms = sum(v["ms_per_step"] for k, v in k2.items() if k.startswith("jfa_") or k == "surface")
             jfa_bytes = sum(v["bytes"] * v["launches_per_step"] for k, v in k2.items() if k.startswith("jfa_") or k == "surface")
             out["n1024"] = {"ms_per_step": round(e2 / 3 * 1e3, 3), "Mvoxels/s": round(n2 ** 3 / (e2 / 3) / 1e6, 1), "jfa_ms": round(jfa_ms, 3),

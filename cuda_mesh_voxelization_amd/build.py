@@ -1,6 +1,7 @@
 """Build recipes for the native parts (in-tree, so the built files travel with the repo snapshot).
 
   libvphip.so   HIP kernels + C ABI (include/vphip.h), hipcc --offload-arch=gfx950
+  libvphip_hooks.so   the same with the test hooks of vox.hip / multi.hip compiled in (-DVP_TEST_HOOKS); only tests load it
   vpcli         C++23 CLI mirroring the reference's apps/cli (links libvphip.so)
 
 hipcc cross-compiles gfx950 code objects without a GPU present.
@@ -17,8 +18,10 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvphip.so")
 CLI = os.path.join(PKG, "vpcli")
 
-HIP_SOURCES = ["capi.hip", "vox.hip", "csg.hip", "jfa.hip", "extract.hip", "multi.hip"]
-JFA_PARTS = 5                    # jfa.hip is compiled as parts 0 .. 4 side by side (-DVP_JFA_PART=i, see the top of the file)
+HIP_SOURCES = ["capi.hip", "vox.hip", "csg.hip", "jfa_seed.hip", "jfa_first_two.hip", "jfa_dense.hip", "extract.hip", "multi.hip"]
+DENSE_PARTS = 3                  # jfa_dense.hip is compiled once per id format, side by side (-DVP_DENSE_PART=1..3, see the end of the file)
+HOOK_SOURCES = ["vox.hip", "multi.hip"]     # the sources that read test hooks from the environment under -DVP_TEST_HOOKS (libvphip_hooks.so)
+HOOKS_LIB = os.path.join(PKG, "libvphip_hooks.so")
 # -ffp-contract=off is part of the parity contract: an FMA changes the bitmask / sdf bits.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
              "-Wall", "-Wno-unused-function"]
@@ -38,35 +41,64 @@ def _newer(target: str, sources) -> bool:
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
+def _jobs(n: int) -> int:
+    """hipcc processes side by side: at most 8 and never more than cores - 1 (each holds ~1-2 GB while it instantiates the tile kernels);
+    VP_BUILD_JOBS overrides"""
+    env = os.environ.get("VP_BUILD_JOBS")
+    if env:
+        return max(1, min(int(env), n))
+    return max(1, min(8, max(2, (os.cpu_count() or 4) - 1), n))
+
+
+def build_lib(force: bool = False, verbose: bool = False, hooks: bool = False) -> str:
+    """libvphip.so; hooks=True: also libvphip_hooks.so -- the same objects except vox.hip / multi.hip compiled with -DVP_TEST_HOOKS, the
+    build the tests that force rare paths load (the default library reads no environment variable on any call path)."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "vp_internal.h"), os.path.join(ROOT, "include", "vphip.h")]
+    deps = srcs + [os.path.join(CSRC, "vp_internal.h"), os.path.join(CSRC, "jfa_common.h"), os.path.join(ROOT, "include", "vphip.h")]
+    objdir = os.path.join(PKG, "build")
+    flags = [f for f in HIP_FLAGS if f != "-shared"]
+
+    def link(objs, out):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    objs = []
+    for s_ in srcs:
+        base = os.path.basename(s_)
+        if base == "jfa_dense.hip":
+            objs += [os.path.join(objdir, "jfa_dense.hip.part%d.o" % part) for part in range(1, DENSE_PARTS + 1)]
+        else:
+            objs.append(os.path.join(objdir, base + ".o"))
     if force or _newer(LIB, deps):
-        # one hipcc per source, side by side (jfa.hip alone is ~2 minutes of template instantiations), then one link
+        # one hipcc per source, side by side (the tile kernel alone is over a minute of template instantiations per id format), then one link
         from concurrent.futures import ThreadPoolExecutor
-        objdir = os.path.join(PKG, "build")
         os.makedirs(objdir, exist_ok=True)
-        flags = [f for f in HIP_FLAGS if f != "-shared"]
-        objs, cmds = [], []
+        cmds = []
         for s_ in srcs:
-            if os.path.basename(s_) == "jfa.hip":               # the longest first: five parts of the tile-kernel instantiations
-                for part in range(JFA_PARTS):
-                    o = os.path.join(objdir, "jfa.hip.part%d.o" % part)
-                    objs.append(o)
-                    cmds.insert(part, [_hipcc()] + flags + ["-DVP_JFA_PART=%d" % part, "-c", s_, "-o", o])
+            base = os.path.basename(s_)
+            if base == "jfa_dense.hip":                         # the longest first
+                for part in range(1, DENSE_PARTS + 1):
+                    cmds.insert(part - 1, [_hipcc()] + flags + ["-DVP_DENSE_PART=%d" % part, "-c", s_, "-o", os.path.join(objdir, "jfa_dense.hip.part%d.o" % part)])
             else:
-                o = os.path.join(objdir, os.path.basename(s_) + ".o")
-                objs.append(o)
-                cmds.append([_hipcc()] + flags + ["-c", s_, "-o", o])
+                cmds.append([_hipcc()] + flags + ["-c", s_, "-o", os.path.join(objdir, base + ".o")])
         if verbose:
             for c in cmds:
                 print(" ".join(c))
-        with ThreadPoolExecutor(max_workers=min(max(2, (os.cpu_count() or 4) - 1), len(cmds))) as ex:
+        with ThreadPoolExecutor(max_workers=_jobs(len(cmds))) as ex:
             list(ex.map(subprocess.check_call, cmds))
-        link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
-        if verbose:
-            print(" ".join(link))
-        subprocess.check_call(link)
+        link(objs, LIB)
+    if hooks and (force or _newer(HOOKS_LIB, deps + [LIB])):
+        hobjs = list(objs)
+        for name in HOOK_SOURCES:
+            o = os.path.join(objdir, name + ".hooks.o")
+            cmd = [_hipcc()] + flags + ["-DVP_TEST_HOOKS", "-c", os.path.join(CSRC, name), "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            hobjs[hobjs.index(os.path.join(objdir, name + ".o"))] = o
+        link(hobjs, HOOKS_LIB)
     return LIB
 
 

@@ -7,7 +7,9 @@ import ctypes
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VPHIP_LIB") or os.path.join(PKG, "libvphip.so")   # VPHIP_LIB: dev experiments only
+# VPHIP_LIB: another build of the library -- dev experiments (tools/exp_build.sh) and the tests that need libvphip_hooks.so
+LIB_PATH = os.environ.get("VPHIP_LIB") or os.path.join(PKG, "libvphip.so")
+HOOKS_LIB_PATH = os.path.join(PKG, "libvphip_hooks.so")
 
 ALGO_NAIVE, ALGO_TILED = 1, 2
 OP_VOID, OP_UNION, OP_INTERSECTION, OP_DIFFERENCE = 0, 1, 2, 3
@@ -24,8 +26,9 @@ SYMBOLS = [
     "vp_malloc", "vp_free", "vp_memset", "vp_memcpy_d2d", "vp_stream_copy", "vp_ctx_workspace", "vp_ctx_release", "vp_upload", "vp_download",
     "vp_grid_words", "vp_grid_voxels",
     "vp_voxelize", "vp_csg", "vp_jfa_workspace_bytes", "vp_jfa_id_bytes", "vp_jfa_state_bytes", "vp_jfa", "vp_jfa_start", "vp_jfa_run", "vp_jfa_init", "vp_jfa_pass",
-    "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_first_pass", "vp_jfa_can_fuse_first_two", "vp_jfa_first_two",
-    "vp_jfa_volume_bytes", "vp_jfa_volume_first_two", "vp_jfa_volume_pass", "vp_jfa_volume_last_pass",
+    "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_can_fuse_first_two",
+    "vp_jfa_window_bytes", "vp_jfa_window_span", "vp_jfa_window_clear", "vp_jfa_window_init", "vp_jfa_window_first_pass", "vp_jfa_window_first_two",
+    "vp_jfa_window_pass", "vp_jfa_window_last_pass",
     "vp_surface", "vp_extract_count", "vp_extract", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_select", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
     "vp_multi_create", "vp_multi_destroy", "vp_multi_count", "vp_multi_ctx", "vp_multi_sync", "vp_multi_set_mesh", "vp_multi_voxelize",
@@ -70,6 +73,17 @@ class Frame(ctypes.Structure):
         return Frame.make(self.n, self.voxel_size, self.origin, z0, z1)
 
 
+class Window(ctypes.Structure):
+    """vp_window: an id buffer in the library's layout -- `planes` id planes, plane z0 of the frame a call is made with at index `at`."""
+    _fields_ = [("d_ids", ctypes.c_void_p), ("planes", ctypes.c_uint32), ("at", ctypes.c_uint32)]
+
+    @classmethod
+    def make(cls, d_ids, planes, at):
+        w = cls()
+        w.d_ids, w.planes, w.at = int(d_ids), int(planes), int(at)
+        return w
+
+
 _lib = None
 _vp = ctypes.c_void_p
 _sz = ctypes.c_size_t
@@ -93,6 +107,7 @@ def lib():
         pass
     L = ctypes.CDLL(LIB_PATH)
     fp = ctypes.POINTER(Frame)
+    wp = ctypes.POINTER(Window)
     sig = {
         "vp_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
         "vp_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
@@ -125,13 +140,15 @@ def lib():
         "vp_jfa_finalize": (ctypes.c_int, [_vp, fp, _vp, _vp, ctypes.c_float, _vp]),
         "vp_jfa_last_pass": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int]),
         "vp_jfa_can_start_from_mask": (ctypes.c_int, [fp, ctypes.c_int]),
-        "vp_jfa_first_pass": (ctypes.c_int, [_vp, fp, _vp, _vp]),
         "vp_jfa_can_fuse_first_two": (ctypes.c_int, [fp, ctypes.c_int]),
-        "vp_jfa_first_two": (ctypes.c_int, [_vp, fp, _vp, _vp]),
-        "vp_jfa_volume_bytes": (_sz, [fp]),
-        "vp_jfa_volume_first_two": (ctypes.c_int, [_vp, fp, _vp, _vp]),
-        "vp_jfa_volume_pass": (ctypes.c_int, [_vp, fp, ctypes.c_uint32, _vp, _vp]),
-        "vp_jfa_volume_last_pass": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, ctypes.c_float, _vp]),
+        "vp_jfa_window_bytes": (_sz, [fp, ctypes.c_uint32]),
+        "vp_jfa_window_span": (ctypes.c_int, [fp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+        "vp_jfa_window_clear": (ctypes.c_int, [_vp, fp, wp]),
+        "vp_jfa_window_init": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, wp]),
+        "vp_jfa_window_first_pass": (ctypes.c_int, [_vp, fp, _vp, wp]),
+        "vp_jfa_window_first_two": (ctypes.c_int, [_vp, fp, _vp, wp]),
+        "vp_jfa_window_pass": (ctypes.c_int, [_vp, fp, ctypes.c_uint32, wp, wp, ctypes.c_uint32]),
+        "vp_jfa_window_last_pass": (ctypes.c_int, [_vp, fp, wp, wp, ctypes.c_uint32, _vp, ctypes.c_float, _vp]),
         "vp_surface": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
         "vp_extract_count": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
         "vp_extract": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_int, _vp, _vp, _vp, _sz]),
@@ -228,11 +245,11 @@ class Context:
         return int(lib().vp_jfa_workspace_bytes(ctypes.byref(frame)))
 
     def jfa_id_bytes(self, frame: Frame) -> int:
-        """Bytes of JFA state per voxel: 4 for n <= 1024, 8 for n <= 2048."""
+        """Bytes of a PLAIN id (the caller-addressed planes of vp_jfa_init / vp_jfa_pass): 4 for n <= 1024, 8 for n <= 2048."""
         return int(lib().vp_jfa_id_bytes(ctypes.byref(frame)))
 
     def jfa_state_bytes(self, frame: Frame, algo: int = ALGO_TILED) -> int:
-        """Bytes of id state per voxel vp_jfa streams per pass (whole grid): 4, 5 (compact layout above n = 1024) or 8."""
+        """Bytes of id state per voxel vp_jfa streams per pass (whole grid): 4, 5 (windows above n = 1024) or 8 (VP_ALGO_NAIVE there)."""
         return int(lib().vp_jfa_state_bytes(ctypes.byref(frame), algo))
 
     def jfa(self, frame: Frame, d_words: int, fill: float, d_sdf: int, d_work=None, work_bytes: int = 0,
@@ -283,25 +300,35 @@ class Context:
     def jfa_can_fuse_first_two(self, frame: Frame, algo: int = ALGO_TILED) -> bool:
         return bool(lib().vp_jfa_can_fuse_first_two(ctypes.byref(frame), algo))
 
-    def jfa_first_two(self, frame: Frame, d_border_grid: int, d_out: int):
+    # -- id windows (vp_jfa_window_*): the slab form of the tile kernels; the layout inside a window is the library's
+    def jfa_window_bytes(self, frame: Frame, planes: int) -> int:
+        return int(lib().vp_jfa_window_bytes(ctypes.byref(frame), planes))
+
+    def jfa_window_span(self, frame: Frame, planes: int, p0: int, p1: int):
+        """[(byte offset, bytes), ...]: where the planes [p0, p1) of a window of `planes` planes live (one range, two above n = 1024)"""
+        off, nb = (_sz * 2)(), (_sz * 2)()
+        check(lib().vp_jfa_window_span(ctypes.byref(frame), planes, p0, p1, off, nb))
+        return [(int(off[i]), int(nb[i])) for i in range(2) if nb[i]]
+
+    def jfa_window_clear(self, frame: Frame, win: Window):
+        check(lib().vp_jfa_window_clear(self._h, ctypes.byref(frame), ctypes.byref(win)))
+
+    def jfa_window_init(self, frame: Frame, d_words: int, d_below, d_above, win: Window):
+        check(lib().vp_jfa_window_init(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_below or None), _vp(d_above or None), ctypes.byref(win)))
+
+    def jfa_window_first_pass(self, frame: Frame, d_border_grid: int, win: Window):
+        check(lib().vp_jfa_window_first_pass(self._h, ctypes.byref(frame), _vp(d_border_grid), ctypes.byref(win)))
+
+    def jfa_window_first_two(self, frame: Frame, d_border_grid: int, win: Window):
         """passes n/2 and n/4 of a whole grid in one launch from its border mask"""
-        check(lib().vp_jfa_first_two(self._h, ctypes.byref(frame), _vp(d_border_grid), _vp(d_out)))
+        check(lib().vp_jfa_window_first_two(self._h, ctypes.byref(frame), _vp(d_border_grid), ctypes.byref(win)))
 
-    def jfa_first_pass(self, frame: Frame, d_border_grid: int, d_out: int):
-        check(lib().vp_jfa_first_pass(self._h, ctypes.byref(frame), _vp(d_border_grid), _vp(d_out)))
+    def jfa_window_pass(self, frame: Frame, k: int, win_in: Window, win_out: Window, stride=None):
+        check(lib().vp_jfa_window_pass(self._h, ctypes.byref(frame), k, ctypes.byref(win_in), ctypes.byref(win_out), k if stride is None else stride))
 
-    # -- whole-volume passes (ghost-plane pipelines): volume base + region frame, layout chosen by the library
-    def jfa_volume_bytes(self, frame: Frame) -> int:
-        return int(lib().vp_jfa_volume_bytes(ctypes.byref(frame)))
-
-    def jfa_volume_first_two(self, frame: Frame, d_border_grid: int, d_vol: int):
-        check(lib().vp_jfa_volume_first_two(self._h, ctypes.byref(frame), _vp(d_border_grid), _vp(d_vol)))
-
-    def jfa_volume_pass(self, region: Frame, k: int, d_vol_in: int, d_vol_out: int):
-        check(lib().vp_jfa_volume_pass(self._h, ctypes.byref(region), k, _vp(d_vol_in), _vp(d_vol_out)))
-
-    def jfa_volume_last_pass(self, region: Frame, d_vol_in: int, d_vol_scratch: int, d_words_region: int, fill: float, d_sdf_region: int):
-        check(lib().vp_jfa_volume_last_pass(self._h, ctypes.byref(region), _vp(d_vol_in), _vp(d_vol_scratch), _vp(d_words_region), fill, _vp(d_sdf_region)))
+    def jfa_window_last_pass(self, frame: Frame, win_in: Window, win_scratch: Window, d_words_region: int, fill: float, d_sdf_region: int, stride: int = 1):
+        check(lib().vp_jfa_window_last_pass(self._h, ctypes.byref(frame), ctypes.byref(win_in), ctypes.byref(win_scratch), stride,
+                                            _vp(d_words_region), fill, _vp(d_sdf_region)))
 
     def surface(self, frame: Frame, d_words: int, d_below, d_above, d_border: int):
         check(lib().vp_surface(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_below or None),

@@ -111,11 +111,19 @@ static int bind_device(vp_ctx* ctx)
 // buffer it was taken from is written through this ABI or handed out again as a workspace slot.
 // The same holds for the record of vp_jfa_start: its border mask (or init ids) was computed from the grid CONTENTS, so a write to
 // that grid -- or to the workspace itself -- between start and run invalidates it ("same grid" in the header means same contents).
-static void grid_written(vp_ctx* ctx, const void* d_ptr)
+// Byte RANGES are compared: a write into the interior of the grid -- vp_voxelize / vp_csg on a slab frame, vp_memcpy_d2d
+// into a sub-range -- invalidates the records like a write to its first byte does.
+static bool overlaps(const void* a, size_t an, const void* b, size_t bn)
+{
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    return a && b && a0 < b0 + (bn ? bn : 1) && b0 < a0 + (an ? an : 1);
+}
+static void grid_written(vp_ctx* ctx, const void* d_ptr, size_t bytes)
 {
     if (!d_ptr) return;
-    if (d_ptr == (const void*)ctx->ext_words) ctx->ext_words = nullptr;
-    if (ctx->jfa_started.valid && (d_ptr == (const void*)ctx->jfa_started.words || d_ptr == ctx->jfa_started.work))
+    if (overlaps(d_ptr, bytes, ctx->ext_words, (size_t)ctx->ext_n * ctx->ext_n * ctx->ext_n / 8)) ctx->ext_words = nullptr;
+    const vp_ctx::JfaStarted& st = ctx->jfa_started;
+    if (st.valid && (overlaps(d_ptr, bytes, st.words, (size_t)st.n * st.n * st.n / 8) || overlaps(d_ptr, bytes, st.work, st.work_bytes)))
         ctx->jfa_started.valid = false;
 }
 
@@ -209,8 +217,7 @@ int vp_free(vp_ctx* ctx, void* d_ptr)
 {
     if (!ctx) return set_error(VP_ERR_INVALID, "vp_free: null ctx");
     VP_TRY(bind_device(ctx));
-    grid_written(ctx, d_ptr);
-    if (d_ptr == ctx->jfa_started.work) ctx->jfa_started.valid = false;
+    grid_written(ctx, d_ptr, 1);
     if (d_ptr) { VP_HIP(hipStreamSynchronize(ctx->stream)); VP_HIP(hipFree(d_ptr)); }
     return 0;
 }
@@ -219,7 +226,7 @@ int vp_memcpy_d2d(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes)
 {
     if (!ctx || ((!d_dst || !d_src) && bytes)) return set_error(VP_ERR_INVALID, "vp_memcpy_d2d: null argument");
     VP_TRY(bind_device(ctx));
-    grid_written(ctx, d_dst);
+    grid_written(ctx, d_dst, bytes);
     if (bytes) VP_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
@@ -230,7 +237,7 @@ int vp_ctx_workspace(vp_ctx* ctx, int slot, size_t bytes, void** d_out)
     VP_TRY(bind_device(ctx));
     VP_TRY(reserve(ctx, ctx->slots[slot], bytes ? bytes : 1));
     *d_out = ctx->slots[slot].ptr;
-    grid_written(ctx, *d_out);                                     // whoever asks for the slot is about to fill it
+    grid_written(ctx, *d_out, ctx->slots[slot].bytes);             // whoever asks for the slot is about to fill it
     return 0;
 }
 
@@ -250,7 +257,7 @@ int vp_memset(vp_ctx* ctx, void* d_ptr, int byte_value, size_t bytes)
 {
     if (!ctx || (!d_ptr && bytes)) return set_error(VP_ERR_INVALID, "vp_memset: null argument");
     VP_TRY(bind_device(ctx));
-    grid_written(ctx, d_ptr);
+    grid_written(ctx, d_ptr, bytes);
     if (bytes) VP_HIP(hipMemsetAsync(d_ptr, byte_value, bytes, ctx->stream));
     return 0;
 }
@@ -259,7 +266,7 @@ int vp_upload(vp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes)
 {
     if (!ctx || ((!d_dst || !h_src) && bytes)) return set_error(VP_ERR_INVALID, "vp_upload: null argument");
     VP_TRY(bind_device(ctx));
-    grid_written(ctx, d_dst);
+    grid_written(ctx, d_dst, bytes);
     if (bytes) {
         VP_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
         VP_HIP(hipStreamSynchronize(ctx->stream));
@@ -299,7 +306,7 @@ int vp_voxelize(vp_ctx* ctx, const vp_frame* f, uint32_t* d_words, const float* 
     if (ntris && (!d_xyz || !d_tri || !nverts)) return set_error(VP_ERR_INVALID, "vp_voxelize: null mesh arrays");
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_voxelize: algo %d", algo);
     if (ntris > 0xFFFFFFFFull / 3) return set_error(VP_ERR_UNSUPPORTED, "vp_voxelize: too many triangles");
-    grid_written(ctx, d_words);
+    grid_written(ctx, d_words, vp_grid_words(f) * 4);
     return launch_voxelize(ctx, make_frame(f), d_words, d_xyz, nverts, d_tri, ntris, algo, accumulate ? 1 : 0);
 }
 
@@ -309,7 +316,7 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
     VP_TRY(bind_device(ctx));
     if (op < VP_OP_VOID || op > VP_OP_DIFFERENCE) return set_error(VP_ERR_INVALID, "vp_csg: unknown op %d", op);
     VP_TRY(check_aligned("vp_csg", {d_a, d_b}));
-    grid_written(ctx, d_a);
+    grid_written(ctx, d_a, nwords * 4);
     return launch_csg(ctx, d_a, d_b, nwords, op);
 }
 
@@ -318,7 +325,7 @@ int vp_stream_copy(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes)
     if (!ctx || !d_dst || !d_src || bytes == 0 || (bytes % 16) != 0 || ((uintptr_t)d_dst % 16) != 0 || ((uintptr_t)d_src % 16) != 0)
         return set_error(VP_ERR_INVALID, "vp_stream_copy: 16-byte aligned buffers of a multiple of 16 bytes required");
     VP_TRY(bind_device(ctx));
-    grid_written(ctx, d_dst);
+    grid_written(ctx, d_dst, bytes);
     return launch_stream_copy(ctx, d_dst, d_src, bytes);
 }
 
@@ -382,8 +389,8 @@ int vp_jfa_finalize(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, con
 }
 
 // The two halves of vp_jfa (the reference times them separately: "::Initialization" / "::Processing",
-// jfa/tiled.cu:265-334).  start: border mask (fast sequence) or init ids; run: every pass + the id -> sdf conversion.
-static int jfa_check(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void*& d_work, size_t work_bytes, int algo, const char* who)
+// jfa/tiled.cu:265-334).  start: border mask (tile kernels) or init ids; run: every pass + the id -> sdf conversion.
+static int jfa_check(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void*& d_work, size_t& work_bytes, int algo, const char* who)
 {
     if (!ctx || !d_words) return set_error(VP_ERR_INVALID, "%s: null argument", who);
     VP_TRY(bind_device(ctx));
@@ -395,11 +402,16 @@ static int jfa_check(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, vo
         VP_TRY(reserve(ctx, ctx->jfa_work, vp_jfa_workspace_bytes(f)));
         if (ctx->jfa_work.ptr != before) ctx->jfa_started.valid = false;   // regrown: what a vp_jfa_start left there is gone
         d_work = ctx->jfa_work.ptr;
+        work_bytes = ctx->jfa_work.bytes;
     } else if (work_bytes < vp_jfa_workspace_bytes(f)) {
         return set_error(VP_ERR_INVALID, "%s: workspace too small", who);
     }
     return 0;
 }
+
+// The tile-kernel sequence of a whole grid: border mask -> passes n/2 + n/4 in one launch -> tile passes on two windows of n planes
+// inside the workspace -> last pass fused with the id -> sdf conversion.
+static bool jfa_tile_sequence(const Frame& fr, int algo) { return jfa_can_fuse_first_two(fr, algo) && fr.n / 4 >= 1; }
 
 int vp_jfa_start(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void* d_work, size_t work_bytes, int algo)
 {
@@ -407,11 +419,11 @@ int vp_jfa_start(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void* 
     const Frame fr = make_frame(f);
     const size_t volBytes = vp_grid_voxels(f) * vp_jfa_id_bytes(f);
     char* a = (char*)d_work;
-    const bool mask = (jfa_can_start_from_mask(fr, algo) || jfa_can_fuse_first_two(fr, algo)) && f->n / 2 > 1;
+    const bool mask = jfa_tile_sequence(fr, algo);
     ctx->jfa_started.valid = false;
     if (mask) VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, nullptr, (uint32_t*)(a + 2 * volBytes)));   // border mask only
     else      VP_TRY(launch_jfa_init(ctx, fr, d_words, nullptr, nullptr, a, nullptr));
-    ctx->jfa_started = {true, mask, f->n, algo, d_work, d_words};
+    ctx->jfa_started = {true, mask, f->n, algo, d_work, work_bytes, d_words};
     return 0;
 }
 
@@ -422,27 +434,30 @@ int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fi
     VP_TRY(check_aligned("vp_jfa_run", {d_sdf}));
     VP_TRY(jfa_check(ctx, f, d_words, d_work, work_bytes, algo, "vp_jfa_run"));
     VP_TRY(check_fill(fill_unset, "vp_jfa_run"));
-    Frame fr = make_frame(f);
+    const Frame fr = make_frame(f);
     const size_t volBytes = vp_grid_voxels(f) * vp_jfa_id_bytes(f);
     char* a = (char*)d_work;
     char* b = a + volBytes;
     uint32_t k = f->n / 2;                                         // jfa/sequential.cpp:72
-    // n > 1024: the id state of this sequence lives in the compact layout (5 bytes per voxel inside the 8-byte volumes of the workspace):
-    // nobody outside this function sees the volumes
-    fr.compact = jfa_compact_applies(fr, algo) ? 1u : 0u;
     // The workspace must hold what THIS sequence starts from: the record of the matching vp_jfa_start (same grid, frame size,
     // algo and workspace).  One start serves one run: the passes overwrite the volumes.
-    const bool wantMask = (jfa_can_start_from_mask(fr, algo) || jfa_can_fuse_first_two(fr, algo)) && k > 1;
+    const bool wantMask = jfa_tile_sequence(fr, algo);
     const vp_ctx::JfaStarted st = ctx->jfa_started;
     ctx->jfa_started.valid = false;
     if (!st.valid || st.n != f->n || st.algo != algo || st.work != d_work || st.words != d_words || st.mask != wantMask)
         return set_error(VP_ERR_INVALID, "vp_jfa_run: call vp_jfa_start with the same grid, frame, algo and workspace first");
-    if (jfa_can_fuse_first_two(fr, algo)) {
-        VP_TRY(launch_jfa_first_two(ctx, fr, (const uint32_t*)(b + volBytes), a));    // passes n/2 and n/4 straight from the border mask
-        k /= 4;
-    } else if (jfa_can_start_from_mask(fr, algo) && k > 1) {
-        VP_TRY(launch_jfa_first_pass(ctx, fr, (const uint32_t*)(b + volBytes), a));   // straight from the border mask
-        k /= 2;
+    if (wantMask) {
+        // two windows of n planes (5 bytes per voxel above n = 1024, inside the 8-byte volumes of the workspace: nobody outside this
+        // function sees them)
+        IdWin wa, wb;
+        wa.base = a; wb.base = b; wa.planes = wb.planes = f->n; wa.at = wb.at = 0;
+        VP_TRY(launch_win_first_two(ctx, fr, (const uint32_t*)(b + volBytes), wa));    // passes n/2 and n/4 straight from the border mask
+        for (k /= 4; k >= 1; k /= 2) {
+            if (k == 1) return launch_win_pass(ctx, fr, 1, wa, wb, 1, d_words, fill_unset, d_sdf);     // last pass writes the sdf itself
+            VP_TRY(launch_win_pass(ctx, fr, k, wa, wb, k, nullptr, 0.0f, nullptr));
+            std::swap(wa, wb);
+        }
+        return set_error(VP_ERR_INVALID, "vp_jfa_run: internal: no last pass");       // n >= 96: the loop always ends in its k = 1 branch
     }
     for (; k >= 1; k /= 2) {
         if (k == 1 && jfa_pass_can_fuse_final(fr, k, algo))        // last pass writes the sdf itself
@@ -466,8 +481,7 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
 size_t vp_jfa_state_bytes(const vp_frame* f, int algo)
 {
     if (!f || check_frame(f, "vp_jfa_state_bytes", false) != 0) return 0;
-    const Frame fr = make_frame(f);
-    return jfa_compact_applies(fr, algo) ? 5 : jfa_id_bytes(fr);
+    return (algo == VP_ALGO_TILED && win_compact(f->n)) ? 5 : vp_jfa_id_bytes(f);
 }
 
 int vp_jfa_can_start_from_mask(const vp_frame* f, int algo)
@@ -475,33 +489,9 @@ int vp_jfa_can_start_from_mask(const vp_frame* f, int algo)
     return (f && check_frame(f, "vp_jfa_can_start_from_mask", false) == 0 && jfa_can_start_from_mask(make_frame(f), algo)) ? 1 : 0;
 }
 
-int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out)
-{
-    if (!ctx || !d_border_grid || !d_out) return set_error(VP_ERR_INVALID, "vp_jfa_first_pass: null argument");
-    VP_TRY(bind_device(ctx));
-    VP_TRY(check_frame(f, "vp_jfa_first_pass", false));
-    VP_TRY(check_aligned("vp_jfa_first_pass", {d_border_grid, d_out}));
-    const Frame fr = make_frame(f);
-    if (!jfa_can_start_from_mask(fr, VP_ALGO_TILED))
-        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_pass: needs n %% 128 == 0");
-    return launch_jfa_first_pass(ctx, fr, d_border_grid, d_out);
-}
-
 int vp_jfa_can_fuse_first_two(const vp_frame* f, int algo)
 {
     return (f && check_frame(f, "vp_jfa_can_fuse_first_two", false) == 0 && jfa_can_fuse_first_two(make_frame(f), algo)) ? 1 : 0;
-}
-
-int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out)
-{
-    if (!ctx || !d_border_grid || !d_out) return set_error(VP_ERR_INVALID, "vp_jfa_first_two: null argument");
-    VP_TRY(bind_device(ctx));
-    VP_TRY(check_frame(f, "vp_jfa_first_two", false));
-    VP_TRY(check_aligned("vp_jfa_first_two", {d_border_grid, d_out}));
-    const Frame fr = make_frame(f);
-    if (!jfa_can_fuse_first_two(fr, VP_ALGO_TILED))
-        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_first_two: needs a whole-grid frame with n >= 96 (VP_ALGO_TILED)");
-    return launch_jfa_first_two(ctx, fr, d_border_grid, d_out);
 }
 
 int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const void* d_minus, const void* d_plus,
@@ -523,69 +513,122 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
     return launch_jfa_final(ctx, fr, d_words, d_scratch, fill_unset, d_sdf);
 }
 
-// ---- whole-volume form of the slab passes (ghost-plane pipelines) -------------------------------
-// The caller holds id volumes of the WHOLE grid and asks for a region of planes per pass; the layout inside a volume is the library's:
-// plain 4-byte ids up to n = 1024, the compact word plane + byte plane above (5 instead of 8 bytes per voxel, jfa.hip: IdC).
-static bool volume_compact(const Frame& whole) { return jfa_compact_applies(whole, VP_ALGO_TILED); }
-
-size_t vp_jfa_volume_bytes(const vp_frame* f)
+// ---- id windows: the slab form of the tile kernels ------------------------------------------------
+size_t vp_jfa_window_bytes(const vp_frame* f, uint32_t planes)
 {
-    if (!f || check_frame(f, "vp_jfa_volume_bytes", false) != 0) return 0;
-    vp_frame w = *f; w.z0 = 0; w.z1 = f->n;
-    const Frame fr = make_frame(&w);
-    const size_t vox = (size_t)f->n * f->n * f->n;
-    return vox * (volume_compact(fr) ? 5 : jfa_id_bytes(fr));
+    if (!f || check_frame(f, "vp_jfa_window_bytes", false) != 0) return 0;
+    return win_bytes(f->n, planes);
 }
 
-static int volume_check(vp_ctx* ctx, const vp_frame* f, const char* who, Frame& region, Frame& whole, size_t& planeBytes)
+int vp_jfa_window_span(const vp_frame* f, uint32_t planes, uint32_t p0, uint32_t p1, size_t offset[2], size_t bytes[2])
 {
-    if (!ctx) return set_error(VP_ERR_INVALID, "%s: null ctx", who);
-    VP_TRY(bind_device(ctx));
-    VP_TRY(check_frame(f, who, false));
-    vp_frame w = *f; w.z0 = 0; w.z1 = f->n;
-    whole = make_frame(&w);
-    region = make_frame(f);
-    if (!jfa_can_fuse_first_two(whole, VP_ALGO_TILED))
-        return set_error(VP_ERR_UNSUPPORTED, "%s: the volume calls need n >= 96 (VP_ALGO_TILED)", who);
-    region.compact = whole.compact = volume_compact(whole) ? 1u : 0u;
-    planeBytes = (size_t)f->n * f->n * (region.compact ? 4 : jfa_id_bytes(whole));   // of the (word) plane the passes address
+    if (!offset || !bytes) return set_error(VP_ERR_INVALID, "vp_jfa_window_span: null argument");
+    VP_TRY(check_frame(f, "vp_jfa_window_span", false));
+    if (p0 > p1 || p1 > planes) return set_error(VP_ERR_INVALID, "vp_jfa_window_span: planes [%u, %u) of %u", p0, p1, planes);
+    const size_t wp = win_plane_bytes(f->n), bp = (size_t)f->n * f->n;
+    offset[0] = (size_t)p0 * wp; bytes[0] = (size_t)(p1 - p0) * wp;
+    offset[1] = (size_t)planes * wp + (size_t)p0 * bp; bytes[1] = win_compact(f->n) ? (size_t)(p1 - p0) * bp : 0;
     return 0;
 }
 
-int vp_jfa_volume_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_vol)
+// A window and the frame it is used with: the planes of f must lie inside it; `below` / `above` = planes the call reads beyond them.
+static int window_check(vp_ctx* ctx, const vp_frame* f, const vp_window* w, const char* who, uint32_t below, uint32_t above, IdWin& out)
 {
-    if (!d_border_grid || !d_vol) return set_error(VP_ERR_INVALID, "vp_jfa_volume_first_two: null argument");
-    Frame region, whole; size_t pb;
-    VP_TRY(volume_check(ctx, f, "vp_jfa_volume_first_two", region, whole, pb));
-    if (f->z0 != 0 || f->z1 != f->n) return set_error(VP_ERR_INVALID, "vp_jfa_volume_first_two: whole-grid frame required");
-    return launch_jfa_first_two(ctx, whole, d_border_grid, d_vol);
+    if (!ctx || !w || !w->d_ids) return set_error(VP_ERR_INVALID, "%s: null argument", who);
+    VP_TRY(bind_device(ctx));
+    VP_TRY(check_frame(f, who, false));
+    VP_TRY(check_aligned(who, {w->d_ids}));
+    if (f->n < kTileMinN) return set_error(VP_ERR_UNSUPPORTED, "%s: windows are the layout of the tile kernels (n >= %u)", who, kTileMinN);
+    const uint64_t nz = f->z1 - f->z0;
+    if (w->planes == 0 || (uint64_t)w->at + nz + above > w->planes || w->at < below)
+        return set_error(VP_ERR_INVALID, "%s: planes [%u, %u) at index %u (+%u below, +%u above) do not fit a window of %u planes", who, f->z0, f->z1, w->at, below, above, w->planes);
+    out.base = (char*)w->d_ids; out.planes = w->planes; out.at = w->at;
+    return 0;
 }
 
-int vp_jfa_volume_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const void* d_vol_in, void* d_vol_out)
+int vp_jfa_window_clear(vp_ctx* ctx, const vp_frame* f, const vp_window* w)
 {
-    if (!d_vol_in || !d_vol_out || d_vol_in == d_vol_out) return set_error(VP_ERR_INVALID, "vp_jfa_volume_pass: bad buffers");
-    Frame region, whole; size_t pb;
-    VP_TRY(volume_check(ctx, f, "vp_jfa_volume_pass", region, whole, pb));
-    if (k == 0 || k * 8 > f->n) return set_error(VP_ERR_INVALID, "vp_jfa_volume_pass: step %u (the volume passes start at n/8, after vp_jfa_volume_first_two)", k);
-    const char* in = (const char*)d_vol_in + (size_t)f->z0 * pb;
-    // halo pointers as vp_jfa_pass wants them (indexed from the unclipped start): the volume is contiguous, so they are plain offsets
-    const char* mi = f->z0 == 0 ? nullptr : reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(d_vol_in) + (uintptr_t)(((ptrdiff_t)f->z0 - (ptrdiff_t)k) * (ptrdiff_t)pb));
-    const char* pl = f->z1 >= f->n ? nullptr : (const char*)d_vol_in + (size_t)std::max(f->z1, f->z0 + k) * pb;
-    return launch_jfa_pass(ctx, region, k, in, mi, pl, (char*)d_vol_out + (size_t)f->z0 * pb, VP_ALGO_TILED);
+    if (!ctx || !w || !w->d_ids || !w->planes) return set_error(VP_ERR_INVALID, "vp_jfa_window_clear: null argument");
+    VP_TRY(bind_device(ctx));
+    VP_TRY(check_frame(f, "vp_jfa_window_clear", false));
+    VP_TRY(check_aligned("vp_jfa_window_clear", {w->d_ids}));
+    IdWin iw; iw.base = (char*)w->d_ids; iw.planes = w->planes; iw.at = 0;
+    return launch_win_clear(ctx, f->n, iw);
 }
 
-int vp_jfa_volume_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_vol_in, void* d_vol_scratch, const uint32_t* d_words_region,
-                            float fill_unset, float* d_sdf_region)
+int vp_jfa_window_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const uint32_t* d_plane_below,
+                       const uint32_t* d_plane_above, const vp_window* out)
 {
-    if (!d_vol_in || !d_vol_scratch || !d_words_region || !d_sdf_region || d_vol_in == d_vol_scratch)
-        return set_error(VP_ERR_INVALID, "vp_jfa_volume_last_pass: bad buffers");
-    Frame region, whole; size_t pb;
-    VP_TRY(volume_check(ctx, f, "vp_jfa_volume_last_pass", region, whole, pb));
-    VP_TRY(check_fill(fill_unset, "vp_jfa_volume_last_pass"));
-    const char* in = (const char*)d_vol_in + (size_t)f->z0 * pb;
-    const char* mi = f->z0 == 0 ? nullptr : reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(d_vol_in) + (uintptr_t)(((ptrdiff_t)f->z0 - 1) * (ptrdiff_t)pb));
-    const char* pl = f->z1 >= f->n ? nullptr : (const char*)d_vol_in + (size_t)std::max(f->z1, f->z0 + 1) * pb;
-    return launch_jfa_pass_ex(ctx, region, 1, in, mi, pl, (char*)d_vol_scratch + (size_t)f->z0 * pb, VP_ALGO_TILED, d_words_region, fill_unset, d_sdf_region);
+    if (!d_words) return set_error(VP_ERR_INVALID, "vp_jfa_window_init: null argument");
+    IdWin w;
+    VP_TRY(window_check(ctx, f, out, "vp_jfa_window_init", 0, 0, w));
+    VP_TRY(check_aligned("vp_jfa_window_init", {d_words, d_plane_below, d_plane_above}));
+    return launch_win_init(ctx, make_frame(f), d_words, d_plane_below, d_plane_above, w);
+}
+
+int vp_jfa_window_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, const vp_window* out)
+{
+    if (!d_border_grid) return set_error(VP_ERR_INVALID, "vp_jfa_window_first_pass: null argument");
+    IdWin w;
+    VP_TRY(window_check(ctx, f, out, "vp_jfa_window_first_pass", 0, 0, w));
+    VP_TRY(check_aligned("vp_jfa_window_first_pass", {d_border_grid}));
+    const Frame fr = make_frame(f);
+    if (!jfa_can_start_from_mask(fr, VP_ALGO_TILED)) return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_window_first_pass: needs n %% 128 == 0");
+    return launch_win_first_pass(ctx, fr, d_border_grid, w);
+}
+
+int vp_jfa_window_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, const vp_window* out)
+{
+    if (!d_border_grid) return set_error(VP_ERR_INVALID, "vp_jfa_window_first_two: null argument");
+    IdWin w;
+    VP_TRY(window_check(ctx, f, out, "vp_jfa_window_first_two", 0, 0, w));
+    VP_TRY(check_aligned("vp_jfa_window_first_two", {d_border_grid}));
+    const Frame fr = make_frame(f);
+    if (!jfa_can_fuse_first_two(fr, VP_ALGO_TILED) || w.planes != f->n || w.at != 0)
+        return set_error(VP_ERR_INVALID, "vp_jfa_window_first_two: whole-grid frame and a window of n planes (at = 0) required");
+    return launch_win_first_two(ctx, fr, d_border_grid, w);
+}
+
+// planes a pass with step k reads below / above the planes of f, in window planes
+static void pass_reach(const vp_frame* f, uint32_t k, uint32_t stride, uint32_t& below, uint32_t& above)
+{
+    if (stride == k) {                                              // consecutive planes: as far as the grid goes
+        below = std::min(k, f->z0);
+        above = std::min(k, f->n - f->z1);
+    } else {                                                       // whole slabs `stride` planes away
+        below = f->z1 > k ? stride : 0;                            // some plane z of f has z - k >= 0
+        above = f->z0 + k < f->n ? stride : 0;
+    }
+}
+
+static int window_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const vp_window* in, const vp_window* out, uint32_t stride,
+                       const uint32_t* d_words, float fill, float* d_sdf, const char* who)
+{
+    if (!in || !out || !in->d_ids || !out->d_ids || in->d_ids == out->d_ids) return set_error(VP_ERR_INVALID, "%s: bad windows", who);
+    if (in->planes != out->planes || in->at != out->at) return set_error(VP_ERR_INVALID, "%s: the two windows must have the same planes / at", who);
+    if (!f || k == 0 || k >= f->n) return set_error(VP_ERR_INVALID, "%s: step %u out of range", who, k);
+    if (stride == 0 || (stride != k && (k < f->z1 - f->z0 || stride < f->z1 - f->z0)))
+        return set_error(VP_ERR_INVALID, "%s: stride %u: either the step itself or, for a step of at least the slab height, the distance of the slabs in the window", who, stride);
+    uint32_t below = 0, above = 0;
+    pass_reach(f, k, stride, below, above);
+    IdWin wi, wo;
+    VP_TRY(window_check(ctx, f, in, who, below, above, wi));
+    VP_TRY(window_check(ctx, f, out, who, 0, 0, wo));
+    return launch_win_pass(ctx, make_frame(f), k, wi, wo, stride, d_words, fill, d_sdf);
+}
+
+int vp_jfa_window_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const vp_window* in, const vp_window* out, uint32_t stride)
+{
+    return window_pass(ctx, f, k, in, out, stride, nullptr, 0.0f, nullptr, "vp_jfa_window_pass");
+}
+
+int vp_jfa_window_last_pass(vp_ctx* ctx, const vp_frame* f, const vp_window* in, const vp_window* scratch, uint32_t stride,
+                            const uint32_t* d_words_region, float fill_unset, float* d_sdf_region)
+{
+    if (!d_words_region || !d_sdf_region) return set_error(VP_ERR_INVALID, "vp_jfa_window_last_pass: null argument");
+    VP_TRY(check_aligned("vp_jfa_window_last_pass", {d_words_region, d_sdf_region}));
+    VP_TRY(check_fill(fill_unset, "vp_jfa_window_last_pass"));
+    return window_pass(ctx, f, 1, in, scratch, stride, d_words_region, fill_unset, d_sdf_region, "vp_jfa_window_last_pass");
 }
 
 // ---- export front end -------------------------------------------------------------------------

@@ -6,18 +6,17 @@
 //
 //   voxelize   every (y, z) column is independent (vox/sequential.cpp:40-57): each device rasterises the mesh into its slab.
 //   CSG        word-wise: each device combines its slabs.
-//   JFA        VP_MULTI_HALO   init needs one bitmask plane from each Z-neighbour; the pass with step k needs the id planes
+//   JFA        on id windows (include/vphip.h, vp_jfa_window_*), three ways of feeding a pass its planes z -+ k:
+//                  VP_MULTI_HALO   seeding needs one bitmask plane from each Z-neighbour; the pass with step k needs the id planes
 //                              [z0-k, min(z0, z1-k)) and [max(z1, z0+k), z1+k) from whoever owns them.  They are moved with
 //                              hipMemcpyPeerAsync on the RECEIVER's stream behind an event of the sender's stream, and every
 //                              stream waits for the copies that read its buffers before it overwrites them two passes later:
-//                              the whole JFA is enqueued without a host synchronisation.  Halos of the narrow passes
-//                              (k <= nz/2) land directly below / above the slab inside one allocation, so those passes see
-//                              one contiguous volume (the dense tile kernel applies).
-//                  VP_MULTI_HYBRID (round 4) ghost planes for the passes with k > nz/2, halo copies from the two adjacent ranks for the
-//                              others; id buffers hold only the window of planes a rank touches (jfa_hybrid below).
+//                              the whole JFA is enqueued without a host synchronisation (jfa_halo below).
+//                  VP_MULTI_HYBRID ghost planes for the passes with k > nz/2, halo copies from the two adjacent ranks for the
+//                              others; the windows hold only the planes a rank touches (jfa_hybrid below).
 //                  VP_MULTI_GHOST  no exchange between passes: the bitmask slabs are all-gathered once (n^3/8 bytes), every
 //                              device runs pass i on its slab widened by the reach of the later passes and the regions shrink
-//                              to the bare slab at k = 1.  Costs two full id volumes per device.
+//                              to the bare slab at k = 1.  Costs two windows of the whole grid per device.
 //
 // Every stage is a pure function of the previous buffers, so the concatenated slabs are bit-identical to the single-device
 // result for any number of devices -- including several contexts on ONE device, which is how the tests run it.
@@ -42,9 +41,10 @@ struct Rank {
     Buffer words;                              // bitmask of the slab (halo) / of the whole grid (ghost, after the all-gather)
     Buffer other;                              // second operand of a CSG
     Buffer below, above;                       // bitmask planes z0-1 / z1
-    Buffer ids[2];                             // halo: [H | nz | H] planes each; ghost: whole volumes
-    Buffer minus, plus;                        // halo: whole slabs of distant ranks (wide passes)
-    Buffer border;                             // ghost: border mask of the whole grid
+    Buffer ids[2];                             // the two id windows of the last vp_multi_jfa (ensure_windows)
+    uint32_t win_n = 0, win_planes = 0;        // ... and their geometry
+    Buffer border;                             // ghost / hybrid: border mask of the whole grid
+    Buffer whole_sdf;                          // n < 96 (not sharded): sdf of the whole grid
     Buffer sdf;                                // slab
     hipEvent_t ready = nullptr;                // "my buffers hold what the peers may read"
     hipEvent_t copied = nullptr;               // "the copies INTO my buffers of this step are done"
@@ -76,18 +76,33 @@ int grow(Rank& r, Buffer& b, size_t bytes)
     return reserve(r.ctx, b, bytes ? bytes : 1);
 }
 
-// Id volumes are filled once when they are (re)allocated: the ghost regions below are rounded OUTWARDS to the 8-plane tile, and the
-// excess planes of a pass read planes the pass before it never produced (see ghost_regions).  What they read is then stale or this
-// fill -- never memory nobody wrote.  VP_MULTI_POISON=<byte> (tests) fills with that byte instead of 0 to show the results do not
-// depend on it.
-int grow_ids(Rank& r, Buffer& b, size_t bytes)
+// The id windows of a rank (two buffers of `planes` id planes in the library's layout, include/vphip.h: vp_jfa_window_*).  They are
+// cleared -- every id := "none" -- whenever their geometry changes: the ghost regions below are rounded OUTWARDS to the 8-plane tile, and
+// the excess planes of a pass read planes the pass before it never produced (see ghost_regions).  What they read is then "none" or ids an
+// earlier job left in the SAME layout -- never memory nobody wrote, never bytes of another layout.
+// Test builds (-DVP_TEST_HOOKS, libvphip_hooks.so): VP_MULTI_POISON=<byte> refills the word planes with that byte before every job to
+// show that the results do not depend on what those planes hold.
+int ensure_windows(Rank& r, const vp_frame& G, uint32_t planes)
 {
-    const size_t before = b.bytes;
     VP_TRY(bind(r));
-    VP_TRY(reserve(r.ctx, b, bytes ? bytes : 1, /*headroom=*/false));   // exact: a window must not cost more than it saves
+    const size_t bytes = vp_jfa_window_bytes(&G, planes);
+    bool fresh = r.win_n != G.n || r.win_planes != planes;
+    for (Buffer& b : r.ids) {
+        const void* before = b.ptr;
+        VP_TRY(reserve(r.ctx, b, bytes, /*headroom=*/false));       // exact: a window must not cost more than it saves
+        fresh = fresh || b.ptr != before;
+    }
+    r.win_n = G.n; r.win_planes = planes;
+#ifdef VP_TEST_HOOKS
     const char* poison = getenv("VP_MULTI_POISON");
-    if (b.bytes != before || poison)
-        VP_HIP(hipMemsetAsync(b.ptr, poison ? (int)strtol(poison, nullptr, 0) & 0xFF : 0, b.bytes, r.ctx->stream));
+    fresh = fresh || poison != nullptr;
+#endif
+    if (fresh)
+        for (int i = 0; i < 2; ++i) { const vp_window w{r.ids[i].ptr, planes, 0}; VP_TRY(vp_jfa_window_clear(r.ctx, &G, &w)); }
+#ifdef VP_TEST_HOOKS
+    if (poison)
+        for (Buffer& b : r.ids) VP_HIP(hipMemsetAsync(b.ptr, (int)strtol(poison, nullptr, 0) & 0xFF, (size_t)planes * G.n * G.n * 4, r.ctx->stream));
+#endif
     return 0;
 }
 
@@ -202,19 +217,62 @@ std::vector<Region> ghost_regions(uint32_t n, uint32_t z0, uint32_t z1)
     return out;
 }
 
-int jfa_halo(vp_multi* m, float fill, int algo)
+// `count` id planes from index `sp` of a window of src (splanes planes) to index `dp` of a window of dst (dplanes): one or two byte ranges
+// (above n = 1024 the word planes and the byte planes: 5 bytes per voxel on the wire)
+int copy_planes(vp_multi* m, uint32_t dplanes, Rank& dst, int dwhich, uint32_t dp, uint32_t splanes, const Rank& src, int swhich, uint32_t sp, uint32_t count)
+{
+    size_t so[2], sb[2], dof[2], db[2];
+    VP_TRY(vp_jfa_window_span(&m->frame, splanes, sp, sp + count, so, sb));
+    VP_TRY(vp_jfa_window_span(&m->frame, dplanes, dp, dp + count, dof, db));
+    for (int i = 0; i < 2; ++i)
+        VP_TRY(peer_copy(m, dst, (char*)dst.ids[dwhich].ptr + dof[i], src, (const char*)src.ids[swhich].ptr + so[i], sb[i]));
+    return 0;
+}
+
+// all-gather of the bitmask slabs: every device ends up with the whole grid (its own slab stays where it is: plane z0)
+int gather_words(vp_multi* m)
+{
+    const uint32_t world = (uint32_t)m->ranks.size();
+    const size_t slabWords = (size_t)(m->frame.n / world) * ((size_t)m->frame.n * m->frame.n / 8);
+    for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
+    for (uint32_t r = 0; r < world; ++r)
+        for (uint32_t o = 0; o < world; ++o)
+            if (o != r) VP_TRY(peer_copy(m, m->ranks[r], (char*)m->ranks[r].words.ptr + (size_t)o * slabWords, m->ranks[o],
+                                         (const char*)m->ranks[o].words.ptr + (size_t)o * slabWords, slabWords));
+    if (world > 1) VP_TRY(fence_copies(m));
+    return 0;
+}
+
+// Grids below the tile kernels' range (n < 96: at most 64^3 voxels, 0.06 ms per JFA) are not sharded: every device computes the whole
+// grid and keeps its slab.
+int jfa_small(vp_multi* m, float fill, int algo)
+{
+    const vp_frame& G = m->frame;
+    const size_t plane = (size_t)G.n * G.n;
+    VP_TRY(gather_words(m));
+    for (Rank& r : m->ranks) {
+        VP_TRY(grow(r, r.whole_sdf, vp_grid_voxels(&G) * 4));
+        VP_TRY(grow(r, r.sdf, (size_t)(r.z1 - r.z0) * plane * 4));
+        VP_TRY(vp_jfa(r.ctx, &G, (const uint32_t*)r.words.ptr, fill, (float*)r.whole_sdf.ptr, nullptr, 0, algo));
+        VP_TRY(vp_memcpy_d2d(r.ctx, r.sdf.ptr, (const char*)r.whole_sdf.ptr + (size_t)r.z0 * plane * 4, (size_t)(r.z1 - r.z0) * plane * 4));
+    }
+    return 0;
+}
+
+// VP_MULTI_HALO.  A rank's windows hold [slab of z - k | own slab | slab of z + k] = 3 nz planes, the own slab in the middle.  The halos
+// of the narrow passes (k <= nz/2) land in the k planes right below / above the slab (stride = k: consecutive planes); for the wide
+// passes (k >= nz: whole slabs of distant ranks) the received slabs land nz planes below / above the own planes and the tile kernel runs
+// with stride = nz -- no separate whole-slab buffers, no second kernel for them.
+int jfa_halo(vp_multi* m, float fill)
 {
     const vp_frame& G = m->frame;
     const uint32_t n = G.n, world = (uint32_t)m->ranks.size(), nz = n / world;
-    const size_t S = vp_jfa_id_bytes(&G), planeIds = (size_t)n * n * S, planeWords = (size_t)n * n / 8;   // bytes
-    const uint32_t H = world > 1 ? nz / 2 : 0;
+    const size_t planeWords = (size_t)n * n / 8;                   // bytes
+    const uint32_t planes = world > 1 ? 3 * nz : nz, at = world > 1 ? nz : 0;
     for (Rank& r : m->ranks) {
-        for (Buffer& b : r.ids) VP_TRY(grow_ids(r, b, (size_t)(nz + 2 * H) * planeIds));
+        VP_TRY(ensure_windows(r, G, planes));
         VP_TRY(grow(r, r.sdf, (size_t)nz * n * n * 4));
-        if (world > 1) {
-            VP_TRY(grow(r, r.minus, (size_t)nz * planeIds)); VP_TRY(grow(r, r.plus, (size_t)nz * planeIds));
-            VP_TRY(grow(r, r.below, planeWords)); VP_TRY(grow(r, r.above, planeWords));
-        }
+        if (world > 1) { VP_TRY(grow(r, r.below, planeWords)); VP_TRY(grow(r, r.above, planeWords)); }
     }
     // bitmask planes for the 26-neighbourhood of the seeding (jfa/sequential.cpp:24-64)
     for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
@@ -225,132 +283,69 @@ int jfa_halo(vp_multi* m, float fill, int algo)
     }
     if (world > 1) VP_TRY(fence_copies(m));
     int cur = 0;
-    auto slab_ids = [&](Rank& r, int which) { return (char*)r.ids[which].ptr + (size_t)H * planeIds; };
     for (uint32_t r = 0; r < world; ++r) {
         Rank& me = m->ranks[r];
         const vp_frame f = slab_frame(G, me.z0, me.z1);
-        VP_TRY(vp_jfa_init(me.ctx, &f, (const uint32_t*)slab_words(m, me), r > 0 ? (const uint32_t*)me.below.ptr : nullptr,
-                           r + 1 < world ? (const uint32_t*)me.above.ptr : nullptr, slab_ids(me, cur)));
+        const vp_window w{me.ids[cur].ptr, planes, at};
+        VP_TRY(vp_jfa_window_init(me.ctx, &f, (const uint32_t*)slab_words(m, me), r > 0 ? (const uint32_t*)me.below.ptr : nullptr,
+                                  r + 1 < world ? (const uint32_t*)me.above.ptr : nullptr, &w));
     }
     for (uint32_t k = n / 2; k >= 1; k /= 2) {
-        const bool narrow = k <= H;
+        const uint32_t stride = (world > 1 && k >= nz) ? nz : k;
         if (world > 1) {
             for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
             for (const HaloMove& h : halo_plan(n, world, k)) {
                 if (h.src == h.dst) continue;
                 Rank& dst = m->ranks[h.dst];
                 const Rank& src = m->ranks[h.src];
-                // where plane g of the receiver's minus / plus buffer lives (include/vphip.h, vp_jfa_pass)
-                const int64_t base = h.minusSide ? (int64_t)dst.z0 - k : std::max<int64_t>(dst.z1, (int64_t)dst.z0 + k);
-                char* buf = narrow ? (h.minusSide ? slab_ids(dst, cur) - (size_t)k * planeIds : slab_ids(dst, cur) + (size_t)nz * planeIds)
-                                   : (char*)(h.minusSide ? dst.minus.ptr : dst.plus.ptr);
-                VP_TRY(peer_copy(m, dst, buf + (size_t)(h.g0 - base) * planeIds, src,
-                                 (const char*)m->ranks[h.src].ids[cur].ptr + (size_t)(H + h.g0 - src.z0) * planeIds, (size_t)(h.g1 - h.g0) * planeIds));
+                // global plane g feeds the plane z = g + k (minus side) / g - k (plus side) of the receiver, which sits `stride` planes away from it
+                const int64_t dp = h.minusSide ? (int64_t)at + ((int64_t)h.g0 + k - dst.z0) - stride : (int64_t)at + ((int64_t)h.g0 - k - dst.z0) + stride;
+                VP_TRY(copy_planes(m, planes, dst, cur, (uint32_t)dp, planes, src, cur, at + (h.g0 - src.z0), h.g1 - h.g0));
             }
             VP_TRY(fence_copies(m));
         }
         for (uint32_t r = 0; r < world; ++r) {
             Rank& me = m->ranks[r];
             const vp_frame f = slab_frame(G, me.z0, me.z1);
-            const void* in = slab_ids(me, cur);
-            const void *mi = nullptr, *pl = nullptr;
-            if (world > 1) {
-                mi = narrow ? (const void*)((const char*)in - (size_t)k * planeIds) : me.minus.ptr;
-                pl = narrow ? (const void*)((const char*)in + (size_t)nz * planeIds) : me.plus.ptr;
-            }
-            if (k == 1) VP_TRY(vp_jfa_last_pass(me.ctx, &f, in, mi, pl, slab_ids(me, cur ^ 1), (const uint32_t*)slab_words(m, me), fill, (float*)me.sdf.ptr, algo));
-            else        VP_TRY(vp_jfa_pass(me.ctx, &f, k, in, mi, pl, slab_ids(me, cur ^ 1), algo));
+            const vp_window in{me.ids[cur].ptr, planes, at}, out{me.ids[cur ^ 1].ptr, planes, at};
+            if (k == 1) VP_TRY(vp_jfa_window_last_pass(me.ctx, &f, &in, &out, stride, (const uint32_t*)slab_words(m, me), fill, (float*)me.sdf.ptr));
+            else        VP_TRY(vp_jfa_window_pass(me.ctx, &f, k, &in, &out, stride));
         }
         cur ^= 1;
     }
     return 0;
 }
 
-int jfa_ghost(vp_multi* m, float fill, int algo)
+// VP_MULTI_GHOST: windows of the whole grid (n planes, a plane sits at its global index); the first two passes are the one whole-grid
+// launch of the single-device path on every rank (its second pass would cover 35 % of the grid or more on any rank of 2 .. 8 slabs: the
+// break-even of the measured kernel times, profiles/r03/slab_scaling_*.txt), every later pass runs on the rank's region.
+int jfa_ghost(vp_multi* m, float fill)
 {
     const vp_frame& G = m->frame;
     const uint32_t n = G.n, world = (uint32_t)m->ranks.size(), nz = n / world;
-    const size_t S = vp_jfa_id_bytes(&G), planeIds = (size_t)n * n * S, planeWords = (size_t)n * n / 8;
-    const size_t slabWords = (size_t)nz * planeWords;
-    // Whole-volume calls (round 4; vp_jfa_volume_*) where the first two passes run as the one whole-grid launch anyway -- every rank of
-    // 2 .. 8 slabs -- and always above n = 1024, where the library then keeps the volumes in its compact 5-byte layout (2 x 40 instead of
-    // 2 x 64 GiB per device at n = 2048).  VP_GHOST_VOLUME=0 (dev / tests) keeps the caller-addressed planes.
-    const char* pctEnv = getenv("VP_FUSED_FIRST_TWO_PCT");
-    const uint64_t fuseThreshold = pctEnv ? strtoull(pctEnv, nullptr, 10) : 35ull;
-    const char* volEnv = getenv("VP_GHOST_VOLUME");
-    bool volume = algo == VP_ALGO_TILED && !(volEnv && volEnv[0] == '0') && n >= 16 && vp_jfa_can_fuse_first_two(&G, algo) != 0;
-    if (volume && n <= 1024)
-        for (Rank& r : m->ranks) {
-            const std::vector<Region> regs = ghost_regions(n, r.z0, r.z1);
-            if ((uint64_t)(regs[1].b1 - regs[1].b0) * 100 < fuseThreshold * n) volume = false;
-        }
-    const size_t volBytes = volume ? vp_jfa_volume_bytes(&G) : (size_t)n * planeIds;
-    // all-gather of the bitmask slabs: every device ends up with the whole grid (its own slab stays where it is: plane z0)
+    const size_t planeWords = (size_t)n * n / 8;
     for (Rank& r : m->ranks) {
         VP_TRY(grow(r, r.border, (size_t)n * planeWords));
-        for (Buffer& b : r.ids) VP_TRY(grow_ids(r, b, volBytes));
+        VP_TRY(ensure_windows(r, G, n));
         VP_TRY(grow(r, r.sdf, (size_t)nz * n * n * 4));
     }
-    // words buffers of the ghost mode hold the whole grid with the rank's own slab at its global position (see vp_multi_set_grid /
-    // vp_multi_voxelize, which place it there when the mode is known; here the slabs of the peers are filled in)
-    for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
-    for (uint32_t r = 0; r < world; ++r)
-        for (uint32_t o = 0; o < world; ++o)
-            if (o != r) VP_TRY(peer_copy(m, m->ranks[r], (char*)m->ranks[r].words.ptr + (size_t)o * slabWords, m->ranks[o],
-                                         (const char*)m->ranks[o].words.ptr + (size_t)o * slabWords, slabWords));
-    if (world > 1) VP_TRY(fence_copies(m));
+    // words buffers hold the whole grid with the rank's own slab at its global position (vp_multi_set_grid / vp_multi_voxelize place it
+    // there); here the slabs of the peers are filled in
+    VP_TRY(gather_words(m));
     for (uint32_t r = 0; r < world; ++r) {
         Rank& me = m->ranks[r];
         const std::vector<Region> regs = ghost_regions(n, me.z0, me.z1);
-        const size_t last = regs.size() - 1;
-        char* a = (char*)me.ids[0].ptr;
-        char* b = (char*)me.ids[1].ptr;
         const uint32_t* words = (const uint32_t*)me.words.ptr;
-        if (volume) {
-            VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
-            VP_TRY(vp_jfa_volume_first_two(me.ctx, &G, (const uint32_t*)me.border.ptr, a));
-            for (size_t i = 2; i < regs.size(); ++i) {
-                const Region& g = regs[i];
-                const vp_frame f = slab_frame(G, g.b0, g.b1);
-                if (i == last) { VP_TRY(vp_jfa_volume_last_pass(me.ctx, &f, a, b, words + (size_t)g.b0 * (planeWords / 4), fill, (float*)me.sdf.ptr)); break; }
-                VP_TRY(vp_jfa_volume_pass(me.ctx, &f, g.k, a, b));
-                std::swap(a, b);
-            }
-            continue;
-        }
-        const bool maskStart = last > 0 && vp_jfa_can_start_from_mask(&G, algo);
-        if (maskStart) VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
-        else           VP_TRY(vp_jfa_init(me.ctx, &G, words, nullptr, nullptr, a));
-        size_t skip = 0;
-        // the first two passes as ONE whole-grid launch where the second pass covers at least 35 % of the grid: break-even of the
-        // measured kernel times (jfa_first_two 0.30 / 2.13 ms against first pass + fraction x second pass), as in slab.py:
-        // fused_first_two_threshold(); every rank of 2 .. 8 slabs is above it
-        const uint64_t threshold = fuseThreshold;                 // VP_FUSED_FIRST_TWO_PCT (dev / tests): 101 forces the two region passes
-        if (maskStart && last >= 2 && vp_jfa_can_fuse_first_two(&G, algo) && (uint64_t)(regs[1].b1 - regs[1].b0) * 100 >= threshold * n) {
-            VP_TRY(vp_jfa_first_two(me.ctx, &G, (const uint32_t*)me.border.ptr, b));
-            std::swap(a, b);
-            skip = 2;
-        }
-        for (size_t i = skip; i < regs.size(); ++i) {
+        int cur = 0;
+        VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
+        { const vp_window w{me.ids[cur].ptr, n, 0}; VP_TRY(vp_jfa_window_first_two(me.ctx, &G, (const uint32_t*)me.border.ptr, &w)); }
+        for (size_t i = 2; i < regs.size(); ++i) {
             const Region& g = regs[i];
             const vp_frame f = slab_frame(G, g.b0, g.b1);
-            // whole volumes addressed by global plane: minus starts k planes below the region, plus at max(b1, b0 + k)
-            const char* in = a + (size_t)g.b0 * planeIds;
-            // (include/vphip.h, vp_jfa_pass: the halo pointers are indexed from the UNCLIPPED start z0 - k, which lies before the
-            // volume when b0 < k: formed by integer arithmetic, never dereferenced below plane 0; null where there is no plane at all)
-            const char* mi = g.b0 == 0 ? nullptr
-                                       : reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(a) + (uintptr_t)(((ptrdiff_t)g.b0 - (ptrdiff_t)g.k) * (ptrdiff_t)planeIds));
-            const char* pl = g.b1 >= n ? nullptr : a + (size_t)std::max(g.b1, g.b0 + g.k) * planeIds;
-            char* out = b + (size_t)g.b0 * planeIds;
-            if (i == 0 && maskStart) {
-                VP_TRY(vp_jfa_first_pass(me.ctx, &f, (const uint32_t*)me.border.ptr, out));
-            } else if (i == last) {
-                VP_TRY(vp_jfa_last_pass(me.ctx, &f, in, mi, pl, out, words + (size_t)g.b0 * (planeWords / 4), fill, (float*)me.sdf.ptr, algo));
-                break;
-            } else {
-                VP_TRY(vp_jfa_pass(me.ctx, &f, g.k, in, mi, pl, out, algo));
-            }
-            std::swap(a, b);
+            const vp_window in{me.ids[cur].ptr, n, g.b0}, out{me.ids[cur ^ 1].ptr, n, g.b0};
+            if (i + 1 == regs.size()) VP_TRY(vp_jfa_window_last_pass(me.ctx, &f, &in, &out, 1, words + (size_t)g.b0 * (planeWords / 4), fill, (float*)me.sdf.ptr));
+            else                      VP_TRY(vp_jfa_window_pass(me.ctx, &f, g.k, &in, &out, g.k));
+            cur ^= 1;
         }
     }
     return 0;
@@ -384,13 +379,12 @@ HybridPlan hybrid_plan(uint32_t n, uint32_t world, uint32_t z0, uint32_t z1, boo
     return p;
 }
 
-int jfa_hybrid(vp_multi* m, float fill, int algo)
+int jfa_hybrid(vp_multi* m, float fill)
 {
     const vp_frame& G = m->frame;
     const uint32_t n = G.n, world = (uint32_t)m->ranks.size(), nz = n / world;
-    const size_t S = vp_jfa_id_bytes(&G), planeIds = (size_t)n * n * S, planeWords = (size_t)n * n / 8;
-    const size_t slabWords = (size_t)nz * planeWords;
-    const bool maskStart = vp_jfa_can_start_from_mask(&G, algo) != 0 && n / 2 > 1;
+    const size_t planeWords = (size_t)n * n / 8;
+    const bool maskStart = vp_jfa_can_start_from_mask(&G, VP_ALGO_TILED) != 0;
     std::vector<HybridPlan> plans;
     m->window_lo.assign(world, 0); m->window_hi.assign(world, 0);
     for (uint32_t r = 0; r < world; ++r) {
@@ -399,22 +393,15 @@ int jfa_hybrid(vp_multi* m, float fill, int algo)
         const HybridPlan& p = plans.back();
         m->window_lo[r] = p.lo; m->window_hi[r] = p.hi;
         VP_TRY(grow(me, me.border, (size_t)n * planeWords));
-        for (Buffer& b : me.ids) VP_TRY(grow_ids(me, b, (size_t)(p.hi - p.lo) * planeIds));
+        VP_TRY(ensure_windows(me, G, p.hi - p.lo));
         VP_TRY(grow(me, me.sdf, (size_t)nz * n * n * 4));
     }
-    // the wide passes need the bitmask of the whole grid on every device (as in the ghost mode): all-gather of the slabs
-    for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
-    for (uint32_t r = 0; r < world; ++r)
-        for (uint32_t o = 0; o < world; ++o)
-            if (o != r) VP_TRY(peer_copy(m, m->ranks[r], (char*)m->ranks[r].words.ptr + (size_t)o * slabWords, m->ranks[o],
-                                         (const char*)m->ranks[o].words.ptr + (size_t)o * slabWords, slabWords));
-    if (world > 1) VP_TRY(fence_copies(m));
+    // the wide passes need the bitmask of the whole grid on every device (as in the ghost mode)
+    VP_TRY(gather_words(m));
     const size_t nwide = plans[0].wide.size(), nnarrow = plans[0].narrow.size();     // the same on every rank (they depend on nz only)
     std::vector<int> cur(world, 0);
-    // plane g of rank r's id volume `which`
-    auto at = [&](uint32_t r, int which, int64_t g) {
-        return reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(m->ranks[r].ids[which].ptr) + (uintptr_t)((g - (int64_t)plans[r].lo) * (int64_t)planeIds));
-    };
+    // window `which` of rank r, positioned for a frame that starts at global plane g
+    auto win = [&](uint32_t r, int which, uint32_t g) { return vp_window{m->ranks[r].ids[which].ptr, plans[r].hi - plans[r].lo, g - plans[r].lo}; };
     // ---- wide passes: ghost planes inside the window, no exchange
     for (uint32_t r = 0; r < world; ++r) {
         Rank& me = m->ranks[r];
@@ -424,23 +411,23 @@ int jfa_hybrid(vp_multi* m, float fill, int algo)
         if (maskStart && nwide > 0) {
             VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
             const vp_frame f = slab_frame(G, p.wide[0].b0, p.wide[0].b1);
-            VP_TRY(vp_jfa_first_pass(me.ctx, &f, (const uint32_t*)me.border.ptr, at(r, 1, p.wide[0].b0)));
+            const vp_window w = win(r, 1, p.wide[0].b0);
+            VP_TRY(vp_jfa_window_first_pass(me.ctx, &f, (const uint32_t*)me.border.ptr, &w));
             cur[r] = 1; start = 1;
         } else {
             const vp_frame f = slab_frame(G, p.lo, p.hi);
-            VP_TRY(vp_jfa_init(me.ctx, &f, words + (size_t)p.lo * (planeWords / 4), p.lo > 0 ? words + (size_t)(p.lo - 1) * (planeWords / 4) : nullptr,
-                               p.hi < n ? words + (size_t)p.hi * (planeWords / 4) : nullptr, at(r, 0, p.lo)));
+            const vp_window w = win(r, 0, p.lo);
+            VP_TRY(vp_jfa_window_init(me.ctx, &f, words + (size_t)p.lo * (planeWords / 4), p.lo > 0 ? words + (size_t)(p.lo - 1) * (planeWords / 4) : nullptr,
+                                      p.hi < n ? words + (size_t)p.hi * (planeWords / 4) : nullptr, &w));
         }
         for (size_t i = start; i < nwide; ++i) {
             const Region& g = p.wide[i];
             const vp_frame f = slab_frame(G, g.b0, g.b1);
-            const int c = cur[r];
-            const char* mi = g.b0 == 0 ? nullptr : at(r, c, (int64_t)g.b0 - g.k);
-            const char* pl = g.b1 >= n ? nullptr : at(r, c, std::max(g.b1, g.b0 + g.k));
+            const vp_window in = win(r, cur[r], g.b0), out = win(r, cur[r] ^ 1, g.b0);
             if (i + 1 == nwide && nnarrow == 0)                     // one rank: the last pass is a wide one
-                VP_TRY(vp_jfa_last_pass(me.ctx, &f, at(r, c, g.b0), mi, pl, at(r, c ^ 1, g.b0), words + (size_t)g.b0 * (planeWords / 4), fill, (float*)me.sdf.ptr, algo));
+                VP_TRY(vp_jfa_window_last_pass(me.ctx, &f, &in, &out, 1, words + (size_t)g.b0 * (planeWords / 4), fill, (float*)me.sdf.ptr));
             else
-                VP_TRY(vp_jfa_pass(me.ctx, &f, g.k, at(r, c, g.b0), mi, pl, at(r, c ^ 1, g.b0), algo));
+                VP_TRY(vp_jfa_window_pass(me.ctx, &f, g.k, &in, &out, g.k));
             cur[r] ^= 1;
         }
     }
@@ -451,20 +438,19 @@ int jfa_hybrid(vp_multi* m, float fill, int algo)
             for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
             for (uint32_t r = 0; r < world; ++r) {
                 Rank& me = m->ranks[r];
-                if (r > 0)         VP_TRY(peer_copy(m, me, at(r, cur[r], (int64_t)me.z0 - k), m->ranks[r - 1], at(r - 1, cur[r - 1], (int64_t)me.z0 - k), (size_t)k * planeIds));
-                if (r + 1 < world) VP_TRY(peer_copy(m, me, at(r, cur[r], me.z1), m->ranks[r + 1], at(r + 1, cur[r + 1], me.z1), (size_t)k * planeIds));
+                const uint32_t mine = plans[r].hi - plans[r].lo;
+                if (r > 0)         VP_TRY(copy_planes(m, mine, me, cur[r], me.z0 - k - plans[r].lo, plans[r - 1].hi - plans[r - 1].lo, m->ranks[r - 1], cur[r - 1], me.z0 - k - plans[r - 1].lo, k));
+                if (r + 1 < world) VP_TRY(copy_planes(m, mine, me, cur[r], me.z1 - plans[r].lo, plans[r + 1].hi - plans[r + 1].lo, m->ranks[r + 1], cur[r + 1], me.z1 - plans[r + 1].lo, k));
             }
             VP_TRY(fence_copies(m));
         }
         for (uint32_t r = 0; r < world; ++r) {
             Rank& me = m->ranks[r];
             const vp_frame f = slab_frame(G, me.z0, me.z1);
-            const int c = cur[r];
-            const char* mi = me.z0 == 0 ? nullptr : at(r, c, (int64_t)me.z0 - k);
-            const char* pl = me.z1 >= n ? nullptr : at(r, c, me.z1);
+            const vp_window in = win(r, cur[r], me.z0), out = win(r, cur[r] ^ 1, me.z0);
             const uint32_t* slabW = (const uint32_t*)me.words.ptr + (size_t)me.z0 * (planeWords / 4);
-            if (j + 1 == nnarrow) VP_TRY(vp_jfa_last_pass(me.ctx, &f, at(r, c, me.z0), mi, pl, at(r, c ^ 1, me.z0), slabW, fill, (float*)me.sdf.ptr, algo));
-            else                  VP_TRY(vp_jfa_pass(me.ctx, &f, k, at(r, c, me.z0), mi, pl, at(r, c ^ 1, me.z0), algo));
+            if (j + 1 == nnarrow) VP_TRY(vp_jfa_window_last_pass(me.ctx, &f, &in, &out, 1, slabW, fill, (float*)me.sdf.ptr));
+            else                  VP_TRY(vp_jfa_window_pass(me.ctx, &f, k, &in, &out, k));
             cur[r] ^= 1;
         }
     }
@@ -512,7 +498,7 @@ int vp_multi_destroy(vp_multi* m)
         if (!r.ctx) continue;
         (void)hipSetDevice(r.device);
         (void)hipStreamSynchronize(r.ctx->stream);
-        Buffer* bufs[] = {&r.mesh_xyz, &r.mesh_tri, &r.words, &r.other, &r.below, &r.above, &r.ids[0], &r.ids[1], &r.minus, &r.plus, &r.border, &r.sdf};
+        Buffer* bufs[] = {&r.mesh_xyz, &r.mesh_tri, &r.words, &r.other, &r.below, &r.above, &r.ids[0], &r.ids[1], &r.border, &r.sdf, &r.whole_sdf};
         for (Buffer* b : bufs) release(*b);
         if (r.ready) (void)hipEventDestroy(r.ready);
         if (r.copied) (void)hipEventDestroy(r.copied);
@@ -612,9 +598,12 @@ int vp_multi_jfa(vp_multi* m, float fill_unset, int algo, int mode)
     if (mode != VP_MULTI_HALO && mode != VP_MULTI_GHOST && mode != VP_MULTI_HYBRID) return set_error(VP_ERR_INVALID, "vp_multi_jfa: mode %d", mode);
     m->bytes_moved = 0;
     m->last_mode = mode;
-    if (mode == VP_MULTI_GHOST) VP_TRY(jfa_ghost(m, fill_unset, algo));
-    else if (mode == VP_MULTI_HYBRID) VP_TRY(jfa_hybrid(m, fill_unset, algo));
-    else VP_TRY(jfa_halo(m, fill_unset, algo));
+    // The sharded forms run the tile kernels on id windows whatever `algo` says (both give the same sdf); below their range the grid is
+    // not sharded and `algo` picks the kernel of the whole-grid JFA every device runs.
+    if (m->frame.n < 96) VP_TRY(jfa_small(m, fill_unset, algo));
+    else if (mode == VP_MULTI_GHOST) VP_TRY(jfa_ghost(m, fill_unset));
+    else if (mode == VP_MULTI_HYBRID) VP_TRY(jfa_hybrid(m, fill_unset));
+    else VP_TRY(jfa_halo(m, fill_unset));
     m->have_sdf = true;
     return 0;
 }
@@ -636,15 +625,13 @@ int vp_multi_window(const vp_multi* m, int rank, uint32_t* lo, uint32_t* hi, uin
 {
     if (!m || rank < 0 || rank >= (int)m->ranks.size() || m->last_mode < 0) return set_error(VP_ERR_INVALID, "vp_multi_window: no JFA has run");
     const uint32_t n = m->frame.n, world = (uint32_t)m->ranks.size(), nz = n / world;
-    uint32_t a = 0, b = n;                                          // ghost: whole volumes
-    if (m->last_mode == VP_MULTI_HALO) { const uint32_t H = world > 1 ? nz / 2 : 0; a = m->ranks[rank].z0 > H ? m->ranks[rank].z0 - H : 0; b = std::min(n, m->ranks[rank].z1 + H); }
-    else if (m->last_mode == VP_MULTI_HYBRID) { a = m->window_lo[(size_t)rank]; b = m->window_hi[(size_t)rank]; }
+    const Rank& r = m->ranks[(size_t)rank];
+    uint32_t a = 0, b = n;                                          // ghost (and n < 96): whole volumes
+    if (n >= 96 && m->last_mode == VP_MULTI_HALO) { a = r.z0; b = r.z1; (void)nz; }       // the slab; its windows also hold the slabs received from z -+ k
+    else if (n >= 96 && m->last_mode == VP_MULTI_HYBRID) { a = m->window_lo[(size_t)rank]; b = m->window_hi[(size_t)rank]; }
     if (lo) *lo = a;
     if (hi) *hi = b;
-    if (id_bytes) {
-        const Rank& r = m->ranks[(size_t)rank];
-        *id_bytes = (uint64_t)r.ids[0].bytes + r.ids[1].bytes + (m->last_mode == VP_MULTI_HALO ? (uint64_t)r.minus.bytes + r.plus.bytes : 0ull);
-    }
+    if (id_bytes) *id_bytes = (uint64_t)r.ids[0].bytes + r.ids[1].bytes;
     return 0;
 }
 

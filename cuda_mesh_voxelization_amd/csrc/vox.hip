@@ -508,10 +508,14 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
         VP_TRY(reserve(ctx, ctx->rec, wantRec * (size_t)kRecDwords * 4));
         uint4* rec = (uint4*)ctx->rec.ptr;
         uint32_t rcap = (uint32_t)std::min<size_t>(ctx->rec.bytes / ((size_t)kRecDwords * 4), ntris);
-        if (const char* e = getenv("VP_VOX_REC_CAP")) rcap = std::min<uint32_t>(rcap, (uint32_t)strtoul(e, nullptr, 10));   // tests: force the walk-in-place path
+#ifdef VP_TEST_HOOKS   // test builds only (libvphip_hooks.so): force the walk-in-place path
+        if (const char* e = getenv("VP_VOX_REC_CAP")) rcap = std::min<uint32_t>(rcap, (uint32_t)strtoul(e, nullptr, 10));
+#endif
         uint32_t* pairs = (uint32_t*)ctx->pairs.ptr;
         uint32_t pcap = (uint32_t)std::min<size_t>(ctx->pairs.bytes / 4, 0xFFFFFFFFu);
-        if (const char* e = getenv("VP_VOX_QUEUE_CAP")) pcap = std::min<uint32_t>(pcap, (uint32_t)strtoul(e, nullptr, 10));   // tests: force the overflow path
+#ifdef VP_TEST_HOOKS   // ... and the work-queue overflow path
+        if (const char* e = getenv("VP_VOX_QUEUE_CAP")) pcap = std::min<uint32_t>(pcap, (uint32_t)strtoul(e, nullptr, 10));
+#endif
         zero(cnt, numTiles + 1u);
         {
             ProfScope p(ctx, VP_K_VOX_SETUP);

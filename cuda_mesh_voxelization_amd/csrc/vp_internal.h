@@ -10,7 +10,7 @@
 
 namespace vp {
 
-// JFA state "no seed yet" of the two 32-bit id formats (jfa.hip, IdU<9> / IdU<10>): y and z fields all ones, x = 2^BITS
+// JFA state "no seed yet" of the two 32-bit id formats (jfa_common.h, IdU<9> / IdU<10>): y and z fields all ones, x = 2^BITS
 constexpr uint32_t kNone9 = 0xFF9FF200u;    // n <= 512
 constexpr uint32_t kNone10 = 0xFFDFFC00u;   // 512 < n <= 1024
 constexpr int kTile = 8;                  // voxelizer tile: 8x8 (y,z) columns = one wave64
@@ -22,7 +22,6 @@ struct Frame {
     uint32_t w;        // words per x-row = n / 32
     uint32_t z0, z1;   // slab
     float vs, ox, oy, oz;
-    uint32_t compact;  // JFA id volumes of this call are in the compact layout (jfa.hip: IdC); set by vp_jfa_run only
 };
 
 inline Frame make_frame(const vp_frame* f)
@@ -30,7 +29,6 @@ inline Frame make_frame(const vp_frame* f)
     Frame r;
     r.n = f->n; r.w = f->n / 32; r.z0 = f->z0; r.z1 = f->z1;
     r.vs = f->voxel_size; r.ox = f->origin[0]; r.oy = f->origin[1]; r.oz = f->origin[2];
-    r.compact = 0;
     return r;
 }
 
@@ -59,6 +57,7 @@ struct vp_ctx {
         uint32_t n = 0;
         int algo = 0;
         const void* work = nullptr;
+        size_t work_bytes = 0;
         const uint32_t* words = nullptr;
     } jfa_started;
     vp::Buffer slots[VP_WORKSPACE_SLOTS];      // vp_ctx_workspace
@@ -110,12 +109,35 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// ---- id windows (include/vphip.h, vp_jfa_window_*) ----
+// A buffer of `planes` id planes in the library's layout -- 4-byte ids (jfa_common.h: IdU<9> / IdU<10>) up to n = 1024; above that `planes`
+// planes of 32-bit words followed by `planes` planes of bytes (IdC: 5 bytes per voxel).  `at` = index, inside the buffer, of plane z0 of
+// the frame a call is made with.
+struct IdWin {
+    char* base = nullptr;
+    uint32_t planes = 0, at = 0;
+};
+constexpr uint32_t kTileMinN = 96;   // VP_ALGO_TILED runs the tile kernels from this side on (n % 32 == 0: 96, 128, ...); the table kernel below it
+                                     // (64 / 32: 0.063 / 0.061 ms per step against 0.117 / 0.102: launch-bound, profiles/r04/ab_tilemin.txt)
+inline bool win_compact(uint32_t n) { return n > 1024; }
+inline size_t win_plane_bytes(uint32_t n) { return (size_t)n * n * 4; }                     // of the (word) plane
+inline size_t win_bytes(uint32_t n, uint32_t planes) { return (size_t)n * n * planes * (win_compact(n) ? 5 : 4); }
+inline char* win_words(const IdWin& w, uint32_t n, int64_t plane)
+{
+    return reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(w.base) + (uintptr_t)(plane * (int64_t)win_plane_bytes(n)));
+}
+inline char* win_bytes_plane(const IdWin& w, uint32_t n, int64_t plane)
+{
+    return reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(w.base) + (uintptr_t)((int64_t)w.planes * (int64_t)win_plane_bytes(n) + plane * (int64_t)n * n));
+}
+
 // ---- stage launchers (each enqueues on ctx->stream) ----
 int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float* d_xyz, size_t nverts,
                     const uint32_t* d_tri, size_t ntris, int algo, int accumulate);
 int launch_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int op);
 int launch_stream_copy(vp_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);   // 16 B per lane: the measured HBM copy rate
-size_t jfa_id_bytes(const Frame& f);                              // 4 (n <= 1024) or 8
+// jfa_seed.hip
+size_t jfa_id_bytes(const Frame& f);                              // plain ids: 4 (n <= 1024) or 8 bytes
 int launch_jfa_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* below,
                     const uint32_t* above, void* d_ids, uint32_t* d_border_words);
 int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, const void* d_minus,
@@ -123,13 +145,22 @@ int launch_jfa_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, c
 bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo);
 int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in, const void* d_minus,
                        const void* d_plus, void* d_out, int algo, const uint32_t* d_words, float fill, float* d_sdf);
-bool jfa_can_start_from_mask(const Frame& f, int algo);
-int launch_jfa_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out);
-bool jfa_can_fuse_first_two(const Frame& f, int algo);          // passes n/2 and n/4 in one launch from the border mask
-bool jfa_compact_applies(const Frame& f, int algo);             // whole-grid vp_jfa at n > 1024: 5-byte id state (jfa.hip: IdC)
-int launch_jfa_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, void* d_out);
 int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const void* d_ids,
                      float fill, float* d_sdf);
+bool jfa_can_start_from_mask(const Frame& f, int algo);         // n % 128 == 0: the pass k = n/2 straight from the border mask
+bool jfa_can_fuse_first_two(const Frame& f, int algo);          // passes n/2 and n/4 in one launch from the border mask (whole grids)
+int launch_win_init(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const uint32_t* below, const uint32_t* above, const IdWin& out);
+int launch_win_first_pass(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, const IdWin& out);
+int launch_win_clear(vp_ctx* ctx, uint32_t n, const IdWin& w);
+// One pass with step k over the planes of f (tile kernel, jfa_dense.hip); the planes z -+ k of a plane z are found `stride` planes below /
+// above it in the window (stride = k for a window of consecutive planes).  d_sdf != nullptr: the last pass, fused with the id -> sdf conversion.
+int launch_win_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride,
+                    const uint32_t* d_words, float fill, float* d_sdf);
+int launch_dense_id9(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf);
+int launch_dense_id10(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf);
+int launch_dense_idc(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf);
+// jfa_first_two.hip: passes n/2 and n/4 of a whole grid from its border mask into a window of n planes
+int launch_win_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, const IdWin& out);
 int launch_extract_count(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, int mode, uint64_t* h_count);
 int launch_extract_write(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, int mode, const float* d_sdf,
                          uint64_t* d_records, float* d_values, size_t capacity);

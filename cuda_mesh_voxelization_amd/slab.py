@@ -25,16 +25,29 @@ import math
 
 import torch
 
-from .capi import ALGO_TILED, Frame
+from .capi import ALGO_TILED, Frame, Window
+
+
+class IdWindow:
+    """An id window (include/vphip.h, vp_jfa_window_*): `planes` id planes in the backend's own layout, held by one tensor."""
+
+    def __init__(self, t, planes):
+        self.t, self.planes = t, int(planes)
 
 
 class HipSlabBackend:
-    """Product backend: torch CUDA tensors for memory, libvphip.so (via Engine.ctx) for compute."""
+    """Product backend: torch CUDA tensors for memory, libvphip.so (via Engine.ctx) for compute.  JFA state lives in id windows; the
+    tile kernels that run on them start at n = 96 (smaller grids are not worth sharding: one GPU does 64^3 in 0.06 ms)."""
 
-    def __init__(self, engine):
+    def __init__(self, engine, poison=None):
         self.engine = engine
         self.ctx = engine.ctx
         self.device = engine.device
+        self.poison = poison          # tests: a byte the word planes of a fresh window are filled with after the clear (see window())
+
+    def check_frame(self, frame):
+        if frame.n < 96:
+            raise ValueError("n = %d: the Z-slab pipelines run the tile kernels (n >= 96); use one GPU below that" % frame.n)
 
     def empty_u32(self, n):
         return torch.empty(int(n), dtype=torch.int32, device=self.device)
@@ -42,105 +55,56 @@ class HipSlabBackend:
     def empty_f32(self, n):
         return torch.empty(int(n), dtype=torch.float32, device=self.device)
 
-    def ids_u32(self, n):
-        """An id volume of the ghost / hybrid pipelines: filled ONCE at allocation.  Their regions are rounded outwards to the
-        8-plane tile, and the excess planes of a pass read planes the pass before it never produced (ghost_regions): what they
-        read is then this fill or stale ids -- never memory nobody wrote.  VP_SLAB_POISON=<byte> (tests) fills with that byte
-        instead of 0 to show that the results do not depend on it."""
-        import os
-        t = torch.empty(int(n), dtype=torch.int32, device=self.device)
-        t.view(torch.uint8).fill_(int(os.environ.get("VP_SLAB_POISON", "0"), 0) & 0xFF)
-        return t
-
-    def id_words(self, frame):
-        """uint32 words of JFA state per voxel (1 for n <= 1024, 2 above)."""
-        return self.ctx.jfa_id_bytes(frame) // 4
-
-    @staticmethod
-    def _p(t):
-        return t.data_ptr() if t is not None else None
-
     def voxelize(self, frame, words, d_xyz, d_tri, algo):
         self.ctx.voxelize(frame, words.data_ptr(), d_xyz.data_ptr(), d_xyz.shape[0], d_tri.data_ptr(), d_tri.shape[0], algo, False)
 
     def csg(self, a, b, op):
         self.ctx.csg(a.data_ptr(), b.data_ptr(), a.numel(), op)
 
-    def jfa_init(self, frame, words, below, above, ids):
-        self.ctx.jfa_init(frame, words.data_ptr(), self._p(below), self._p(above), ids.data_ptr())
-
-    def jfa_pass(self, frame, k, src, minus, plus, dst, algo):
-        self.ctx.jfa_pass(frame, k, src.data_ptr(), self._p(minus), self._p(plus), dst.data_ptr(), algo)
-
-    def jfa_finalize(self, frame, words, ids, fill, sdf):
-        self.ctx.jfa_finalize(frame, words.data_ptr(), ids.data_ptr(), fill, sdf.data_ptr())
-
-    def jfa_last_pass(self, frame, src, minus, plus, scratch, words, fill, sdf, algo):
-        self.ctx.jfa_last_pass(frame, src.data_ptr(), self._p(minus), self._p(plus), scratch.data_ptr(), words.data_ptr(),
-                               fill, sdf.data_ptr(), algo)
-
-    # -- whole-grid id buffers addressed by global plane (GhostSlabPipeline) --------------------
-    def _global_ptrs(self, region, k, src_full, dst_full):
-        pb = region.n * region.n * self.ctx.jfa_id_bytes(region)    # bytes per id plane
-        s, d = src_full.data_ptr(), dst_full.data_ptr()
-        # vphip.h / vp_jfa_pass: plane p of d_minus is global plane z0-k+p, d_plus starts at max(z1, z0+k)
-        return (s + region.z0 * pb, s + (region.z0 - k) * pb, s + max(region.z1, region.z0 + k) * pb, d + region.z0 * pb)
-
-    def jfa_pass_global(self, region, k, src_full, dst_full, algo):
-        src, minus, plus, dst = self._global_ptrs(region, k, src_full, dst_full)
-        self.ctx.jfa_pass(region, k, src, minus, plus, dst, algo)
-
-    # -- id buffers that hold the planes [lo, hi) only, addressed by global plane (HybridSlabPipeline) --------------
-    def _window_ptrs(self, region, k, src, dst, lo):
-        pb = region.n * region.n * self.ctx.jfa_id_bytes(region)
-        s, d = src.data_ptr() - lo * pb, dst.data_ptr() - lo * pb      # where plane 0 would be
-        return (s + region.z0 * pb, s + (region.z0 - k) * pb, s + max(region.z1, region.z0 + k) * pb, d + region.z0 * pb)
-
-    def jfa_pass_window(self, region, k, src, dst, lo, algo):
-        a, minus, plus, out = self._window_ptrs(region, k, src, dst, lo)
-        self.ctx.jfa_pass(region, k, a, minus, plus, out, algo)
-
-    def jfa_last_pass_window(self, region, src, scratch, lo, words_region, fill, sdf, algo):
-        a, minus, plus, out = self._window_ptrs(region, 1, src, scratch, lo)
-        self.ctx.jfa_last_pass(region, a, minus, plus, out, words_region.data_ptr(), fill, sdf.data_ptr(), algo)
-
-    def jfa_first_pass_window(self, region, border_full, dst, lo):
-        pb = region.n * region.n * self.ctx.jfa_id_bytes(region)
-        self.ctx.jfa_first_pass(region, border_full.data_ptr(), dst.data_ptr() + (region.z0 - lo) * pb)
-
-    def can_start_from_mask(self, frame, algo):
-        return self.ctx.jfa_can_start_from_mask(frame, algo)
-
     def surface(self, frame, words, border):
         self.ctx.surface(frame, words.data_ptr(), None, None, border.data_ptr())
 
-    def can_fuse_first_two(self, frame, algo):
-        return self.ctx.jfa_can_fuse_first_two(frame, algo)
+    def can_start_from_mask(self, frame):
+        return self.ctx.jfa_can_start_from_mask(frame, ALGO_TILED)
 
-    def jfa_first_two_global(self, frame, border_full, dst_full):
-        self.ctx.jfa_first_two(frame, border_full.data_ptr(), dst_full.data_ptr())
+    @staticmethod
+    def _p(t):
+        return t.data_ptr() if t is not None else None
 
-    def jfa_first_pass_global(self, region, border_full, dst_full):
-        self.ctx.jfa_first_pass(region, border_full.data_ptr(),
-                                dst_full.data_ptr() + region.z0 * region.n * region.n * self.ctx.jfa_id_bytes(region))
+    # -- id windows ----------------------------------------------------------------------------
+    def window(self, frame, planes):
+        """A fresh window, every id "none".  The regions of the ghost / hybrid pipelines are rounded outwards to the 8-plane tile, and
+        the excess planes of a pass read planes the pass before it never produced (ghost_regions): what they read is then "none" -- never
+        memory nobody wrote.  `poison` (tests) overwrites the word planes with an arbitrary byte afterwards to show that the results do
+        not depend on what those planes hold."""
+        t = torch.empty(self.ctx.jfa_window_bytes(frame, planes), dtype=torch.uint8, device=self.device)
+        self.ctx.jfa_window_clear(frame, Window.make(t.data_ptr(), planes, 0))
+        if self.poison is not None:
+            t[:planes * frame.n * frame.n * 4].fill_(int(self.poison) & 0xFF)
+        return IdWindow(t, planes)
 
-    def jfa_last_pass_global(self, region, src_full, scratch_full, words_region, fill, sdf, algo):
-        src, minus, plus, scratch = self._global_ptrs(region, 1, src_full, scratch_full)
-        self.ctx.jfa_last_pass(region, src, minus, plus, scratch, words_region.data_ptr(), fill, sdf.data_ptr(), algo)
+    def win_spans(self, frame, w, p0, p1):
+        """the tensor slices that hold the planes [p0, p1) of a window: what a halo exchange sends / receives"""
+        return [w.t[o:o + nb] for o, nb in self.ctx.jfa_window_span(frame, w.planes, p0, p1)]
 
-    # -- whole-volume calls (vp_jfa_volume_*): volume base + region frame, the library picks the layout (compact above n = 1024)
-    def volume_words(self, frame):
-        """uint32 words of one id volume of the whole grid in the library's layout"""
-        return (self.ctx.jfa_volume_bytes(frame) + 3) // 4
+    @staticmethod
+    def _w(w, at):
+        return Window.make(w.t.data_ptr(), w.planes, at)
 
-    def jfa_volume_first_two(self, frame, border_full, vol):
-        self.ctx.jfa_volume_first_two(frame, border_full.data_ptr(), vol.data_ptr())
+    def win_init(self, region, words_region, below, above, w, at):
+        self.ctx.jfa_window_init(region, words_region.data_ptr(), self._p(below), self._p(above), self._w(w, at))
 
-    def jfa_volume_pass(self, region, k, vol_in, vol_out):
-        self.ctx.jfa_volume_pass(region, k, vol_in.data_ptr(), vol_out.data_ptr())
+    def win_first_pass(self, region, border_full, w, at):
+        self.ctx.jfa_window_first_pass(region, border_full.data_ptr(), self._w(w, at))
 
-    def jfa_volume_last_pass(self, region, vol_in, vol_scratch, words_region, fill, sdf):
-        self.ctx.jfa_volume_last_pass(region, vol_in.data_ptr(), vol_scratch.data_ptr(), words_region.data_ptr(), fill, sdf.data_ptr())
+    def win_first_two(self, frame, border_full, w):
+        self.ctx.jfa_window_first_two(frame, border_full.data_ptr(), self._w(w, 0))
+
+    def win_pass(self, region, k, w_in, w_out, at, stride=None):
+        self.ctx.jfa_window_pass(region, k, self._w(w_in, at), self._w(w_out, at), stride)
+
+    def win_last_pass(self, region, w_in, w_scratch, at, words_region, fill, sdf, stride=1):
+        self.ctx.jfa_window_last_pass(region, self._w(w_in, at), self._w(w_scratch, at), words_region.data_ptr(), fill, sdf.data_ptr(), stride)
 
 
 class HostStagedDist:
@@ -188,6 +152,8 @@ def hbm_bytes(obj) -> int:
 
     def walk(v):
         nonlocal total
+        if isinstance(v, IdWindow):
+            v = v.t
         if isinstance(v, torch.Tensor):
             st = v.untyped_storage()
             if st.data_ptr() not in seen:
@@ -231,31 +197,29 @@ def halo_plan(n: int, world: int, k: int):
 
 
 class SlabPipeline:
-    """voxelize -> (CSG) -> JFA for the slab of this rank."""
+    """voxelize -> (CSG) -> JFA for the slab of this rank, halo planes exchanged point to point before every pass.
+
+    A rank's two id windows hold [slab holding z - k | own slab | slab holding z + k] = 3 nz planes, the own slab in the middle.  The halos
+    of the narrow passes (k <= nz/2) land in the k planes right below / above the slab (stride = k: consecutive planes).  For the wide
+    passes (k >= nz) whole slabs of distant ranks land nz planes below / above the own planes and the tile kernel runs with stride = nz
+    (include/vphip.h, vp_jfa_window_pass) -- one kernel, one buffer layout, and above n = 1024 five bytes per voxel on the wire."""
 
     def __init__(self, backend, frame: Frame, rank: int, world: int, dist):
         self.be = backend
         self.dist = dist
         self.rank, self.world = rank, world
         self.global_frame = frame
+        self.be.check_frame(frame)
         self.z0, self.z1 = slab_range(frame.n, rank, world)
         self.frame = frame.slab(self.z0, self.z1)
         n = frame.n
-        idw = self.be.id_words(frame) if hasattr(self.be, "id_words") else 1
-        self.plane_ids = n * n * idw              # uint32 words of id state per plane
         self.plane_words = n * n // 32            # bitmask words per plane
         self.nz = self.z1 - self.z0
         self.words = self.be.empty_u32(self.frame.words)
-        # Id volumes with room for the halo planes of the narrow passes (k <= nz/2) directly below and above the slab:
-        # [H | nz | H] planes, H = nz/2.  For those passes the received planes land next to the slab, the three buffers
-        # vp_jfa_pass takes are ONE contiguous volume, and the dense tile kernel (jfa.hip: jfa_pass_dense) applies.
-        # Wide passes (k >= nz) receive whole slabs of distant ranks into the separate minus / plus buffers.
-        self.H = (self.nz // 2) if world > 1 else 0
-        self._bufs = [self.be.empty_u32((self.nz + 2 * self.H) * self.plane_ids) for _ in range(2)]
-        self.ids = [b[self.H * self.plane_ids:(self.H + self.nz) * self.plane_ids] for b in self._bufs]
+        self.planes = 3 * self.nz if world > 1 else self.nz
+        self.at = self.nz if world > 1 else 0
+        self.ids = [self.be.window(frame, self.planes) for _ in range(2)]
         self.sdf = self.be.empty_f32(self.frame.voxels)
-        self.minus = self.be.empty_u32(self.frame.voxels * idw) if world > 1 else None
-        self.plus = self.be.empty_u32(self.frame.voxels * idw) if world > 1 else None
         self.below = self.be.empty_u32(self.plane_words) if rank > 0 else None
         self.above = self.be.empty_u32(self.plane_words) if rank < world - 1 else None
         self.bytes_received = 0
@@ -264,7 +228,7 @@ class SlabPipeline:
         return "z-slab x%d, RCCL p2p halo exchange before every pass" % self.world
 
     def report(self):
-        return {"pipeline": "halo", "slab_planes": self.nz, "bytes_received_total": int(self.bytes_received),
+        return {"pipeline": "halo", "slab_planes": self.nz, "window_planes": self.planes, "bytes_received_total": int(self.bytes_received),
                 "hbm_bytes_this_rank": hbm_bytes(self)}
 
     # -- stages ---------------------------------------------------------------------------
@@ -294,53 +258,43 @@ class SlabPipeline:
             ops.append(P(d.irecv, self.above, self.rank + 1))
         self._exchange(ops)
 
-    def _halo_buffers(self, k: int, src):
-        """(minus, plus) for step k around the id volume `src` (one of self.ids): views into src's own allocation when
-        the halo fits next to the slab (k <= H), else the separate whole-slab buffers."""
-        if self.world == 1:
-            return None, None
-        if k <= self.H:
-            buf = self._bufs[0] if src.data_ptr() == self.ids[0].data_ptr() else self._bufs[1]
-            pi = self.plane_ids
-            return buf[(self.H - k) * pi:self.H * pi], buf[(self.H + self.nz) * pi:(self.H + self.nz + k) * pi]
-        return self.minus, self.plus
+    def _stride(self, k: int) -> int:
+        return self.nz if (self.world > 1 and k >= self.nz) else k
 
     def _exchange_ids(self, k: int, src):
         d, P = self.dist, self.dist.P2POp
-        pi = self.plane_ids
-        minus_base = self.z0 - k                                  # global plane of minus[0] (vphip.h, vp_jfa_pass)
-        plus_base = max(self.z1, self.z0 + k)
-        minus, plus = self._halo_buffers(k, src)
+        G, stride = self.global_frame, self._stride(k)
         ops = []
-        for s, t, side, g0, g1 in halo_plan(self.global_frame.n, self.world, k):
+        for s, t, side, g0, g1 in halo_plan(G.n, self.world, k):
             if s == t:
                 continue
             if s == self.rank:
-                ops.append(P(d.isend, src[(g0 - self.z0) * pi:(g1 - self.z0) * pi], t))
+                for piece in self.be.win_spans(G, src, self.at + g0 - self.z0, self.at + g1 - self.z0):
+                    ops.append(P(d.isend, piece, t))
             elif t == self.rank:
-                buf, base = (minus, minus_base) if side == "minus" else (plus, plus_base)
-                ops.append(P(d.irecv, buf[(g0 - base) * pi:(g1 - base) * pi], s))
-                self.bytes_received += (g1 - g0) * pi * 4
+                # global plane g feeds my plane z = g + k (minus side) / g - k (plus side), which sits `stride` planes away from it
+                dp = self.at + (g0 + k - self.z0) - stride if side == "minus" else self.at + (g0 - k - self.z0) + stride
+                for piece in self.be.win_spans(G, src, dp, dp + (g1 - g0)):
+                    ops.append(P(d.irecv, piece, s))
+                    self.bytes_received += piece.numel() * piece.element_size()
         self._exchange(ops)
 
-    def jfa(self, algo=ALGO_TILED, fill=-math.inf, out=None):
+    def jfa(self, fill=-math.inf, out=None):
         out = self.sdf if out is None else out
         if self.world > 1:
             self._exchange_mask_planes()
         a, b = self.ids
-        self.be.jfa_init(self.frame, self.words, self.below, self.above, a)
+        self.be.win_init(self.frame, self.words, self.below, self.above, a, self.at)
         k = self.global_frame.n // 2
         while k >= 1:                                             # jfa/sequential.cpp:72
             if self.world > 1:
                 self._exchange_ids(k, a)
-            minus, plus = self._halo_buffers(k, a)
-            if k == 1 and hasattr(self.be, "jfa_last_pass"):       # last pass + finalize fused
-                self.be.jfa_last_pass(self.frame, a, minus, plus, b, self.words, fill, out, algo)
+            if k == 1:                                            # last pass + id -> sdf conversion fused
+                self.be.win_last_pass(self.frame, a, b, self.at, self.words, fill, out, self._stride(1))
                 return out
-            self.be.jfa_pass(self.frame, k, a, minus, plus, b, algo)
+            self.be.win_pass(self.frame, k, a, b, self.at, self._stride(k))
             a, b = b, a
             k //= 2
-        self.be.jfa_finalize(self.frame, self.words, a, fill, out)
         return out
 
 
@@ -375,52 +329,33 @@ def ghost_regions(n: int, rank: int, world: int):
     return out
 
 
-def fused_first_two_threshold(n: int) -> int:
-    """Per cent of the grid the second pass of a rank must cover before the whole-grid launch of the first two passes is the cheaper
-    way to run them.  Break-even of the measured kernel times: jfa_first_two 0.30 ms at n = 512 against 0.18 for the first pass + 0.36 x
-    the covered fraction for the second (33 %); 2.13 ms against 1.39 + 2.12 x the fraction at n = 1024 (35 %).  Swept on the GPU
-    (profiles/r03/slab_scaling_*.txt: 35 against round 2's 65 / 73): 8 slabs 1.26 -> 1.09 ms at n = 512, 11.2 -> 9.1 ms at n = 1024,
-    195 -> 144 ms at n = 2048.  The same rule lives in csrc/multi.hip."""
-    import os
-    if os.environ.get("VP_FUSED_FIRST_TWO_PCT"):                   # dev: tools/slab_scaling.py sweeps it
-        return int(os.environ["VP_FUSED_FIRST_TWO_PCT"])
-    return 35
-
-
 class GhostSlabPipeline:
     """Z-slab strong scaling WITHOUT halo exchange.
 
     Measured on MI355X one JFA pass costs ~1.6 us per 512^2 plane, while moving that plane (1 MiB) to a
     peer over one xGMI link costs ~20 us: recomputing ghost planes is an order of magnitude cheaper than
-    exchanging them.  Every rank therefore voxelizes and initialises the whole grid (0.2 ms at n = 512)
-    and runs pass i on its slab widened by the reach of the later passes (ghost_regions).  The regions
+    exchanging them.  Every rank therefore voxelizes the whole grid (0.06 ms at n = 512), runs the first two
+    passes as the one whole-grid launch of the single-GPU path (its second pass would cover 35 % of the grid or
+    more on any rank of 2 .. 8 slabs: the break-even of the measured kernel times, profiles/r03/slab_scaling_*.txt)
+    and every later pass i on its slab widened by the reach of the passes after it (ghost_regions).  The regions
     shrink to the bare slab at k = 1; the result is the slab's part of the single-GPU result, bit for
-    bit, with zero bytes exchanged.  Id buffers are addressed by global plane, so each rank holds two
-    full id volumes (2 x 4 n^3 B: 1 GiB at n = 512, 8 GiB at n = 1024 -- small against 288 GB).
-    SlabPipeline above (RCCL point-to-point halos) remains for grids whose state does not fit.
+    bit, with zero bytes exchanged.  The two id windows hold the whole grid (a plane sits at its global index):
+    2 x 4 n^3 B up to n = 1024, 2 x 5 n^3 B above (2 x 40 GiB at n = 2048).
     """
 
     def __init__(self, backend, frame: Frame, rank: int, world: int):
         self.be = backend
         self.rank, self.world = rank, world
         self.global_frame = frame
+        self.be.check_frame(frame)
         self.z0, self.z1 = slab_range(frame.n, rank, world)
         self.frame = frame.slab(self.z0, self.z1)
         self.regions = ghost_regions(frame.n, rank, world)
         self.words = self.be.empty_u32(frame.words)                 # whole grid
-        idw = self.be.id_words(frame) if hasattr(self.be, "id_words") else 1
-        # Whole-volume calls (round 4) where the first two passes are fused over the whole grid anyway -- always above n = 1024, where the
-        # library then keeps the volumes in its compact 5-byte layout: 2 x 40 instead of 2 x 64 GiB at n = 2048 and 10 instead of 16 bytes
-        # per voxel and pass.  VP_GHOST_VOLUME=0 (dev / tests) keeps the caller-addressed 8-byte planes.
-        import os
-        self.volume_mode = (hasattr(self.be, "jfa_volume_pass") and os.environ.get("VP_GHOST_VOLUME", "1") != "0" and len(self.regions) > 3
-                            and self.be.can_fuse_first_two(frame, ALGO_TILED)
-                            and (frame.n > 1024 or (self.regions[1][2] - self.regions[1][1]) * 100 >= fused_first_two_threshold(frame.n) * frame.n))
-        vol_words = self.be.volume_words(frame) if self.volume_mode else frame.voxels * idw
-        self.ids = [(self.be.ids_u32(vol_words) if hasattr(self.be, "ids_u32") else self.be.empty_u32(vol_words)) for _ in range(2)]
+        self.ids = [self.be.window(frame, frame.n) for _ in range(2)]
         self.sdf = self.be.empty_f32(self.frame.voxels)             # own slab only
         self.planes_computed = sum(b1 - b0 for _, b0, b1 in self.regions)
-        self.border = None
+        self.border = self.be.empty_u32(frame.words)
 
     def describe(self):
         return "z-slab x%d, ghost planes recomputed, no data-path exchange" % self.world
@@ -430,8 +365,7 @@ class GhostSlabPipeline:
         return {"pipeline": "ghost", "slab_planes": self.z1 - self.z0, "regions": [[k, b0, b1] for k, b0, b1 in self.regions],
                 "plane_passes_this_rank": int(self.planes_computed), "plane_passes_one_gpu": n * passes,
                 "plane_pass_ratio": round(n * passes / self.planes_computed, 3), "bytes_exchanged": 0, "bytes_received_total": 0,
-                "first_two_passes_fused_over_whole_grid": bool(getattr(self, "fused_first_two", False)),
-                "volume_calls": bool(self.volume_mode), "id_volume_bytes": int(self.ids[0].numel() * 4),
+                "id_window_bytes": int(self.ids[0].t.numel() * self.ids[0].t.element_size()),
                 "hbm_bytes_this_rank": hbm_bytes(self)}
 
     def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
@@ -443,15 +377,13 @@ class GhostSlabPipeline:
         self.be.csg(self.words, other, op)
         return self.words
 
-    def _jfa_volume(self, fill, out):
-        """the whole-volume sequence: border mask, passes n/2 + n/4 over the whole grid in one launch, every later pass on its region"""
+    def jfa(self, fill=-math.inf, out=None):
+        """border mask, passes n/2 + n/4 over the whole grid in one launch, every later pass on its region"""
+        out = self.sdf if out is None else out
         a, b = self.ids
         G = self.global_frame
-        if self.border is None:
-            self.border = self.be.empty_u32(G.words)
         self.be.surface(G, self.words, self.border)
-        self.be.jfa_volume_first_two(G, self.border, a)
-        self.fused_first_two = True
+        self.be.win_first_two(G, self.border, a)
         pw = G.n * G.n // 32
         last = len(self.regions) - 1
         for i, (k, b0, b1) in enumerate(self.regions):
@@ -459,52 +391,9 @@ class GhostSlabPipeline:
                 continue
             region = G.slab(b0, b1)
             if i == last:
-                self.be.jfa_volume_last_pass(region, a, b, self.words[b0 * pw:b1 * pw], fill, out)
+                self.be.win_last_pass(region, a, b, b0, self.words[b0 * pw:b1 * pw], fill, out)
                 return out
-            self.be.jfa_volume_pass(region, k, a, b)
-            a, b = b, a
-        return out
-
-    def jfa(self, algo=ALGO_TILED, fill=-math.inf, out=None):
-        out = self.sdf if out is None else out
-        if self.volume_mode and algo == ALGO_TILED:
-            return self._jfa_volume(fill, out)
-        need = self.global_frame.voxels * (self.be.id_words(self.global_frame) if hasattr(self.be, "id_words") else 1)
-        if self.ids[0].numel() < need:                            # the volumes were sized for the library's layout: caller-addressed ids need more
-            self.ids = [(self.be.ids_u32(need) if hasattr(self.be, "ids_u32") else self.be.empty_u32(need)) for _ in range(2)]
-        a, b = self.ids
-        last = len(self.regions) - 1
-        mask_start = last > 0 and hasattr(self.be, "can_start_from_mask") and self.be.can_start_from_mask(self.global_frame, algo)
-        if mask_start:
-            # border mask of the whole grid -> first pass directly (no init id volume), see vp_jfa_first_pass
-            if self.border is None:
-                self.border = self.be.empty_u32(self.global_frame.words)
-            self.be.surface(self.global_frame, self.words, self.border)
-        else:
-            self.be.jfa_init(self.global_frame, self.words, None, None, a)
-        # The first two passes (k = n/2, n/4) as ONE launch over the whole grid (vp_jfa_first_two) where the second pass would cover
-        # most of the grid anyway: 0.40 ms at n = 512 against 0.18 for the first pass + 0.36 x the covered fraction for the second
-        # (break-even at 61 % in round 2; the kernel has since come down to 0.30 / 2.13 ms: 35 %, see fused_first_two_threshold()).
-        skip = 0
-        if (mask_start and last >= 2 and hasattr(self.be, "can_fuse_first_two") and self.be.can_fuse_first_two(self.global_frame, algo)
-                and (self.regions[1][2] - self.regions[1][1]) * 100 >= fused_first_two_threshold(self.global_frame.n) * self.global_frame.n):
-            self.be.jfa_first_two_global(self.global_frame, self.border, b)
-            a, b = b, a
-            skip = 2
-            self.fused_first_two = True
-        for i, (k, b0, b1) in enumerate(self.regions):
-            if i < skip:
-                continue
-            region = self.global_frame.slab(b0, b1)
-            if i == 0 and mask_start:
-                self.be.jfa_first_pass_global(region, self.border, b)
-                a, b = b, a
-                continue
-            if i == last:
-                pw = self.global_frame.n * self.global_frame.n // 32
-                self.be.jfa_last_pass_global(region, a, b, self.words[b0 * pw:b1 * pw], fill, out, algo)
-                return out
-            self.be.jfa_pass_global(region, k, a, b, algo)
+            self.be.win_pass(region, k, a, b, b0)
             a, b = b, a
         return out
 
@@ -549,17 +438,18 @@ class HybridSlabPipeline:
         self.be, self.dist = backend, dist
         self.rank, self.world = rank, world
         self.global_frame = frame
+        self.be.check_frame(frame)
         self.z0, self.z1 = slab_range(frame.n, rank, world)
         self.nz = self.z1 - self.z0
         self.frame = frame.slab(self.z0, self.z1)
         self.wide, self.narrow = hybrid_plan(frame.n, rank, world)
-        idw = self.be.id_words(frame) if hasattr(self.be, "id_words") else 1
-        self.plane_ids = frame.n * frame.n * idw
         self.plane_words = frame.n * frame.n // 32
         self.words = self.be.empty_u32(frame.words)                  # whole grid: every rank rasterises it (0.06 ms at n = 512)
         self.sdf = self.be.empty_f32(self.frame.voxels)
         self.border = None
-        self._bufs = {}
+        self.mask_start = bool(self.wide) and len(self.wide) + len(self.narrow) > 1 and self.be.can_start_from_mask(frame)
+        self.window = list(self._window_planes(self.mask_start))     # global planes [lo, hi) the two id windows hold
+        self.ids = [self.be.window(frame, self.window[1] - self.window[0]) for _ in range(2)]
         self.bytes_received = 0
         self.planes_computed = sum(b1 - b0 for _, b0, b1 in self.wide) + self.nz * len(self.narrow)
 
@@ -571,7 +461,7 @@ class HybridSlabPipeline:
         return {"pipeline": "hybrid", "slab_planes": self.nz, "wide_regions": [[k, b0, b1] for k, b0, b1 in self.wide],
                 "narrow_steps": list(self.narrow), "plane_passes_this_rank": int(self.planes_computed),
                 "plane_passes_one_gpu": n * passes, "plane_pass_ratio": round(n * passes / self.planes_computed, 3),
-                "bytes_received_total": int(self.bytes_received), "id_buffer_planes": getattr(self, "window", None),
+                "bytes_received_total": int(self.bytes_received), "id_buffer_planes": self.window,
                 "hbm_bytes_this_rank": hbm_bytes(self)}
 
     def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
@@ -583,36 +473,36 @@ class HybridSlabPipeline:
         self.be.csg(self.words, other, op)
         return self.words
 
-    # -- buffers: planes [lo, hi) of the id volume, twice ------------------------------------
-    def _window(self, mask_start: bool):
+    # -- the window: planes [lo, hi) of the id volume ------------------------------------------
+    def _window_planes(self, mask_start: bool):
         n, H = self.global_frame.n, (self.nz // 2 if self.world > 1 else 0)
         lo, hi = max(0, self.z0 - H), min(n, self.z1 + H)            # room for the halos of the narrow passes
         for i, (k, b0, b1) in enumerate(self.wide):
             lo, hi = min(lo, b0), max(hi, b1)
             if i > 0 or not mask_start:                               # every pass that reads ids reads k planes beyond its region
                 lo, hi = min(lo, max(0, b0 - k)), max(hi, min(n, b1 + k))
-        key = (lo, hi)
-        if key not in self._bufs:
-            self._bufs = {key: [(self.be.ids_u32((hi - lo) * self.plane_ids) if hasattr(self.be, "ids_u32") else self.be.empty_u32((hi - lo) * self.plane_ids)) for _ in range(2)]}
-        self.window = [lo, hi]
-        return lo, hi, self._bufs[key]
+        return lo, hi
 
-    def _planes(self, buf, lo, g0, g1):
-        return buf[(g0 - lo) * self.plane_ids:(g1 - lo) * self.plane_ids]
-
-    def _start_exchange(self, k: int, buf, lo):
-        """Halo of k planes for the pass with step k on the state in `buf`: my bottom / top k planes go down / up, theirs land
+    def _start_exchange(self, k: int, w):
+        """Halo of k planes for the pass with step k on the state in `w`: my bottom / top k planes go down / up, theirs land
         in the planes just outside my slab.  Returns the requests (waited for right before the pass that needs them)."""
         d, P = self.dist, self.dist.P2POp
+        G, lo = self.global_frame, self.window[0]
         ops = []
+
+        def planes(g0, g1):
+            return self.be.win_spans(G, w, g0 - lo, g1 - lo)
+
         if self.rank > 0:
-            ops.append(P(d.isend, self._planes(buf, lo, self.z0, self.z0 + k), self.rank - 1))
-            ops.append(P(d.irecv, self._planes(buf, lo, self.z0 - k, self.z0), self.rank - 1))
-            self.bytes_received += k * self.plane_ids * 4
+            ops += [P(d.isend, t, self.rank - 1) for t in planes(self.z0, self.z0 + k)]
+            for t in planes(self.z0 - k, self.z0):
+                ops.append(P(d.irecv, t, self.rank - 1))
+                self.bytes_received += t.numel() * t.element_size()
         if self.rank < self.world - 1:
-            ops.append(P(d.isend, self._planes(buf, lo, self.z1 - k, self.z1), self.rank + 1))
-            ops.append(P(d.irecv, self._planes(buf, lo, self.z1, self.z1 + k), self.rank + 1))
-            self.bytes_received += k * self.plane_ids * 4
+            ops += [P(d.isend, t, self.rank + 1) for t in planes(self.z1 - k, self.z1)]
+            for t in planes(self.z1, self.z1 + k):
+                ops.append(P(d.irecv, t, self.rank + 1))
+                self.bytes_received += t.numel() * t.element_size()
         return d.batch_isend_irecv(ops) if ops else []
 
     @staticmethod
@@ -620,55 +510,55 @@ class HybridSlabPipeline:
         for r in reqs:
             r.wait()
 
-    def jfa(self, algo=ALGO_TILED, fill=-math.inf, out=None):
+    def jfa(self, fill=-math.inf, out=None):
         out = self.sdf if out is None else out
         G, n, z0, z1, pw = self.global_frame, self.global_frame.n, self.z0, self.z1, self.plane_words
-        mask_start = (bool(self.wide) and len(self.wide) + len(self.narrow) > 1 and hasattr(self.be, "can_start_from_mask")
-                      and self.be.can_start_from_mask(G, algo))
-        lo, hi, (a, b) = self._window(mask_start)
+        lo, hi = self.window
+        a, b = self.ids
         slab_words = self.words[z0 * pw:z1 * pw]
         npass = len(self.wide) + len(self.narrow)
         # ---- wide passes: ghost planes
         start = 0
-        if mask_start:
+        if self.mask_start:
             if self.border is None:
                 self.border = self.be.empty_u32(G.words)
             self.be.surface(G, self.words, self.border)
             k, b0, b1 = self.wide[0]
-            self.be.jfa_first_pass_window(G.slab(b0, b1), self.border, b, lo)
+            self.be.win_first_pass(G.slab(b0, b1), self.border, b, b0 - lo)
             a, b = b, a
             start = 1
         else:
             below = self.words[(lo - 1) * pw:lo * pw] if lo > 0 else None
             above = self.words[hi * pw:(hi + 1) * pw] if hi < n else None
-            self.be.jfa_init(G.slab(lo, hi), self.words[lo * pw:hi * pw], below, above, a)
+            self.be.win_init(G.slab(lo, hi), self.words[lo * pw:hi * pw], below, above, a, 0)
         for i in range(start, len(self.wide)):
             k, b0, b1 = self.wide[i]
             if i == npass - 1:                                        # one rank: the last pass is a wide one
-                self.be.jfa_last_pass_window(G.slab(b0, b1), a, b, lo, slab_words, fill, out, algo)
+                self.be.win_last_pass(G.slab(b0, b1), a, b, b0 - lo, slab_words, fill, out)
                 return out
-            self.be.jfa_pass_window(G.slab(b0, b1), k, a, b, lo, algo)
+            self.be.win_pass(G.slab(b0, b1), k, a, b, b0 - lo)
             a, b = b, a
         # ---- narrow passes: halos from the adjacent ranks, the next pass's halo sent under this pass's interior planes
         pend = None
+        at = z0 - lo
         for idx, k in enumerate(self.narrow):
             if pend is None:
-                pend = self._start_exchange(k, a, lo)
+                pend = self._start_exchange(k, a)
             self._wait(pend)
             pend = None
             if idx == len(self.narrow) - 1:
-                self.be.jfa_last_pass_window(self.frame, a, b, lo, slab_words, fill, out, algo)
+                self.be.win_last_pass(self.frame, a, b, at, slab_words, fill, out)
                 return out
             nk = self.narrow[idx + 1]
             nb = -(-nk // 8) * 8                                       # sub-slabs are cut at multiples of 8 planes
             if 2 * nb >= self.nz:
-                self.be.jfa_pass_window(self.frame, k, a, b, lo, algo)
-                pend = self._start_exchange(nk, b, lo)
+                self.be.win_pass(self.frame, k, a, b, at)
+                pend = self._start_exchange(nk, b)
             else:
-                self.be.jfa_pass_window(G.slab(z0, z0 + nb), k, a, b, lo, algo)          # what the neighbours need next: first
-                self.be.jfa_pass_window(G.slab(z1 - nb, z1), k, a, b, lo, algo)
-                pend = self._start_exchange(nk, b, lo)
-                self.be.jfa_pass_window(G.slab(z0 + nb, z1 - nb), k, a, b, lo, algo)     # the transfer runs under this
+                self.be.win_pass(G.slab(z0, z0 + nb), k, a, b, at)                       # what the neighbours need next: first
+                self.be.win_pass(G.slab(z1 - nb, z1), k, a, b, at + (z1 - nb - z0))
+                pend = self._start_exchange(nk, b)
+                self.be.win_pass(G.slab(z0 + nb, z1 - nb), k, a, b, at + nb)             # the transfer runs under this
             a, b = b, a
         return out
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 4
+#define VP_ABI_VERSION 5
 
 enum {
     VP_OK = 0,
@@ -127,23 +127,24 @@ int vp_csg(vp_ctx* ctx, uint32_t* d_a, const uint32_t* d_b, size_t nwords, int o
  * (vplib/src/jfa/jfa.h:42-43, jfa/naive.cu:121-180, jfa/tiled.cu:244-337); results are those of
  * the sequential path (jfa/sequential.cpp:7-127): signed SQUARED distance, +inside, -outside.
  *
- * State between passes is one packed id per voxel: the coordinates of the nearest seed found so far
- * (vp_jfa_id_bytes(f) = 4 bytes for n <= 1024, 8 bytes for n <= 2048) instead of the
- * reference's float sdf + float3 position; distances are recomputed from it with the reference's
- * expressions.  Id buffers are opaque (void*): vp_grid_voxels(f) * vp_jfa_id_bytes(f) bytes per volume.
+ * State between passes is one packed id per voxel -- the coordinates of the nearest seed found so far -- instead of the
+ * reference's float sdf + float3 position (jfa/sequential.cpp:69-70); distances are recomputed from it with the reference's
+ * expressions.  Two layouts:
+ *   PLAIN ids   vp_jfa_id_bytes(f) = 4 bytes per voxel for n <= 1024, 8 for n <= 2048, x-fastest, in planes the CALLER addresses
+ *               (vp_jfa_init / vp_jfa_pass / vp_jfa_finalize below): the form of the direct kernel (VP_ALGO_NAIVE).
+ *   WINDOWS     buffers in the library's own layout (vp_jfa_window_*): what the tile kernels (VP_ALGO_TILED, n >= 96) run on.
+ * Id buffers are opaque either way.
  *
- * vp_jfa runs init + all passes + finalize on one device for a whole-grid frame.
+ * vp_jfa runs seeding + all passes + the id -> sdf conversion on one device for a whole-grid frame.
  *   fill_unset  value the caller pre-filled the sdf with (apps/cli/main.cpp:200 uses -INFINITY);
  *               must be +-infinity (a finite fill is undefined behaviour in the reference).
  *   d_work      scratch of vp_jfa_workspace_bytes(f) bytes (two id volumes + border mask), or NULL: the
  *               context then keeps a grow-only workspace of its own (work_bytes ignored).
- *   algo        VP_ALGO_NAIVE: direct kernel; VP_ALGO_TILED: LDS-table kernel.  Same results. */
+ *   algo        VP_ALGO_NAIVE: direct kernel; VP_ALGO_TILED: tile kernels.  Same results. */
 size_t vp_jfa_workspace_bytes(const vp_frame* f);
 size_t vp_jfa_id_bytes(const vp_frame* f);
-/* Bytes of id state per voxel that vp_jfa (whole-grid frame, its own workspace) really streams per pass -- the S of SURVEY.md 8(d)
- * "as implemented": 4 for n <= 1024; above that 5 when the call keeps its state in the compact layout (a 32-bit word plane + a byte
- * plane inside the 8-byte volumes of the workspace: VP_ALGO_TILED), else 8.  Measurement only: the id buffers a caller
- * passes to the slab entry points are always vp_jfa_id_bytes wide. */
+/* Bytes of id state per voxel that vp_jfa really streams per pass -- the S of SURVEY.md 8(d) "as implemented": 4 for n <= 1024; above
+ * that 5 with VP_ALGO_TILED (windows: a 32-bit word plane + a byte plane), 8 with VP_ALGO_NAIVE.  Measurement only. */
 size_t vp_jfa_state_bytes(const vp_frame* f, int algo);
 int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
            float* d_sdf, void* d_work, size_t work_bytes, int algo);
@@ -153,19 +154,24 @@ int vp_jfa(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_u
  * The context records what vp_jfa_start left in the workspace (grid pointer, n, algo, workspace, border mask or init ids);
  * vp_jfa_run returns VP_ERR_INVALID unless exactly that start preceded it -- one start serves one run, and the record is
  * dropped when the workspace is released, regrown or freed, and when the grid buffer or the workspace is written through this ABI
- * in between (vp_voxelize, vp_csg, vp_upload, vp_memset, vp_memcpy_d2d, vp_stream_copy into it, vp_free, or the buffer handed out
- * again by vp_ctx_workspace): "the same grid" means the same CONTENTS -- the border mask of the start no longer describes them. */
+ * in between -- vp_voxelize, vp_csg, vp_upload, vp_memset, vp_memcpy_d2d, vp_stream_copy into ANY part of it (a slab of the grid, a
+ * sub-range of the workspace: the byte ranges are compared), vp_free, or the buffer handed out again by vp_ctx_workspace: "the same
+ * grid" means the same CONTENTS -- the border mask of the start no longer describes them. */
 int vp_jfa_start(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, void* d_work, size_t work_bytes, int algo);
 int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fill_unset,
                float* d_sdf, void* d_work, size_t work_bytes, int algo);
 
-/* The three stages separately, for Z-slab sharding (halo exchange happens between calls).
+/* The stages separately on PLAIN ids in caller-addressed planes, for Z-slab sharding (halo exchange happens between calls).
  * Halo pointers may be NULL where the slab touches the global boundary.
  *   init:  d_plane_below / d_plane_above = bitmask plane z0-1 / z1 (n*n/32 words each).
  *   pass:  step k; d_minus holds id planes [z0-k, min(z0, z1-k)), d_plus holds
  *          [max(z1, z0+k), z1+k), each clipped to the global grid but indexed from the unclipped
  *          start (plane p of d_minus is global plane z0-k+p).
- *   finalize: ids -> float sdf for the slab. */
+ *   finalize: ids -> float sdf for the slab.
+ * VP_ALGO_NAIVE serves any such buffers (the direct kernel: one thread per voxel -- the independent form the tile kernels are tested
+ * against, pass by pass).  VP_ALGO_TILED: any buffers below n = 96; from there on the tile kernel, which needs 4-byte ids (n <= 1024) and
+ * the three buffers to be ONE run of consecutive planes (d_minus + k planes == d_in, d_plus == d_in + the slab: whole grids, and slabs
+ * with their halo planes right below / above them) -- anything else is VP_ERR_UNSUPPORTED: hand it over as a window. */
 int vp_jfa_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words,
                 const uint32_t* d_plane_below, const uint32_t* d_plane_above, void* d_ids);
 int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const void* d_in,
@@ -179,34 +185,48 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
                      const void* d_plus, void* d_scratch, const uint32_t* d_words, float fill_unset,
                      float* d_sdf, int algo);
 
-/* Sparse start (n % 128 == 0, VP_ALGO_TILED; the halo / hybrid slab pipelines use it; vp_jfa itself starts with vp_jfa_first_two below).  Before any pass a border
- * voxel's seed is itself and nothing else has one (jfa/sequential.cpp:55-60), so the first pass (k = n/2) can run
- * straight from the border bitmask of the WHOLE grid (vp_surface on a whole-grid frame): no init id volume is
- * written or read.  vp_jfa_first_pass produces the ids after step n/2 for the planes of f; the result is
- * identical to vp_jfa_init + vp_jfa_pass(k = n/2). */
+/* Id WINDOWS: the slab form of the tile kernels (VP_ALGO_TILED, n >= 96) -- what the multi-GPU pipelines run (cuda_mesh_voxelization_amd/slab.py,
+ * vp_multi_* below), and what vp_jfa itself runs on its workspace.  A window is a buffer of `planes` id planes in the library's layout:
+ * vp_jfa_window_bytes(f, planes) bytes -- 4-byte ids up to n = 1024; above that `planes` planes of 32-bit words followed by `planes`
+ * planes of bytes (5 instead of 8 bytes per voxel in memory, per pass and on the wire).  A call names a frame f (the planes [z0, z1) it
+ * produces) and says where plane z0 sits in the window (`at`); the planes around it are the halo the pass reads.  Nothing else is
+ * assumed about which global planes a window holds: a ghost-plane pipeline keeps whole volumes (planes = n, at = z0), a hybrid one the
+ * planes a rank touches, a halo pipeline its slab with room for the halos on both sides.
+ *   stride  where the planes z - k and z + k of a plane z are found: `stride` planes below / above it.  stride = k for a window of
+ *           consecutive planes.  A pass whose step spans whole slabs (k >= z1 - z0: the wide passes of a halo pipeline) keeps
+ *           [slab holding z - k | own slab | slab holding z + k] and passes stride = the slab height: the tile kernel then runs on the
+ *           received slabs where they landed.
+ *   vp_jfa_window_span     where the planes [p0, p1) of a window live, for whoever moves them (halo exchange): one or two byte ranges
+ *                          relative to d_ids (bytes[1] = 0 for 4-byte ids)
+ *   vp_jfa_window_clear    every id := "none" (a pipeline whose regions are rounded outwards to whole tiles reads planes nobody
+ *                          produced: cleared once, they hold ids of the window's own layout -- never stale bytes of another one)
+ *   vp_jfa_window_init     seeding: ids of the planes of f from its bitmask (halo planes as in vp_jfa_init)
+ *   vp_jfa_window_first_pass   the pass k = n/2 of the planes of f straight from the border bitmask of the WHOLE grid (vp_surface on
+ *                          a whole-grid frame): no init ids are written or read (jfa/sequential.cpp:55-60: before any pass a border
+ *                          voxel's seed is itself and nothing else has one).  n % 128 == 0 (vp_jfa_can_start_from_mask).
+ *   vp_jfa_window_first_two    the passes k = n/2 AND k = n/4 of a WHOLE grid in one launch from its border bitmask; whole-grid frame,
+ *                          a window of n planes, at = 0 (vp_jfa_can_fuse_first_two: any n >= 96)
+ *   vp_jfa_window_pass     one pass with step k over the planes of f: reads `in` (the planes of f and `stride` planes on each side of
+ *                          them, as far as the grid goes), writes the planes of f in `out` (same planes / at as `in`)
+ *   vp_jfa_window_last_pass    step 1 fused with the id -> sdf conversion; d_words_region / d_sdf_region hold the planes [z0, z1) only
+ * Same results as the plain-id calls, bit for bit. */
+typedef struct vp_window {
+    void*    d_ids;       /* vp_jfa_window_bytes(f, planes) bytes, 16-byte aligned */
+    uint32_t planes;      /* id planes the buffer holds */
+    uint32_t at;          /* index inside the buffer of plane z0 of the frame given with it */
+} vp_window;
+size_t vp_jfa_window_bytes(const vp_frame* f, uint32_t planes);
+int vp_jfa_window_span(const vp_frame* f, uint32_t planes, uint32_t p0, uint32_t p1, size_t offset[2], size_t bytes[2]);
+int vp_jfa_window_clear(vp_ctx* ctx, const vp_frame* f, const vp_window* w);
+int vp_jfa_window_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, const uint32_t* d_plane_below,
+                       const uint32_t* d_plane_above, const vp_window* out);
 int vp_jfa_can_start_from_mask(const vp_frame* f, int algo);
-int vp_jfa_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out);
-/* The passes k = n/2 AND k = n/4 of a WHOLE grid in one launch from its border bitmask (vp_jfa uses it internally): identical
- * to vp_jfa_first_pass + vp_jfa_pass(k = n/4), with the first pass never written to memory.  Whole-grid frames only
- * (z0 = 0, z1 = n) of any side the tile kernels serve (n >= 96; the chains of four it works on are closed for every n % 4 == 0); a slab
- * driver whose second pass covers most of the grid anyway may run it instead of the two region passes. */
+int vp_jfa_window_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, const vp_window* out);
 int vp_jfa_can_fuse_first_two(const vp_frame* f, int algo);
-int vp_jfa_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_out);
-
-/* Whole-volume form of the slab passes, for ghost-plane pipelines (every rank holds id volumes of the WHOLE grid and recomputes the
- * planes its later passes reach: no exchange between passes).  The caller no longer offsets pointers by plane -- it passes the volume
- * base and a frame whose [z0, z1) is the region to produce -- so the layout inside a volume is the library's: vp_jfa_volume_bytes(f)
- * per volume, plain 4-byte ids up to n = 1024 and the compact 5-byte state above (a 32-bit word plane + a byte plane; 40 instead of
- * 64 GiB per volume at n = 2048, and 10 instead of 16 bytes per voxel and pass).  Needs vp_jfa_can_fuse_first_two (n >= 96, VP_ALGO_TILED).
- *   vp_jfa_volume_first_two  passes n/2 and n/4 of the whole grid from its border mask (vp_surface on a whole-grid frame)
- *   vp_jfa_volume_pass       one pass with step k <= n/8 over the planes [z0, z1) of f; reads the planes z0-k .. z1+k of d_vol_in
- *   vp_jfa_volume_last_pass  step 1 fused with the id -> sdf conversion; d_words_region / d_sdf_region hold the planes [z0, z1) only
- * Same results as the slab calls on 8-byte ids, bit for bit. */
-size_t vp_jfa_volume_bytes(const vp_frame* f);
-int vp_jfa_volume_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, void* d_vol);
-int vp_jfa_volume_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const void* d_vol_in, void* d_vol_out);
-int vp_jfa_volume_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_vol_in, void* d_vol_scratch, const uint32_t* d_words_region,
-                            float fill_unset, float* d_sdf_region);
+int vp_jfa_window_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, const vp_window* out);
+int vp_jfa_window_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const vp_window* in, const vp_window* out, uint32_t stride);
+int vp_jfa_window_last_pass(vp_ctx* ctx, const vp_frame* f, const vp_window* in, const vp_window* scratch, uint32_t stride,
+                            const uint32_t* d_words_region, float fill_unset, float* d_sdf_region);
 
 /* "Surface" output (README.md:9): the border-voxel mask that JFA seeds
  * from (jfa/sequential.cpp:24-64), as a bitmask with the grid's layout. */
@@ -233,19 +253,24 @@ int vp_extract(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode
 
 /* ---- several GPUs of one node: Z-slabs -------------------------------------------------------
  * Replaces the reference's hard-wired device 0 (apps/cli/main.cpp:22-23) when more than one device is given: ONE process,
- * one context per device, rank r owns the planes [r n/G, (r+1) n/G) of the grid, the sdf and the JFA state; G must divide n
- * into slabs of a multiple of 8 planes.  The stages are the slab forms of the calls above (vp_frame.z0 / z1):
+ * one context per device, rank r owns the planes [r n/G, (r+1) n/G) of the grid and of the sdf; G must divide n
+ * into slabs of a multiple of 8 planes.  The stages are the slab forms of the calls above (vp_frame.z0 / z1); the JFA state of a rank
+ * lives in two id windows (vp_jfa_window_*):
  *   voxelize / CSG   no exchange (columns and words are independent)
- *   JFA              VP_MULTI_HALO : bitmask planes z0-1 / z1 before the seeding and the id planes [z0-k, min(z0, z1-k)),
- *                                    [max(z1, z0+k), z1+k) before the pass with step k travel device to device
- *                                    (hipMemcpyPeerAsync behind stream events; no host synchronisation inside the JFA)
+ *   JFA              VP_MULTI_HALO : windows of 3 n/G planes, [slab holding z - k | own slab | slab holding z + k].  Bitmask planes z0-1 /
+ *                                    z1 before the seeding and, before the pass with step k, the id planes [z0-k, min(z0, z1-k)),
+ *                                    [max(z1, z0+k), z1+k) travel device to device (hipMemcpyPeerAsync behind stream events; no host
+ *                                    synchronisation inside the JFA): next to the slab for k <= n/2G, a slab height away for the steps
+ *                                    that span whole slabs (stride = n/G, see vp_jfa_window_pass)
  *                    VP_MULTI_GHOST: the bitmask slabs are all-gathered once (n^3/8 bytes) and every device recomputes the
- *                                    ghost planes its later passes reach: no exchange between passes, two full id volumes
+ *                                    ghost planes its later passes reach: no exchange between passes, two windows of the whole grid
  *                                    per device
  *                    VP_MULTI_HYBRID: ghost planes for the passes with k > nz/2 (as far as the later such passes reach), halo
- *                                    planes from the two adjacent devices for the passes with k <= nz/2; the id volumes hold only
+ *                                    planes from the two adjacent devices for the passes with k <= nz/2; the windows hold only
  *                                    the planes a device touches (vp_multi_window): capacity, not speed
- * Results are bit-identical to the single-device calls for any G.  `devices` may name one device several times (several
+ * Results are bit-identical to the single-device calls for any G.  The sharded forms run the tile kernels whatever `algo` says (both
+ * algorithms give the same sdf); grids below their range (n < 96) are not sharded: every device computes the whole grid with `algo`
+ * and keeps its slab.  `devices` may name one device several times (several
  * contexts on it): that is how the parity tests run on a one-GPU box.  Grid, sdf and mesh stay resident on the devices
  * between calls; host arrays are whole-grid arrays in the reference's layout. */
 typedef struct vp_multi vp_multi;
@@ -270,9 +295,9 @@ int vp_multi_jfa(vp_multi* m, float fill_unset, int algo, int mode);
 int vp_multi_get_sdf(vp_multi* m, float* h_sdf);
 /* device-to-device bytes the last vp_multi_jfa enqueued (halo planes / the bitmask all-gather) */
 uint64_t vp_multi_bytes_moved(const vp_multi* m);
-/* JFA state a rank held during the last vp_multi_jfa: the global planes [lo, hi) its two id volumes cover -- the whole grid with
- * VP_MULTI_GHOST, the slab +- nz/2 with VP_MULTI_HALO (plus two whole-slab buffers for the wide passes), the rank's WINDOW with
- * VP_MULTI_HYBRID -- and the bytes of device memory in all its id buffers.  Any out pointer may be NULL. */
+/* JFA state a rank held during the last vp_multi_jfa: the global planes [lo, hi) its two id windows are addressed by -- the whole grid with
+ * VP_MULTI_GHOST, the slab with VP_MULTI_HALO (its windows also hold the two slabs received from z -+ k), the planes the rank touches
+ * with VP_MULTI_HYBRID -- and the bytes of device memory in its id buffers.  Any out pointer may be NULL. */
 int vp_multi_window(const vp_multi* m, int rank, uint32_t* lo, uint32_t* hi, uint64_t* id_bytes);
 
 /* ---- host-in / host-out conveniences (the reference's Compute() calling convention) -------

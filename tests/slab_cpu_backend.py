@@ -15,8 +15,16 @@ def _np(t):
 
 
 class CpuSlabBackend:
-    def __init__(self, mesh_host):
+    """The backend interface of slab.py (HipSlabBackend) on numpy: an id window is `planes` x n x n int32 linear voxel indices (NONE = no
+    seed) -- the layout is the backend's own business, the pipelines only move whole planes of it (win_spans)."""
+
+    def __init__(self, mesh_host, poison=None):
         self.mesh_host = mesh_host            # (xyz, tri) numpy: 'device' mesh handles are ignored
+        self.poison = poison                  # tests: a voxel index every entry of a fresh window starts as: a (wrong) seed that would spoil the
+                                              # result if a plane nobody produced were ever consumed
+
+    def check_frame(self, frame):
+        pass
 
     def empty_u32(self, n):
         return torch.zeros(int(n), dtype=torch.int32)
@@ -24,11 +32,66 @@ class CpuSlabBackend:
     def empty_f32(self, n):
         return torch.zeros(int(n), dtype=torch.float32)
 
-    def ids_u32(self, n):
-        """id volumes of the ghost / hybrid pipelines (slab.py: filled once at allocation).  VP_SLAB_POISON = a voxel index every
-        entry starts as: a (wrong) seed that would spoil the result if a plane nobody produced were ever consumed."""
-        import os
-        return torch.full((int(n),), int(os.environ.get("VP_SLAB_POISON", "0"), 0), dtype=torch.int32)
+    def can_start_from_mask(self, frame):
+        return False
+
+    # -- id windows ---------------------------------------------------------------------------
+    def window(self, frame, planes):
+        from cuda_mesh_voxelization_amd.slab import IdWindow
+        return IdWindow(torch.full((int(planes) * frame.n * frame.n,), int(NONE if self.poison is None else self.poison), dtype=torch.int32), planes)
+
+    def win_spans(self, frame, w, p0, p1):
+        pv = frame.n * frame.n
+        assert 0 <= p0 <= p1 <= w.planes, "planes [%d, %d) outside a window of %d" % (p0, p1, w.planes)
+        return [w.t[p0 * pv:p1 * pv]]
+
+    def _planes(self, frame, w, p0, p1):
+        return _np(self.win_spans(frame, w, p0, p1)[0]).reshape(p1 - p0, frame.n, frame.n)
+
+    def win_init(self, region, words_region, below, above, w, at):
+        nz = region.z1 - region.z0
+        ids = torch.zeros(nz * region.n * region.n, dtype=torch.int32)
+        self.jfa_init(region, words_region, below, above, ids)
+        self._planes(region, w, at, at + nz)[:] = _np(ids).reshape(nz, region.n, region.n)
+
+    def surface(self, frame, words, border):
+        ids = torch.zeros(frame.voxels, dtype=torch.int32)
+        self.jfa_init(frame, words, None, None, ids)
+        bits = (_np(ids) != NONE)
+        _np(border)[:] = np.packbits(bits, bitorder="little").view(np.int32)
+
+    def win_first_two(self, frame, border_full, w):
+        """passes n/2 and n/4 of the whole grid from its border mask"""
+        from cuda_mesh_voxelization_amd.slab import IdWindow
+        n = frame.n
+        assert w.planes == n
+        bits = np.unpackbits(_np(border_full).view(np.uint8), bitorder="little").astype(bool)
+        lin = np.arange(n * n * n, dtype=np.int32)
+        tmp = [IdWindow(torch.from_numpy(np.where(bits, lin, NONE).astype(np.int32)), n), IdWindow(torch.zeros(n * n * n, dtype=torch.int32), n)]
+        self.win_pass(frame, n // 2, tmp[0], tmp[1], 0)
+        self.win_pass(frame, n // 4, tmp[1], w, 0)
+
+    def win_pass(self, region, k, w_in, w_out, at, stride=None):
+        n, z0, z1 = region.n, region.z0, region.z1
+        stride = k if stride is None else stride
+        assert w_in.planes == w_out.planes
+        A = _np(w_in.t).reshape(w_in.planes, n, n)
+        none_plane = np.full((n, n), NONE, np.int32)
+
+        def plane(z, d):                      # the plane z + d k of a region plane z sits d * stride planes from it in the window
+            if z + d * k < 0 or z + d * k >= n:
+                return none_plane
+            i = at + (z - z0) + d * stride
+            assert 0 <= i < w_in.planes, "pass with step %d (stride %d) on [%d, %d) at %d reads window plane %d of %d" % (k, stride, z0, z1, at, i, w_in.planes)
+            return A[i]
+
+        _np(w_out.t).reshape(w_out.planes, n, n)[at:at + (z1 - z0)] = self._pass(region, k, plane)
+
+    def win_last_pass(self, region, w_in, w_scratch, at, words_region, fill, sdf, stride=1):
+        n, nz = region.n, region.z1 - region.z0
+        self.win_pass(region, 1, w_in, w_scratch, at, stride)
+        ids = torch.from_numpy(_np(w_scratch.t).reshape(-1, n, n)[at:at + nz].reshape(-1).copy())
+        self.jfa_finalize(region, words_region, ids, fill, sdf)
 
     # -- stages -------------------------------------------------------------------------------
     def voxelize(self, frame, words, d_xyz, d_tri, algo):
@@ -74,66 +137,12 @@ class CpuSlabBackend:
         sz = oz + (safe // (n * n)).astype(f32) * vs
         return ((sx - px) * (sx - px) + (sy - py) * (sy - py)) + (sz - pz) * (sz - pz)
 
-    def jfa_pass(self, frame, k, src, minus, plus, dst, algo):
-        n, z0, z1 = frame.n, frame.z0, frame.z1
-        nz = z1 - z0
-        S = _np(src).reshape(nz, n, n)
-        M = _np(minus).reshape(-1, n, n) if minus is not None else None
-        P = _np(plus).reshape(-1, n, n) if plus is not None else None
-        none_plane = np.full((n, n), NONE, np.int32)
-
-        def plane(zg):                       # the addressing rule of vphip.h / vp_jfa_pass
-            if zg < 0 or zg >= n:
-                return none_plane
-            if zg < z0:
-                return M[zg - (z0 - k)]
-            if zg >= z1:
-                return P[zg - max(z1, z0 + k)]
-            return S[zg - z0]
-
-        _np(dst)[:] = self._pass(frame, k, plane).reshape(-1)
-
-    # -- whole-grid buffers addressed by global plane (GhostSlabPipeline) --
-    def jfa_pass_global(self, region, k, src_full, dst_full, algo):
-        n = region.n
-        A = _np(src_full).reshape(n, n, n)
-        none_plane = np.full((n, n), NONE, np.int32)
-        best = self._pass(region, k, lambda zg: A[zg] if 0 <= zg < n else none_plane)
-        _np(dst_full).reshape(n, n, n)[region.z0:region.z1] = best
-
-    def jfa_last_pass_global(self, region, src_full, scratch_full, words_region, fill, sdf, algo):
-        n = region.n
-        self.jfa_pass_global(region, 1, src_full, scratch_full, algo)
-        ids = torch.from_numpy(_np(scratch_full).reshape(n, n, n)[region.z0:region.z1].reshape(-1).copy())
-        self.jfa_finalize(region, words_region, ids, fill, sdf)
-
-    # -- buffers that hold the planes [lo, hi) only (HybridSlabPipeline) --
-    def jfa_pass_window(self, region, k, src, dst, lo, algo):
-        n = region.n
-        A = _np(src).reshape(-1, n, n)
-        hi = lo + A.shape[0]
-        none_plane = np.full((n, n), NONE, np.int32)
-
-        def plane(zg):
-            if zg < 0 or zg >= n:
-                return none_plane
-            assert lo <= zg < hi, "pass with step %d on [%d, %d) reads plane %d outside the window [%d, %d)" % (k, region.z0, region.z1, zg, lo, hi)
-            return A[zg - lo]
-
-        _np(dst).reshape(-1, n, n)[region.z0 - lo:region.z1 - lo] = self._pass(region, k, plane)
-
-    def jfa_last_pass_window(self, region, src, scratch, lo, words_region, fill, sdf, algo):
-        n = region.n
-        self.jfa_pass_window(region, 1, src, scratch, lo, algo)
-        ids = torch.from_numpy(_np(scratch).reshape(-1, n, n)[region.z0 - lo:region.z1 - lo].reshape(-1).copy())
-        self.jfa_finalize(region, words_region, ids, fill, sdf)
-
     def _pass(self, frame, k, plane):
         n, z0, z1 = frame.n, frame.z0, frame.z1
         nz = z1 - z0
         f32 = np.float32
         vs, ox, oy, oz = f32(frame.voxel_size), f32(frame.origin[0]), f32(frame.origin[1]), f32(frame.origin[2])
-        S = np.stack([plane(zg) for zg in range(z0, z1)], 0)
+        S = np.stack([plane(zg, 0) for zg in range(z0, z1)], 0)
         zz, yy, xx = np.meshgrid(np.arange(z0, z1), np.arange(n), np.arange(n), indexing="ij")
         px = ox + xx.astype(f32) * vs
         py = oy + yy.astype(f32) * vs
@@ -141,7 +150,7 @@ class CpuSlabBackend:
         best = S.copy()
         bestd = np.where(best == NONE, f32(np.inf), self._dist(frame, best, px, py, pz)).astype(f32)
         for dz in (-1, 0, 1):
-            stack = np.stack([plane(zg + dz * k) for zg in range(z0, z1)], 0)
+            stack = np.stack([plane(zg, dz) for zg in range(z0, z1)], 0)
             pad = np.pad(stack, ((0, 0), (k, k), (k, k)), constant_values=NONE)
             for dy in (-1, 0, 1):
                 for dx in (-1, 0, 1):

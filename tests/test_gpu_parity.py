@@ -103,33 +103,53 @@ def test_voxelize_empty_and_degenerate(engine):
         assert np.array_equal(got, exp)
 
 
-def test_voxelize_work_queue_overflow_path(engine, monkeypatch):
+def _run_with_hooks(code, env):
+    """Child process on libvphip_hooks.so (the build with -DVP_TEST_HOOKS: the default library reads no environment variable on any call
+    path, VERDICT r04 #6); the hooks are read per call, the contexts are fresh."""
+    import os, subprocess, sys
+    from cuda_mesh_voxelization_amd import build
+    build.build_lib(hooks=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pre = "import sys, numpy as np\nsys.path.insert(0, %r)\n" % root
+    return subprocess.run([sys.executable, "-c", pre + code], capture_output=True, text=True, timeout=900,
+                          env=dict(os.environ, VPHIP_LIB=capi.HOOKS_LIB_PATH, **env))
+
+
+def test_default_library_reads_no_environment():
+    """the shipping library has no getenv on any path: the symbol is not even imported"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in out
+    from cuda_mesh_voxelization_amd import build
+    build.build_lib(hooks=True)
+    assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", capi.HOOKS_LIB_PATH], capture_output=True, text=True).stdout
+
+
+def test_voxelize_work_queue_overflow_path(engine):
     """The tile stage sizes nothing on the host: a tile whose slice of the work queue does not fit scans the record list
-    itself.  Force that path (VP_VOX_QUEUE_CAP) on meshes made of large triangles and on a mixed one."""
-    for name, n in (("d20.obj", 128), ("torus.obj", 256), ("sphere.obj", 160)):
-        xyz, tri = M.import_mesh(M.asset(name))
-        origin, vs = M.frame([xyz], n)
-        fr = Frame.make(n, vs, origin)
-        exp = O.voxelize(xyz, tri, n, vs, origin)
-        dx, dt = engine.mesh_to_device(xyz, tri)
-        for cap in ("0", "7", "100"):
-            monkeypatch.setenv("VP_VOX_QUEUE_CAP", cap)
-            got = engine.words_to_numpy(engine.voxelize(fr, dx, dt, algo=ALGO_TILED))
-            assert np.array_equal(got, exp), (name, n, cap)
-        monkeypatch.delenv("VP_VOX_QUEUE_CAP")
-        got = engine.words_to_numpy(engine.voxelize(fr, dx, dt, algo=ALGO_TILED))
-        assert np.array_equal(got, exp), (name, n)
+    itself.  Force that path (VP_VOX_QUEUE_CAP, hooks build) on meshes made of large triangles and on a mixed one."""
+    code = (
+        "from cuda_mesh_voxelization_amd import mesh as M\n"
+        "from cuda_mesh_voxelization_amd.capi import Frame, ALGO_TILED\n"
+        "from cuda_mesh_voxelization_amd.pipeline import Engine\n"
+        "from oracle import oracle as O\n"
+        "eng = Engine(0)\n"
+        "for name, n in (('d20.obj', 128), ('torus.obj', 256), ('sphere.obj', 160)):\n"
+        "    xyz, tri = M.import_mesh(M.asset(name)); origin, vs = M.frame([xyz], n); fr = Frame.make(n, vs, origin)\n"
+        "    dx, dt = eng.mesh_to_device(xyz, tri)\n"
+        "    g = eng.voxelize(fr, dx, dt, algo=ALGO_TILED); eng.sync()\n"
+        "    assert np.array_equal(eng.words_to_numpy(g), O.voxelize(xyz, tri, n, vs, origin)), (name, n)\n"
+        "print('ok')\n")
+    for cap in ("0", "7", "100"):
+        p = _run_with_hooks(code, {"VP_VOX_QUEUE_CAP": cap})
+        assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (cap, p.stdout[-500:], p.stderr[-2000:])
 
 
 def test_voxelize_record_list_overflow_path(engine):
     """The list of large-triangle records is sized from what earlier calls counted; a large triangle that finds it full is
-    rasterised in place by the setup kernel.  VP_VOX_REC_CAP forces that: a record list of 0 / 3 / 7 entries for a mesh of 20
-    huge triangles (child processes: the switch is read per call, the contexts are fresh) -- same bitmask, bit for bit."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rasterised in place by the setup kernel.  VP_VOX_REC_CAP (hooks build) forces that: a record list of 0 / 3 / 7 entries for a mesh of
+    20 huge triangles -- same bitmask, bit for bit."""
     code = (
-        "import sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
         "from cuda_mesh_voxelization_amd import mesh as M\n"
         "from cuda_mesh_voxelization_amd.capi import Frame, ALGO_TILED\n"
         "from cuda_mesh_voxelization_amd.pipeline import Engine\n"
@@ -141,9 +161,9 @@ def test_voxelize_record_list_overflow_path(engine):
         "    for rep in range(3):\n"                                  # the second and third call see the lazily read counts
         "        g = eng.voxelize(fr, dx, dt, algo=ALGO_TILED); eng.sync()\n"
         "        assert np.array_equal(eng.words_to_numpy(g), O.voxelize(xyz, tri, n, vs, origin)), (name, n, rep)\n"
-        "print('ok')\n" % root)
+        "print('ok')\n")
     for cap in ("0", "3", "7"):
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VP_VOX_REC_CAP=cap))
+        p = _run_with_hooks(code, {"VP_VOX_REC_CAP": cap})
         assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (cap, p.stdout[-500:], p.stderr[-2000:])
 
 
@@ -243,6 +263,21 @@ def test_jfa_run_needs_its_own_start(engine):
     ctx.memset(work.data_ptr(), 0, 16)                                 # ... and so does a write to the workspace itself
     with pytest.raises(capi.VPError, match="vp_jfa_start"):
         run(256, ALGO_TILED)
+    # ... wherever the write lands (byte ranges, not base pointers): a slab of the grid re-voxelized in place, a copy into
+    # the interior of the grid, a write into the middle of the workspace
+    pb = 256 * 256 // 8
+    start(256, ALGO_TILED)
+    ctx.voxelize(frames[256].slab(8, 16), g[256].data_ptr() + 8 * pb, dx.data_ptr(), dx.shape[0], dt.data_ptr(), dt.shape[0], ALGO_TILED, False)
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(256, ALGO_TILED)
+    start(256, ALGO_TILED)
+    ctx.memcpy_d2d(g[256].data_ptr() + 4096, g[256].data_ptr() + 4096, 64)
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(256, ALGO_TILED)
+    start(256, ALGO_TILED)
+    ctx.memset(work.data_ptr() + nb // 2, 0, 16)
+    with pytest.raises(capi.VPError, match="vp_jfa_start"):
+        run(256, ALGO_TILED)
     start(256, ALGO_TILED)
     run(256, ALGO_TILED)                                               # an undisturbed pair still works
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
@@ -333,7 +368,7 @@ def test_jfa_random_and_edge_grids(engine):
 
 
 def test_jfa_tile_kernel_edge_grids(engine):
-    """The same edge cases at n = 256, where the tiled path is jfa_first_pass + jfa_pass_zstream (sparse, dense and
+    """The same edge cases at n = 256, where the tiled path is the fused first two passes + the tile kernel (dense and
     fused last variants): empty grid (everything stays +-inf), full grid (only the hull is border), one voxel,
     1 % random voxels, dense noise -- against the oracle, both fill signs."""
     n = 256
@@ -695,14 +730,33 @@ def test_extract_records_match_numpy(engine):
                 assert np.array_equal(r2[:10].view(np.uint64), exp[:10]) and (r2[10:] == -1).all()
 
 
+def _coords_plain64(t):
+    """(x, scr(y), scr(z), none) of plain 8-byte ids (jfa_common.h: Id64 -- .x = scr(z) << 2 | x << 13, .y = scr(y) << 2, "none" = all ones)"""
+    lo, hi = (t & 0xFFFFFFFF), ((t >> 32) & 0xFFFFFFFF)
+    none = lo == 0xFFFFFFFF
+    return (lo >> 13) & 2047, (hi >> 2) & 2047, (lo >> 2) & 2047, none
+
+
+def _coords_window(w, planes, n):
+    """the same of a window above n = 1024 (IdC: word plane x | scr(y) << 11 | (scr(z) & 1023) << 22, byte plane = top z bit << 1 | none << 2)"""
+    vox = planes * n * n
+    word = w[:vox * 4].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    byte = w[vox * 4:vox * 5].to(torch.int64)
+    return word & 2047, (word >> 11) & 2047, ((word >> 22) & 1023) | ((byte & 2) << 9), (byte & 4) != 0
+
+
 @pytest.mark.parametrize("n,kind", [(512, "noise"), (512, "sparse"), (512, "mesh"), (1024, "sparse"), (288, "noise"), (1152, "noise"), (256, "noise"), (1024, "noise"),
                                     (96, "noise"), (128, "noise"), (128, "sparse"), (160, "sparse"), (224, "noise")])
 def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
-    """Pass by pass, on the SAME input state: the packed seed ids the tile kernels write (sparse, dense with the
-    v_min_f64 pair update, every k; and the first pass in its from-the-border-mask form) equal those of the one-thread-per-voxel kernel, which walks the 27
-    candidates in the reference's order with its strict '<' (sequential.cpp:84-112).  Random grids are full of equidistant
-    seeds, so this is the test of the first-minimum rule itself -- the sdf alone would forgive a wrong winner of a tie."""
+    """Pass by pass: the packed seed ids the tile kernel writes (every k; and the first pass / the first two passes in their
+    from-the-border-mask forms) equal those of the one-thread-per-voxel kernel, which walks the 27 candidates in the reference's order with
+    its strict '<' (sequential.cpp:84-112).  Random grids are full of equidistant seeds, so this is the test of the first-minimum rule itself
+    -- the sdf alone would forgive a wrong winner of a tie.  Up to n = 1024 both kernels run on the SAME input state (a window of 4-byte ids
+    IS an array of plain ids); above, the tile kernel's state is a window in its own layout, so two sequences run side by side from the
+    same seeding and are compared coordinate by coordinate after every pass."""
+    import gc
     import torch
+    from cuda_mesh_voxelization_amd.capi import Window
     rng = np.random.default_rng(n + len(kind))
     if kind == "mesh":
         xyz, tri = M.import_mesh(M.asset("bimba.obj"))
@@ -718,42 +772,63 @@ def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
         else:
             words = (rng.random(nw) < 0.004).astype(np.uint32) << rng.integers(0, 32, nw).astype(np.uint32)
         g = engine.to_device(words, np.uint32)
-    idb = engine.ctx.jfa_id_bytes(fr)
-    assert idb == (8 if n > 1024 else 4)                              # n = 1152: 8-byte ids (tile-relative ranks in the dense kernel)
-    cur = torch.empty(fr.voxels, dtype=torch.int32 if idb == 4 else torch.int64, device=engine.device)
-    engine.ctx.jfa_init(fr, g.data_ptr(), None, None, cur.data_ptr())
-    a = torch.empty_like(cur)
+    ctx = engine.ctx
+    idb = ctx.jfa_id_bytes(fr)
+    assert idb == (8 if n > 1024 else 4)
+    border = torch.empty(fr.words, dtype=torch.int32, device=engine.device)
+    ctx.surface(fr, g.data_ptr(), None, None, border.data_ptr())
+    wbytes = ctx.jfa_window_bytes(fr, n)
+    assert wbytes == fr.voxels * (5 if n > 1024 else 4)
+    cur = torch.empty(fr.voxels, dtype=torch.int32 if idb == 4 else torch.int64, device=engine.device)     # the naive sequence
     b = torch.empty_like(cur)
+    ctx.jfa_init(fr, g.data_ptr(), None, None, cur.data_ptr())
+    wa = torch.empty(wbytes, dtype=torch.uint8, device=engine.device)
+    wb = torch.empty(wbytes, dtype=torch.uint8, device=engine.device)
+    W = lambda t: Window.make(t.data_ptr(), n, 0)
+
+    def same(win, plain, what):
+        engine.sync()
+        if n <= 1024:
+            ok = torch.equal(win.view(torch.int32), plain)
+        else:
+            cw, cp = _coords_window(win, n, n), _coords_plain64(plain)
+            ok = bool(torch.equal(cw[3], cp[3])) and all(bool(torch.equal(torch.where(cw[3], 0, x), torch.where(cp[3], 0, y))) for x, y in zip(cw[:3], cp[:3]))
+        assert ok, (n, kind, what)
+
+    if n > 1024:
+        ctx.jfa_window_init(fr, g.data_ptr(), None, None, W(wa))          # the tile sequence starts from the same seeding
+        same(wa, cur, "init")
     k = n // 2
     while k >= 1:
-        engine.ctx.jfa_pass(fr, k, cur.data_ptr(), None, None, a.data_ptr(), ALGO_TILED)
-        engine.ctx.jfa_pass(fr, k, cur.data_ptr(), None, None, b.data_ptr(), ALGO_NAIVE)
-        engine.sync()
-        assert torch.equal(a, b), (n, kind, k, int((a != b).sum().item()))
-        if k == n // 2 and engine.ctx.jfa_can_start_from_mask(fr, ALGO_TILED):
-            # what vp_jfa really runs first: the pass straight from the border bitmask, no id volume read
-            border = torch.empty(fr.words, dtype=torch.int32, device=engine.device)
-            engine.ctx.surface(fr, g.data_ptr(), None, None, border.data_ptr())
-            engine.ctx.jfa_first_pass(fr, border.data_ptr(), a.data_ptr())
-            engine.sync()
-            assert torch.equal(a, b), (n, kind, "first pass from the mask", int((a != b).sum().item()))
-        if k == n // 4 and engine.ctx.jfa_can_fuse_first_two(fr, ALGO_TILED):
-            # ... and what vp_jfa runs since: both passes in one launch from the mask (vp_jfa_first_two)
-            border = torch.empty(fr.words, dtype=torch.int32, device=engine.device)
-            engine.ctx.surface(fr, g.data_ptr(), None, None, border.data_ptr())
-            engine.ctx.jfa_first_two(fr, border.data_ptr(), a.data_ptr())
-            engine.sync()
-            assert torch.equal(a, b), (n, kind, "passes n/2 + n/4 from the mask", int((a != b).sum().item()))
-        cur, a = a, cur
+        ctx.jfa_pass(fr, k, cur.data_ptr(), None, None, b.data_ptr(), ALGO_NAIVE)
+        if n <= 1024:
+            ctx.jfa_pass(fr, k, cur.data_ptr(), None, None, wa.data_ptr(), ALGO_TILED)     # plain 4-byte ids in consecutive planes: the tile kernel
+            same(wa, b, k)
+        else:
+            ctx.jfa_window_pass(fr, k, W(wa), W(wb))
+            same(wb, b, k)
+            wa, wb = wb, wa
+        if k == n // 2 and ctx.jfa_can_start_from_mask(fr, ALGO_TILED):
+            # the pass straight from the border bitmask, no id volume read
+            t = torch.empty(wbytes, dtype=torch.uint8, device=engine.device)
+            ctx.jfa_window_first_pass(fr, border.data_ptr(), W(t))
+            same(t, b, "first pass from the mask")
+            del t
+        if k == n // 4 and ctx.jfa_can_fuse_first_two(fr, ALGO_TILED):
+            # ... and what vp_jfa runs: both passes in one launch from the mask
+            t = torch.empty(wbytes, dtype=torch.uint8, device=engine.device)
+            ctx.jfa_window_first_two(fr, border.data_ptr(), W(t))
+            same(t, b, "passes n/2 + n/4 from the mask")
+            del t
+        cur, b = b, cur
         k //= 2
-    del cur, a, b
-    import gc
+    del cur, b, wa, wb
     gc.collect(); torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("n,kind", [(1152, "sparse"), (1152, "mesh"), (1280, "sparse"), (2048, "sparse")])
 def test_compact_id_state_of_whole_grid_jfa_matches_naive(engine, n, kind):
-    """n > 1024, whole grid: vp_jfa keeps its id state in the compact layout of round 4 (jfa.hip: IdC -- a word plane and a byte plane,
+    """n > 1024, whole grid: vp_jfa keeps its id state in windows (jfa_common.h: IdC -- a word plane and a byte plane,
     5 bytes per voxel; first two passes fused from the border mask, every later pass and the fused last pass on the tile kernel, the top z
     bit of a candidate carried in its rank).  The check is the naive sequence on 8-byte ids (one thread per voxel, the reference's scan
     order and strict '<').  Sparse random grids are full of equidistant seeds and of voxels that stay "none" for many passes; sizes
@@ -815,34 +890,6 @@ def test_compact_id_state_edge_grids(engine, kind):
     del g
     engine._work = None
     gc.collect(); torch.cuda.empty_cache()
-
-
-def test_round1_tile_kernel_path_still_matches(engine):
-    """VP_JFA_DENSE=0 routes every pass of a 32-bit-id JFA through jfa_pass_zstream (the kernel that still serves 8-byte ids, the
-    sparse pass and slabs whose halo buffers are not contiguous): same sdf, bit for bit, as the default path.  The switch is read
-    once per process, hence the child process."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from cuda_mesh_voxelization_amd import mesh as M\n"
-        "from cuda_mesh_voxelization_amd.capi import Frame\n"
-        "from cuda_mesh_voxelization_amd.pipeline import Engine\n"
-        "from oracle import oracle as O\n"
-        "eng = Engine(0)\n"
-        "xyz, tri = M.import_mesh(M.asset('bunny.obj'))\n"
-        "for n in (256, 288, 512):\n"
-        "    origin, vs = M.frame([xyz], n); fr = Frame.make(n, vs, origin)\n"
-        "    dx, dt = eng.mesh_to_device(xyz, tri)\n"
-        "    g = eng.voxelize(fr, dx, dt)\n"
-        "    print(n, O.fnv(eng.jfa(fr, g).cpu().numpy()))\n" % root)
-    outs = []
-    for v in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VP_JFA_DENSE=v), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([l for l in r.stdout.splitlines() if l and l[0].isdigit()])
-    assert len(outs[0]) == 3 and outs[0] == outs[1], outs
 
 
 @pytest.mark.parametrize("n,seed", [(96, 1), (160, 2), (256, 3), (512, 4)])

@@ -44,7 +44,9 @@ def test_multi_matches_single_and_oracle(engine, name, n, world):
                 # halo: planes really moved (bitmask planes + id planes of every pass); ghost: only the bitmask all-gather;
                 # hybrid: the all-gather + k planes per side and narrow pass
                 gather = world * (world - 1) * (fr.words // world) * 4
-                if mode == MULTI_GHOST:
+                if n < 96:                                               # below the tile kernels' range the grid is not sharded: every device
+                    assert m.bytes_moved == gather and m.window(0)[:2] == (0, n)    # computes the whole 64^3 grid and keeps its slab
+                elif mode == MULTI_GHOST:
                     assert m.bytes_moved == gather
                 elif mode == MULTI_HYBRID:
                     nz = n // world
@@ -86,14 +88,10 @@ def test_multi_csg_and_set_grid(engine):
         m.close()
 
 
-@pytest.mark.parametrize("world,mode,fused_pct", [(2, MULTI_HALO, None), (4, MULTI_HALO, None), (8, MULTI_HALO, None), (4, MULTI_GHOST, None),
-                                                  (8, MULTI_GHOST, None), (8, MULTI_GHOST, "101"), (4, MULTI_HYBRID, None), (8, MULTI_HYBRID, None)])
-def test_multi_headline_size_equals_single(engine, world, mode, fused_pct, monkeypatch):
-    """n = 512 on the benchmark mesh: narrow passes land next to the slab (dense tile kernel), wide ones in the whole-slab
-    buffers; ghost regions take the first two passes as the one whole-grid launch (every rank of 2 .. 8 slabs is above the 35 %
-    break-even) or, forced with VP_FUSED_FIRST_TWO_PCT=101, as the two region passes."""
-    if fused_pct:
-        monkeypatch.setenv("VP_FUSED_FIRST_TWO_PCT", fused_pct)
+@pytest.mark.parametrize("world,mode", [(2, MULTI_HALO), (4, MULTI_HALO), (8, MULTI_HALO), (4, MULTI_GHOST), (8, MULTI_GHOST), (4, MULTI_HYBRID), (8, MULTI_HYBRID)])
+def test_multi_headline_size_equals_single(engine, world, mode):
+    """n = 512 on the benchmark mesh: halos of the narrow passes land next to the slab, the slabs of the wide ones a slab height away
+    (stride = nz); ghost regions take the first two passes as the one whole-grid launch."""
     xyz, tri = M.bunny(24)
     n = 512
     origin, vs = M.frame([xyz], n)
@@ -138,36 +136,47 @@ def test_multi_config4_n1024_four_slabs(engine, mode):
 
 
 @pytest.mark.parametrize("poison", ["0xA5", "0xFF"])
-def test_multi_ghost_ignores_unproduced_planes(engine, monkeypatch, poison):
-    """ADVICE r03: the ghost regions are rounded outwards to the 8-plane tile, so the excess planes of a pass read planes the pass
-    before it never produced.  The id volumes are refilled with a poison byte before every vp_multi_jfa (VP_MULTI_POISON): the slabs
-    must not depend on it.  n = 256 over 8 ranks: slabs of 32 planes, every pass with k < 8 has rounding excess on both sides."""
-    monkeypatch.setenv("VP_MULTI_POISON", poison)
-    xyz, tri = M.import_mesh(M.asset("bunny.obj"))
-    n, world = 256, 8
-    origin, vs = M.frame([xyz], n)
-    fr = Frame.make(n, vs, origin)
-    ref_w, ref_s = _single(engine, fr, xyz, tri)
-    m = capi.Multi([0] * world)
-    try:
-        m.set_mesh(xyz, tri)
-        m.voxelize(fr)
-        for fused in ("35", "101"):                                  # with and without the fused whole-grid first two passes
-            monkeypatch.setenv("VP_FUSED_FIRST_TWO_PCT", fused)
-            m.jfa(mode=MULTI_GHOST)
-            assert np.array_equal(m.get_sdf().view(np.uint32), ref_s.view(np.uint32)), fused
-    finally:
-        m.close()
+def test_multi_ghost_ignores_unproduced_planes(engine, poison):
+    """ADVICE r03 / r04: the ghost regions are rounded outwards to the 8-plane tile, so the excess planes of a pass read planes the pass
+    before it never produced.  In the hooks build (libvphip_hooks.so, VP_MULTI_POISON) the word planes of the id windows are refilled
+    with a poison byte before every vp_multi_jfa: the slabs must not depend on it.  n = 256 over 8 ranks: slabs of 32 planes, every pass
+    with k < 8 has rounding excess on both sides; n = 1152 over 4: the 5-byte window layout, the windows re-used by another mode (another
+    geometry: cleared) in between."""
+    import os, subprocess, sys
+    from cuda_mesh_voxelization_amd import build
+    build.build_lib(hooks=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from cuda_mesh_voxelization_amd import capi, mesh as M\n"
+        "from cuda_mesh_voxelization_amd.capi import Frame, MULTI_GHOST, MULTI_HALO, MULTI_HYBRID\n"
+        "from cuda_mesh_voxelization_amd.pipeline import Engine\n"
+        "eng = Engine(0)\n"
+        "xyz, tri = M.import_mesh(M.asset('bunny.obj'))\n"
+        "for n, world in ((256, 8), (1152, 4)):\n"
+        "    origin, vs = M.frame([xyz], n); fr = Frame.make(n, vs, origin)\n"
+        "    dx, dt = eng.mesh_to_device(xyz, tri)\n"
+        "    ref = eng.jfa(fr, eng.voxelize(fr, dx, dt)).cpu().numpy(); eng._work = None\n"
+        "    m = capi.Multi([0] * world)\n"
+        "    m.set_mesh(xyz, tri); m.voxelize(fr)\n"
+        "    for mode in (MULTI_GHOST, MULTI_HYBRID, MULTI_GHOST, MULTI_HALO):\n"
+        "        m.jfa(mode=mode)\n"
+        "        assert np.array_equal(m.get_sdf().view(np.uint32), ref.view(np.uint32)), (n, mode)\n"
+        "    m.close()\n"
+        "print('ok')\n" % root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, VPHIP_LIB=capi.HOOKS_LIB_PATH, VP_MULTI_POISON=poison))
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.stdout[-500:], p.stderr[-3000:])
 
 
-def test_python_ghost_and_hybrid_ignore_unproduced_planes(engine, monkeypatch):
-    """the same for the one-process-per-GPU pipelines of slab.py (VP_SLAB_POISON fills their id volumes at allocation)"""
+def test_python_ghost_and_hybrid_ignore_unproduced_planes(engine):
+    """the same for the one-process-per-GPU pipelines of slab.py (HipSlabBackend(poison=...) overwrites the word planes of fresh windows)"""
     from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline, HipSlabBackend, HybridSlabPipeline
 
     class _Alone:                                                    # the hybrid pipeline of rank 0 of 1 exchanges nothing
         pass
 
-    monkeypatch.setenv("VP_SLAB_POISON", "0xA5")
     xyz, tri = M.import_mesh(M.asset("bunny.obj"))
     n, world = 256, 8
     origin, vs = M.frame([xyz], n)
@@ -176,12 +185,12 @@ def test_python_ghost_and_hybrid_ignore_unproduced_planes(engine, monkeypatch):
     dx, dt = engine.mesh_to_device(xyz, tri)
     nzv = fr.voxels // world
     for r in range(world):
-        pipe = GhostSlabPipeline(HipSlabBackend(engine), fr, r, world)
+        pipe = GhostSlabPipeline(HipSlabBackend(engine, poison=0xA5), fr, r, world)
         pipe.voxelize(dx, dt)
         s = pipe.jfa().cpu().numpy()
         assert np.array_equal(s.view(np.uint32), ref_s[r * nzv:(r + 1) * nzv].view(np.uint32)), r
         assert pipe.report()["hbm_bytes_this_rank"] >= 2 * fr.voxels * 4 + fr.words * 4
-    pipe = HybridSlabPipeline(HipSlabBackend(engine), fr, 0, 1, _Alone())
+    pipe = HybridSlabPipeline(HipSlabBackend(engine, poison=0xA5), fr, 0, 1, _Alone())
     pipe.voxelize(dx, dt)
     assert np.array_equal(pipe.jfa().cpu().numpy().view(np.uint32), ref_s.view(np.uint32))
 

@@ -97,7 +97,7 @@ def test_halo_plan_covers_exactly_what_a_pass_reads():
         slab_range(64, 0, 16)          # 4 planes per slab: not a multiple of the 8-row tile
 
 
-def _ghost_worker(rank, world, port, n, asset, outdir):
+def _ghost_worker(rank, world, port, n, asset, outdir, poison=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -110,7 +110,7 @@ def _ghost_worker(rank, world, port, n, asset, outdir):
         from slab_cpu_backend import CpuSlabBackend
         mesh = M.import_mesh(M.asset(asset))
         origin, vs = M.frame([mesh[0]], n)
-        pipe = GhostSlabPipeline(CpuSlabBackend(mesh), Frame.make(n, vs, origin), rank, world)
+        pipe = GhostSlabPipeline(CpuSlabBackend(mesh, poison=poison), Frame.make(n, vs, origin), rank, world)
         pipe.voxelize(None, None)
         sdf = pipe.jfa()
         dist.barrier()
@@ -132,16 +132,17 @@ def test_ghost_slab_pipeline_matches_single_domain_oracle(tmp_path, world, n, as
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
 
 
-@pytest.mark.parametrize("poison", ["0", "777", "-1"])
-def test_ghost_ignores_unproduced_planes(tmp_path, monkeypatch, poison):
+@pytest.mark.parametrize("poison", [0, 777, -1])
+def test_ghost_ignores_unproduced_planes(tmp_path, poison):
     """the ghost regions are rounded outwards to the 8-plane tile and the excess planes of a pass read planes the pass
-    before it never produced.  Whatever those planes hold -- voxel 0 as a seed, voxel 777, "none" -- the slabs must not change."""
+    before it never produced.  Whatever those planes hold -- voxel 0 as a seed, voxel 777, "none" -- the slabs must not change.
+    (The first two passes run over the whole grid, so the windows are fully written once; what the rounding planes of the LATER passes
+    read is then the output of an earlier pass on the same buffer or this fill.)"""
     sys.path.insert(0, ROOT)
     from cuda_mesh_voxelization_amd import mesh as M
     from oracle import oracle as O
-    monkeypatch.setenv("VP_SLAB_POISON", poison)
     world, n, asset = 4, 64, "torus.obj"
-    mp.spawn(_ghost_worker, args=(world, _free_port(), n, asset, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_ghost_worker, args=(world, _free_port(), n, asset, str(tmp_path), poison), nprocs=world, join=True)
     xyz, tri = M.import_mesh(M.asset(asset))
     origin, vs = M.frame([xyz], n)
     exp = O.jfa(O.voxelize(xyz, tri, n, vs, origin), n, vs, origin)

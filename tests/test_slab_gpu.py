@@ -1,7 +1,7 @@
 """Z-slab path on ONE GPU: world_size ranks are emulated by threads, the point-to-point exchange by an
 in-process loopback that implements the torch.distributed calls slab.py uses.  This drives the real
-HIP kernels with slab frames and halo buffers (vp_jfa_init / vp_jfa_pass addressing, slab voxelize),
-which the single-GPU tests never do.  Results must be bit-identical to the whole-grid run."""
+HIP kernels with slab frames and id windows (vp_jfa_window_*: halo planes next to the slab, whole slabs
+a slab height away for the steps that span them, slab voxelize), which the single-GPU tests never do.  Results must be bit-identical to the whole-grid run."""
 import queue
 import threading
 
@@ -49,20 +49,20 @@ class LoopbackDist:
         return reqs
 
 
-def _run_slabs(world, frame, xyz, tri, algo, kind="halo"):
+def _run_slabs(world, frame, xyz, tri, algo, kind="halo", poison=None):
     queues = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
     engines = [Engine(0) for _ in range(world)]
     pipes, errors = [], []
     for r in range(world):
         cls = SlabPipeline if kind == "halo" else HybridSlabPipeline
-        pipes.append(cls(HipSlabBackend(engines[r]), frame, r, world, LoopbackDist(r, queues)))
+        pipes.append(cls(HipSlabBackend(engines[r], poison=poison), frame, r, world, LoopbackDist(r, queues)))
     meshes = [engines[r].mesh_to_device(xyz, tri) for r in range(world)]
 
     def work(r):
         try:
             torch.cuda.set_device(0)
             pipes[r].voxelize(meshes[r][0], meshes[r][1], algo=algo)
-            pipes[r].jfa(algo=algo)
+            pipes[r].jfa()
             torch.cuda.synchronize()
         except Exception as e:          # surface in the main thread
             errors.append((r, repr(e)))
@@ -71,7 +71,7 @@ def _run_slabs(world, frame, xyz, tri, algo, kind="halo"):
     for t in threads:
         t.start()
     for t in threads:
-        t.join(300)
+        t.join(600)
     assert not errors, errors
     if kind == "hybrid":                                         # every rank holds the whole bitmask there
         pw = frame.n * frame.n // 32
@@ -82,10 +82,16 @@ def _run_slabs(world, frame, xyz, tri, algo, kind="halo"):
     return words, sdf
 
 
-@pytest.mark.parametrize("world,n,name,algo", [(2, 64, "bunny.obj", ALGO_TILED), (4, 64, "bunny.obj", ALGO_TILED),
-                                               (8, 64, "torus.obj", ALGO_TILED), (4, 32, "d20.obj", ALGO_NAIVE),
-                                               (2, 256, "bimba.obj", ALGO_TILED), (8, 256, "bunny.obj", ALGO_TILED)])
+@pytest.mark.parametrize("world,n,name,algo", [(2, 96, "bunny.obj", ALGO_TILED), (4, 128, "bunny.obj", ALGO_TILED),
+                                               (8, 128, "torus.obj", ALGO_TILED), (4, 96, "d20.obj", ALGO_NAIVE),
+                                               (2, 256, "bimba.obj", ALGO_TILED), (8, 256, "bunny.obj", ALGO_TILED),
+                                               (4, 288, "bimba.obj", ALGO_TILED), (4, 1152, "bimba.obj", ALGO_TILED), (8, 1280, "bunny.obj", ALGO_TILED)])
 def test_slabs_equal_whole_grid(engine, world, n, name, algo):
+    """SlabPipeline (point-to-point halos before every pass): narrow passes with their halo planes next to the slab, the steps that span
+    whole slabs (k >= nz) with the received slabs a slab height away (stride = nz).  n = 288 / 1152 / 1280: steps that are not powers of
+    two; above n = 1024 the windows are in the 5-byte layout (two byte ranges per halo piece)."""
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
     xyz, tri = M.import_mesh(M.asset(name))
     origin, vs = M.frame([xyz], n)
     fr = Frame.make(n, vs, origin)
@@ -98,11 +104,15 @@ def test_slabs_equal_whole_grid(engine, world, n, name, algo):
     assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
 
 
-@pytest.mark.parametrize("world,n,name,algo", [(2, 64, "bunny.obj", ALGO_TILED), (4, 64, "torus.obj", ALGO_NAIVE), (2, 256, "bimba.obj", ALGO_TILED),
-                                               (8, 256, "bunny.obj", ALGO_TILED), (4, 512, "bimba.obj", ALGO_TILED), (8, 512, "bunny.obj", ALGO_TILED)])
+@pytest.mark.parametrize("world,n,name,algo", [(2, 96, "bunny.obj", ALGO_TILED), (4, 96, "torus.obj", ALGO_NAIVE), (2, 256, "bimba.obj", ALGO_TILED),
+                                               (8, 256, "bunny.obj", ALGO_TILED), (4, 512, "bimba.obj", ALGO_TILED), (8, 512, "bunny.obj", ALGO_TILED),
+                                               (4, 1152, "bimba.obj", ALGO_TILED), (8, 1280, "bunny.obj", ALGO_TILED)])
 def test_hybrid_slabs_equal_whole_grid(engine, world, n, name, algo):
     """HybridSlabPipeline with the real kernels: ghost planes for the wide passes inside id buffers that hold only the planes the rank
-    touches (window addressing), sub-slab launches (boundary planes first) and halos sent a pass ahead for the narrow ones."""
+    touches (window addressing), sub-slab launches (boundary planes first) and halos sent a pass ahead for the narrow ones.  n = 1152 /
+    1280: the 5-byte window layout (init ids / the first pass from the mask written in it, halos as two byte ranges)."""
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
     xyz, tri = M.import_mesh(M.asset(name))
     origin, vs = M.frame([xyz], n)
     fr = Frame.make(n, vs, origin)
@@ -115,14 +125,10 @@ def test_hybrid_slabs_equal_whole_grid(engine, world, n, name, algo):
     assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
 
 
-@pytest.mark.parametrize("world,n,name,fused_pct", [(2, 64, "bunny.obj", None), (4, 64, "torus.obj", None), (8, 256, "bunny.obj", None),
-                                                    (4, 512, "bimba.obj", None), (4, 512, "bimba.obj", "101")])
-def test_ghost_slabs_equal_whole_grid(engine, world, n, name, fused_pct, monkeypatch):
-    """Communication-free variant: every emulated rank recomputes its ghost planes; no exchange at all.  The first two passes run as
-    the one whole-grid launch (slab.fused_first_two_threshold) or, forced, as the two region passes."""
+@pytest.mark.parametrize("world,n,name", [(2, 96, "bunny.obj"), (4, 128, "torus.obj"), (8, 256, "bunny.obj"), (4, 512, "bimba.obj")])
+def test_ghost_slabs_equal_whole_grid(engine, world, n, name):
+    """Communication-free variant: every emulated rank recomputes its ghost planes; no exchange at all."""
     from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
-    if fused_pct:
-        monkeypatch.setenv("VP_FUSED_FIRST_TWO_PCT", fused_pct)
     xyz, tri = M.import_mesh(M.asset(name))
     origin, vs = M.frame([xyz], n)
     fr = Frame.make(n, vs, origin)
@@ -139,16 +145,15 @@ def test_ghost_slabs_equal_whole_grid(engine, world, n, name, fused_pct, monkeyp
     assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
 
 
-@pytest.mark.parametrize("world,n,volume", [(4, 1152, "1"), (4, 1152, "0"), (8, 512, "1"), (8, 512, "0"), (2, 1280, "1")])
-def test_ghost_volume_calls_equal_whole_grid(engine, world, n, volume, monkeypatch):
-    """vp_jfa_volume_* (round 4): the ghost pipeline hands the library whole id volumes + a region frame instead of plane pointers it
-    offsets itself, so the library picks the layout -- plain 4-byte ids up to n = 1024, the compact word plane + byte plane above (here
+@pytest.mark.parametrize("world,n,poison", [(4, 1152, None), (8, 512, 0xA5), (2, 1280, 0xFF), (4, 1152, 0x5A)])
+def test_ghost_windows_equal_whole_grid(engine, world, n, poison):
+    """The ghost pipeline on id windows of the whole grid: plain 4-byte ids up to n = 1024, the word plane + byte plane above (here
     n = 1152 / 1280: regions that are not multiples of 8 k planes, chains of 9 / 10, 4-plane and 8-plane tiles with halo planes taken from
-    the middle of a compact volume).  Every rank's slab must equal the whole-grid run, with the volume calls (default) and with the
-    caller-addressed 8-byte planes (VP_GHOST_VOLUME=0); the volumes are 5 / 8 of the size above n = 1024."""
+    the middle of a window).  Every rank's slab must equal the whole-grid run; the windows are 5 / 8 of two 8-byte volumes above n = 1024.
+    `poison`: the word planes of the fresh windows are overwritten with an arbitrary byte -- the planes a pass reads without needing them
+    (regions rounded outwards to whole tiles) must not matter (the test now also runs above n = 1024)."""
     import gc
     from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
-    monkeypatch.setenv("VP_GHOST_VOLUME", volume)
     gc.collect(); torch.cuda.empty_cache()
     xyz, tri = M.import_mesh(M.asset("bimba.obj"))
     origin, vs = M.frame([xyz], n)
@@ -158,18 +163,39 @@ def test_ghost_volume_calls_equal_whole_grid(engine, world, n, volume, monkeypat
     ref_s = engine.jfa(fr, ref_w)
     nzv = fr.voxels // world
     for r in range(world):
-        pipe = GhostSlabPipeline(HipSlabBackend(engine), fr, r, world)
-        rep = pipe.report()
-        assert rep["volume_calls"] == (volume == "1")
-        assert rep["id_volume_bytes"] == fr.voxels * ((5 if n > 1024 else 4) if volume == "1" else (8 if n > 1024 else 4))
+        pipe = GhostSlabPipeline(HipSlabBackend(engine, poison=poison), fr, r, world)
+        assert pipe.report()["id_window_bytes"] == fr.voxels * (5 if n > 1024 else 4)
         pipe.voxelize(dx, dt)
         s = pipe.jfa()
-        assert torch.equal(s.view(torch.int32), ref_s[r * nzv:(r + 1) * nzv].view(torch.int32)), (r, volume)
+        assert torch.equal(s.view(torch.int32), ref_s[r * nzv:(r + 1) * nzv].view(torch.int32)), (r, poison)
         del pipe, s
         gc.collect(); torch.cuda.empty_cache()
     del ref_s, ref_w
     engine._work = None
     gc.collect(); torch.cuda.empty_cache()
+
+
+def test_pipelines_refuse_grids_below_the_tile_kernels(engine):
+    from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
+    fr = Frame.make(64, 0.1, (0.0, 0.0, 0.0))
+    with pytest.raises(ValueError, match="n >= 96"):
+        GhostSlabPipeline(HipSlabBackend(engine), fr, 0, 2)
+
+
+def test_halo_bytes_on_the_wire_above_n1024(engine):
+    """What the halo / hybrid pipelines move and hold at n = 2048 x 8 (where the state no longer fits one GPU in 8-byte ids), from the byte
+    ranges the exchange really posts (vp_jfa_window_span) and the window sizes the library reports -- without allocating 40-GiB windows:
+    5 bytes per voxel on the wire instead of the 8 of round 4 (-37.5 %), and 35 GiB per hybrid window (was 56)."""
+    from cuda_mesh_voxelization_amd.slab import hybrid_plan
+    n, world = 2048, 8
+    fr = Frame.make(n, 0.01, (0.0, 0.0, 0.0))
+    nz = n // world
+    spans = engine.ctx.jfa_window_span(fr, 3 * nz, nz - 16, nz)              # 16 halo planes below the slab of a halo-pipeline window
+    assert [nb for _, nb in spans] == [16 * n * n * 4, 16 * n * n] and sum(nb for _, nb in spans) * 8 == 16 * n * n * 8 * 5
+    assert spans[0][0] == (nz - 16) * n * n * 4 and spans[1][0] == 3 * nz * n * n * 4 + (nz - 16) * n * n
+    wide, narrow = hybrid_plan(n, 3, world)
+    planes = max(b1 + k for k, b0, b1 in wide[1:]) - min(b0 - k for k, b0, b1 in wide[1:])
+    assert planes == 1792 and engine.ctx.jfa_window_bytes(fr, planes) == planes * n * n * 5 <= 35 * 2**30
 
 
 def test_config4_n1024_four_slabs(engine):
@@ -206,7 +232,7 @@ def test_config4_n1024_four_slabs(engine):
 
 
 def test_config5_n2048_eight_ghost_slabs(engine):
-    """BASELINE config 5 at its stated shape: the 10,785,024-face mesh, n = 2048 (64-bit ids), eight Z-slabs, ghost-plane
+    """BASELINE config 5 at its stated shape: the 10,785,024-face mesh, n = 2048 (5-byte id windows), eight Z-slabs, ghost-plane
     pipeline: every emulated rank's slab bit-identical to the single-GPU result (itself checked against the oracle's
     recorded run in test_gpu_parity.py)."""
     import gc

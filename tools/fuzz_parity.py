@@ -10,7 +10,7 @@ Prints one line per case; exits non-zero on the first mismatch with the seed tha
 import argparse, math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, Frame
+from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, Frame, Window
 from cuda_mesh_voxelization_amd.pipeline import Engine
 from oracle import oracle as O
 
@@ -78,11 +78,11 @@ def check_ids(fr, g, n):
         eng.ctx.jfa_pass(fr, k, cur.data_ptr(), None, None, y.data_ptr(), ALGO_NAIVE)
         eng.sync()
         if not torch.equal(x, y): return "pass k=%d: %d ids differ" % (k, int((x != y).sum().item()))
-        for first, can, fn in ((n // 2, eng.ctx.jfa_can_start_from_mask, eng.ctx.jfa_first_pass), (n // 4, eng.ctx.jfa_can_fuse_first_two, eng.ctx.jfa_first_two)):
-            if k == first and can(fr, ALGO_TILED):
+        for first, can, fn in ((n // 2, eng.ctx.jfa_can_start_from_mask, eng.ctx.jfa_window_first_pass), (n // 4, eng.ctx.jfa_can_fuse_first_two, eng.ctx.jfa_window_first_two)):
+            if k == first and idb == 4 and can(fr, ALGO_TILED):                  # (a window of 4-byte ids IS an array of plain ids)
                 border = torch.empty(fr.words, dtype=torch.int32, device=eng.device)
                 eng.ctx.surface(fr, g.data_ptr(), None, None, border.data_ptr())
-                fn(fr, border.data_ptr(), x.data_ptr()); eng.sync()
+                fn(fr, border.data_ptr(), Window.make(x.data_ptr(), n, 0)); eng.sync()
                 if not torch.equal(x, y): return "from-the-mask form at k=%d: %d ids differ" % (k, int((x != y).sum().item()))
         cur, x = x, cur
         k //= 2

@@ -1,6 +1,6 @@
 """Dev tool (GPU box): randomized campaign for the Python Z-slab pipelines (slab.py: what `bench.py --gpus N` runs): random mesh (asset
-under a random similarity, or a triangle soup), grid side, rank count and pipeline (ghost planes with / without the whole-volume calls,
-RCCL-halo and hybrid with ranks emulated by threads over the loopback of tests/test_slab_gpu.py); every rank's slab of the bitmask and of
+under a random similarity, or a triangle soup), grid side, rank count and pipeline (ghost planes; RCCL-halo and hybrid
+with ranks emulated by threads over the loopback of tests/test_slab_gpu.py), all on id windows, now and then above n = 1024 (5-byte layout); every rank's slab of the bitmask and of
 the sdf against the whole-grid run, bit for bit.
   python tools/fuzz_pipelines.py [--seconds 600] [--seed0 20000]"""
 import argparse, gc, os, sys, time
@@ -21,10 +21,10 @@ assets = [M.import_mesh(M.asset(nm)) for nm in ("bunny.obj", "bimba.obj", "torus
 t_end, seed, done = time.time() + a.seconds, a.seed0, 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
-    n = int(rng.choice([64, 128, 192, 256, 384, 512]))
+    n = int(rng.choice([96, 128, 192, 256, 288, 384, 512, 1152] if rng.random() < 0.9 else [1152, 1280]))
     world = int(rng.choice([g for g in (2, 3, 4, 6, 8) if n % g == 0 and (n // g) % 8 == 0]))
-    kind = str(rng.choice(["ghost", "ghost-planes", "halo", "hybrid"]))
-    algo = ALGO_TILED if (kind.startswith("ghost") or rng.random() < 0.8) else ALGO_NAIVE
+    kind = str(rng.choice(["ghost", "halo", "hybrid"]))
+    algo = ALGO_TILED if (n > 512 or rng.random() < 0.8) else ALGO_NAIVE          # the voxelizer's and the reference run's algorithm
     if rng.random() < 0.6:                                        # an asset, rotated about z by a multiple of 90 degrees, scaled, moved
         xyz, tri = assets[int(rng.integers(len(assets)))]
         q = int(rng.integers(4)); c, s = [(1, 0), (0, 1), (-1, 0), (0, -1)][q]
@@ -44,7 +44,6 @@ while time.time() < t_end:
     ref_s = eng.jfa(fr, ref_w, algo=algo).clone()
     ok = True
     if kind.startswith("ghost"):
-        os.environ["VP_GHOST_VOLUME"] = "1" if kind == "ghost" else "0"
         nzv, pw = fr.voxels // world, n * n // 32
         for r in range(world):
             pipe = GhostSlabPipeline(HipSlabBackend(eng), fr, r, world)

@@ -30,7 +30,7 @@ for algo in [int(x) for x in a.algos.split(",")]:
     out = torch.empty_like(cur)
     tot = 0.0
     for k, st in states:
-        none = -1 if idw == 2 else (0xFF9FF200 if n <= 512 else 0xFFDFFC00) - (1 << 32)   # jfa.hip: Id64 / IdU<9> / IdU<10> as int32
+        none = -1 if idw == 2 else (0xFF9FF200 if n <= 512 else 0xFFDFFC00) - (1 << 32)   # jfa_common.h: Id64 / IdU<9> / IdU<10> as int32
         seeds = int((st[::idw] != none).sum().item())
         ctx.prof_reset(); ctx.prof_enable(True)
         for _ in range(a.reps):

@@ -19,13 +19,13 @@ import torch
 from cuda_mesh_voxelization_amd import mesh as M
 from cuda_mesh_voxelization_amd.capi import ALGO_TILED, Frame
 from cuda_mesh_voxelization_amd.pipeline import Engine
-from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline, HipSlabBackend, HybridSlabPipeline, halo_plan, ghost_regions, hybrid_plan
+from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline, HipSlabBackend, HybridSlabPipeline, SlabPipeline, halo_plan, ghost_regions, hybrid_plan
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 refine = 24 if n <= 1024 else 192
 xyz, tri = M.bunny(refine); origin, vs = M.frame([xyz], n); fr = Frame.make(n, vs, origin)
 eng = Engine(0); dx, dt = eng.mesh_to_device(xyz, tri)
-S = eng.ctx.jfa_id_bytes(fr); passes = int(math.log2(n))
+S = eng.ctx.jfa_state_bytes(fr, ALGO_TILED); passes = int(math.log2(n))
 reps = 10 if n <= 512 else 3
 
 def timeit(fn, reps):
@@ -73,6 +73,17 @@ class NullDist:
     class P2POp:
         def __init__(self, op, tensor, peer): pass
     def batch_isend_irecv(self, ops): return []
+
+print("\nhalo pipeline, compute only (every rank measured on this GPU with the real kernels on its [slab - k | slab | slab + k] windows, transfers left out)")
+print("  G   slowest rank ms   speedup if transfers were free   per-rank ms")
+for world in (2, 4, 8):
+    ts = []
+    for r in range(world):
+        pipe = SlabPipeline(HipSlabBackend(eng), fr, r, world, NullDist())
+        def step(): pipe.voxelize(dx, dt); pipe.jfa()
+        ts.append(timeit(step, max(2, reps // 2)))
+        del pipe; torch.cuda.empty_cache()
+    print("  %d   %8.3f          %5.2fx                            %s" % (world, max(ts), t1 / max(ts), " ".join("%.2f" % t for t in ts)))
 
 print("\nhybrid, compute only (every rank measured on this GPU with the real kernels and sub-slab launches, transfers left out)")
 print("  G   slowest rank ms   speedup if transfers were free   per-rank ms")

@@ -1,6 +1,6 @@
 // Dev probe (round 4): the FLOOR of the exact 27-candidate scatter formulation of a JFA pass on gfx950.
 //
-// The tile kernel (csrc/jfa.hip: jfa_pass_dense) evaluates, per voxel and pass, 27 candidates in float32 with a (distance, rank)
+// The tile kernel (csrc/jfa_dense.hip: jfa_pass_dense) evaluates, per voxel and pass, 27 candidates in float32 with a (distance, rank)
 // minimum each (v_add_f32 into the high half of a pair + v_min_f64), after decoding the ids they come from.  This probe keeps
 // nothing but that irreducible work and the stream it needs:
 //
