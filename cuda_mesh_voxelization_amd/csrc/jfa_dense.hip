@@ -75,12 +75,6 @@ __device__ __forceinline__ float from_partner(float v)
 // Occupancy the register allocation aims at: six waves per SIMD where the LDS footprint allows six workgroups (2-KB tables) or three
 // 512-thread ones (4-KB tables); four for 8-row tiles, the 8-KB tables of the compact ids (six would leave 80 VGPRs: the id passes spill
 // 50 registers, 34.0 -> 46.2 ms) and the 256-thread variant with 4-KB tables (LDS-limited).
-#ifndef VP_EXP_IDC_RY8
-#define VP_EXP_IDC_RY8 0
-#endif
-#ifndef VP_EXP_IDC_CLOSED
-#define VP_EXP_IDC_CLOSED 0
-#endif
 template <class ID, int RY, int NT, bool FINAL>
 constexpr int dense_waves()
 {
@@ -497,12 +491,8 @@ jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, co
                             const uint32_t r = lo < 4u ? (uint32_t)((P * NR + a + HY + 1) << 14) + xo : lo - 1u - zt;
                             const ptrdiff_t row = (ptrdiff_t)(int)RB[(r >> 14) - 1u];
                             const uint32_t none1 = __builtin_bit_cast(u32x2, best[a][P - 1]).y == 0x7F800000u ? IdC::kNoneBit : 0u;
-#ifdef VP_EXP_NOGATHER
-                            pend[a] = make_uint2((uint32_t)row + (r & 16383u), zt | none1);
-#else
                             pend[a] = make_uint2(*reinterpret_cast<const uint32_t*>(in + row * (ptrdiff_t)rowBytes + (ptrdiff_t)(r & 16383u)),
                                                  zt | none1);
-#endif
                         } else {
                             const uint32_t ownOff = orank + ro[a + HY] + xo;
                             const uint32_t off = lo ? lo - 1u : ownOff;
@@ -563,7 +553,7 @@ void launch_tile(const DenseArgs& a)
 {
     const uint32_t ty = a.nresY * ((a.ylen + RY - 1) / RY), t = ty * a.nres * ((a.zlen + CH - 1) / CH);
     // workgroups a CU holds (what dense_waves and the LDS footprint allow): the unit of the tail split
-    constexpr uint32_t perCu = std::is_same<ID, IdC>::value ? (RY == 8 ? 1u : 2u)
+    constexpr uint32_t perCu = std::is_same<ID, IdC>::value ? 2u
                              : ID::kTab == 512 ? (RY == 8 ? 4u : (F && !final_mask_global<ID>()) ? 5u : 6u)
                              : NT == 512 ? (RY == 8 ? 2u : 3u) : 4u;
     const uint32_t sp = a.f.n > (uint32_t)NT ? tail_split(a.ctx, t, perCu) : 0u;     // a row of <= NT voxels has no halves
@@ -583,7 +573,7 @@ template <int V> using int_c = std::integral_constant<int, V>;
 template <class ID, int CH, int NT, bool F>
 void launch_shape(const DenseArgs& a, bool pairsOk, bool wholeChains)
 {
-    constexpr int RY = ((ID::kTab == 512 || (VP_EXP_IDC_RY8 && ID::kTab == 2048)) && !F && CH == 8) ? 8 : 4;
+    constexpr int RY = (ID::kTab == 512 && !F && CH == 8) ? 8 : 4;
     constexpr bool canFull = CH == 8 && (ID::kTab != 1024 || F);
     auto go = [&](auto pm) {
         constexpr int PM = decltype(pm)::value;
@@ -637,9 +627,11 @@ int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const
     const bool wholeChains = zlen % 8 == 0 && nz % k == 0 && n % k == 0;
     // threads per workgroup: 256 with the 2-KB tables (26 KB of LDS, six workgroups per CU); with the 4-KB tables the 4 x 8 tile takes 52 KB,
     // shared by the 8 waves of a 512-thread workgroup (three per CU), as do the 8-KB tables of the compact ids (two per CU)
-    constexpr int NTD = ID::kTab == 512 ? 256 : (VP_EXP_IDC_RY8 && ID::kTab == 2048) ? 1024 : 512;               // 8-plane tiles
+    constexpr int NTD = ID::kTab == 512 ? 256 : 512;               // 8-plane tiles
     constexpr int NTS = ID::kTab == 2048 ? 512 : 256;              // 4- and 2-plane tiles
-    // closed 8 x 8 tiles at k = n/8 (see jfa_pass_dense): whole power-of-two grids on 32-bit ids
+    // closed 8 x 8 tiles at k = n/8 (see jfa_pass_dense): whole power-of-two grids on 32-bit ids.  (Compact ids, n = 2048: the closed tile's
+    // 86 KB of tables need 1024 threads -- 128 VGPRs + 25 spilled -- and buy 5 % of that one pass; 8-row tiles for every pass cost 20 .. 38 %:
+    // profiles/r05/ab_idc_tiles_2048.txt.)
     if constexpr (!std::is_same<ID, IdC>::value) {
         if (pow2 && !fin && stride == k && f.z0 == 0 && f.z1 == n && n == 8u * k && n % NTD == 0) {
             launch_tile<ID, 8, 8, NTD, false, 8, 3, ID::kTab == 512>(a);
@@ -651,16 +643,7 @@ int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const
     // (the remainders of the split above, and the slabs of a pass whose step spans whole slabs): 2-plane tiles
     const bool deep = zlen % 8 == 0 || (zlen > 4 && zlen < 8);
     const bool tiny = !fin && zlen <= 2;
-#if VP_EXP_IDC_CLOSED
-    if constexpr (std::is_same<ID, IdC>::value) {
-        if (pow2 && !fin && stride == k && f.z0 == 0 && f.z1 == n && n == 8u * k && n % 1024 == 0) {
-            launch_tile<ID, 8, 8, 1024, false, 8, 3, true>(a);
-            VP_HIP(hipGetLastError());
-            return 0;
-        }
-    }
-#endif
-    if (deep) { if (fin) launch_shape<ID, 8, (ID::kTab == 2048 ? 512 : NTD), true>(a, pow2, wholeChains); else launch_shape<ID, 8, NTD, false>(a, pow2 && k >= 2, wholeChains); }
+    if (deep) { if (fin) launch_shape<ID, 8, NTD, true>(a, pow2, wholeChains); else launch_shape<ID, 8, NTD, false>(a, pow2 && k >= 2, wholeChains); }
     else if (tiny) launch_shape<ID, 2, NTS, false>(a, false, false);
     else { if (fin) launch_shape<ID, 4, NTS, true>(a, false, false); else launch_shape<ID, 4, NTS, false>(a, false, false); }
     VP_HIP(hipGetLastError());

@@ -16,6 +16,7 @@ dev = torch.device("cuda", 0)
 dx = torch.from_numpy(xyz.copy()).to(dev); dt = torch.from_numpy(tri.astype("int32")).to(dev)
 g = torch.zeros(fr.words, dtype=torch.int32, device=dev); sdf = torch.empty(fr.voxels, dtype=torch.float32, device=dev)
 libs = []
+work = None                                                   # ONE workspace for every build (n = 2048: 129 GiB each otherwise)
 for p in a.libs.split(","):
     L = ctypes.CDLL(os.path.abspath(p)); ctx = _vp()
     L.vp_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]; L.vp_ctx_create(0, ctypes.byref(ctx))
@@ -24,6 +25,9 @@ for p in a.libs.split(","):
     L.vp_prof_get.argtypes = [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     L.vp_prof_name.restype = ctypes.c_char_p; L.vp_prof_name.argtypes = [ctypes.c_int]
     L.vp_prof_enable.argtypes = [_vp, ctypes.c_int]; L.vp_prof_reset.argtypes = [_vp]; L.vp_ctx_sync.argtypes = [_vp]
+    if work is None:
+        L.vp_jfa_workspace_bytes.restype = _sz; L.vp_jfa_workspace_bytes.argtypes = [fp]
+        work = torch.empty(L.vp_jfa_workspace_bytes(fr), dtype=torch.uint8, device=dev)
     libs.append((os.path.basename(p).replace("libvphip_", "").replace(".so", ""), L, ctx))
 res = {nm: {} for nm, _, _ in libs}
 chk = {}
@@ -33,7 +37,7 @@ for r in range(a.rounds + 1):
         L.vp_prof_reset(ctx); L.vp_prof_enable(ctx, 1)
         for _ in range(2):
             L.vp_voxelize(ctx, fr, g.data_ptr(), dx.data_ptr(), dx.shape[0], dt.data_ptr(), dt.shape[0], 2, 0)
-            L.vp_jfa(ctx, fr, g.data_ptr(), -math.inf, sdf.data_ptr(), None, 0, 2)
+            L.vp_jfa(ctx, fr, g.data_ptr(), -math.inf, sdf.data_ptr(), work.data_ptr(), work.numel(), 2)
         L.vp_prof_enable(ctx, 0)
         if r == 0:
             L.vp_ctx_sync(ctx); chk[nm] = sum(int(c.to(torch.int64).sum().item()) for c in sdf.view(torch.int32).split(1 << 28)); continue   # in chunks: 8.6 G voxels at n = 2048
