@@ -60,6 +60,7 @@ struct Options {
     unsigned gpus = 1;
     std::string multi = "ghost";
     bool verify = false;
+    bool surfaceOnly = false;
     bool help = false;
 };
 
@@ -82,6 +83,8 @@ const char* kUsage =
     "      --multi arg       JFA on several devices: ghost = recomputed ghost planes, no exchange between passes (default);\n"
     "                        halo = halo planes copied device to device before every pass; hybrid = ghost planes for the\n"
     "                        wide passes (k > slab/2), halos for the others, id volumes cut to the planes a device touches\n"
+    "      --surface-only    With -e: the grid meshes hold only the faces between a set voxel and an unset / outside neighbour\n"
+    "                        (default: the reference's mesh -- every face of every set voxel once, interior faces included)\n"
     "      --verify          With -g > 1: run the job again on device 0 alone, compare grid and sdf bit for bit, print\n"
     "                        '# multi-gpu' lines (parity, bytes moved between devices); exit code 3 on a mismatch (extension)\n"
     "  -h, --help            Print usage\n";
@@ -91,7 +94,7 @@ Options Parse(int argc, char** argv)
 {
     static const std::map<std::string, char> longNames = {
         {"filenames", 'i'}, {"num-voxels", 'n'}, {"type", 't'}, {"output", 'o'}, {"operation", 'p'}, {"export", 'e'},
-        {"sdf", 's'}, {"block-size", 'b'}, {"benckmark", 'm'}, {"benchmark", 'm'}, {"dump", 'd'}, {"gpus", 'g'}, {"multi", 'M'}, {"verify", 'V'}, {"help", 'h'}};
+        {"sdf", 's'}, {"block-size", 'b'}, {"benckmark", 'm'}, {"benchmark", 'm'}, {"dump", 'd'}, {"gpus", 'g'}, {"multi", 'M'}, {"verify", 'V'}, {"surface-only", 'S'}, {"help", 'h'}};
     Options o;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -112,10 +115,10 @@ Options Parse(int argc, char** argv)
             o.filenames.push_back(a);
             continue;
         }
-        const bool isSwitch = key == 'e' || key == 's' || key == 'h' || key == 'V';
+        const bool isSwitch = key == 'e' || key == 's' || key == 'h' || key == 'V' || key == 'S';
         if (isSwitch) {
             const bool v = !hasValue || value == "true" || value == "1";
-            if (key == 'e') o.doExport = v; else if (key == 's') o.sdf = v; else if (key == 'V') o.verify = v; else o.help = v;
+            if (key == 'e') o.doExport = v; else if (key == 's') o.sdf = v; else if (key == 'V') o.verify = v; else if (key == 'S') o.surfaceOnly = v; else o.help = v;
             continue;
         }
         if (!hasValue) {
@@ -166,6 +169,15 @@ void WriteRaw(const std::string& path, const void* data, size_t bytes)
 }
 
 }  // namespace
+
+// -e: the mesh of a grid (main.cpp:118-124,192-197): the reference's compressed mesh, or (--surface-only) the visible surface alone; the GPU
+// types leave the walk over the grid to vp_extract
+template <typename View>
+static void GridMesh(bool gpu, bool surfaceOnly, const View& grid, Mesh& out)
+{
+    if (surfaceOnly) { if (gpu) VoxelsGridToSurfaceMeshDevice(grid, out); else VoxelsGridToSurfaceMesh(grid, out); }
+    else             { if (gpu) VoxelsGridToMeshCompressedDevice(grid, out); else VoxelsGridToMeshCompressed(grid, out); }
+}
 
 int main(int argc, char** argv)
 {
@@ -233,7 +245,7 @@ int main(int argc, char** argv)
             }
             if (EXPORT) {                                                                               // main.cpp:118-124
                 Mesh outMesh;
-                if (GPU) VoxelsGridToMeshCompressedDevice(grid.View(), outMesh); else VoxelsGridToMeshCompressed(grid.View(), outMesh);
+                GridMesh(GPU, opt.surfaceOnly, grid.View(), outMesh);
                 cpuAssert(ExportMesh("out/" + typeName + "_" + GetFilename(opt.filenames[i]), outMesh),
                           "Error in " + typeName + " " + opt.filenames[i] + " export");
             }
@@ -251,7 +263,7 @@ int main(int argc, char** argv)
 
         if (EXPORT && OPERATION != CSG::Op::VOID) {                                                     // main.cpp:192-197
             Mesh outMesh;
-            if (GPU) VoxelsGridToMeshCompressedDevice(grids[0].View(), outMesh); else VoxelsGridToMeshCompressed(grids[0].View(), outMesh);
+            GridMesh(GPU, opt.surfaceOnly, grids[0].View(), outMesh);
             cpuAssert(ExportMesh("out/csg_vox_" + typeName + "_" + opt.output, outMesh), "Error in " + opt.output + " export (csg)");
         }
 

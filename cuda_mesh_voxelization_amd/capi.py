@@ -13,7 +13,7 @@ HOOKS_LIB_PATH = os.path.join(PKG, "libvphip_hooks.so")
 
 ALGO_NAIVE, ALGO_TILED = 1, 2
 OP_VOID, OP_UNION, OP_INTERSECTION, OP_DIFFERENCE = 0, 1, 2, 3
-EXTRACT_SET, EXTRACT_EXPOSED = 0, 1
+EXTRACT_SET, EXTRACT_EXPOSED, EXTRACT_FACES = 0, 1, 2
 MULTI_HALO, MULTI_GHOST, MULTI_HYBRID = 0, 1, 2
 
 KERNELS = ["vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",

@@ -637,7 +637,7 @@ int vp_extract_count(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, in
     if (!ctx || !d_words) return set_error(VP_ERR_INVALID, "vp_extract_count: null argument");
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_extract_count", true));
-    if (mode != VP_EXTRACT_SET && mode != VP_EXTRACT_EXPOSED) return set_error(VP_ERR_INVALID, "vp_extract_count: mode %d", mode);
+    if (mode < VP_EXTRACT_SET || mode > VP_EXTRACT_FACES) return set_error(VP_ERR_INVALID, "vp_extract_count: mode %d", mode);
     return launch_extract_count(ctx, make_frame(f), d_words, mode, h_count);
 }
 
@@ -648,7 +648,7 @@ int vp_extract(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode
     if ((d_values != nullptr) != (d_sdf != nullptr)) return set_error(VP_ERR_INVALID, "vp_extract: d_sdf and d_values go together");
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_extract", true));
-    if (mode != VP_EXTRACT_SET && mode != VP_EXTRACT_EXPOSED) return set_error(VP_ERR_INVALID, "vp_extract: mode %d", mode);
+    if (mode < VP_EXTRACT_SET || mode > VP_EXTRACT_FACES) return set_error(VP_ERR_INVALID, "vp_extract: mode %d", mode);
     return launch_extract_write(ctx, make_frame(f), d_words, mode, d_sdf, d_records, d_values, capacity);
 }
 

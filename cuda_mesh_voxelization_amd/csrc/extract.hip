@@ -5,7 +5,9 @@
 //   mode VP_EXTRACT_SET      every set voxel                                   (point cloud / sdf cubes, :133-201)
 //   mode VP_EXTRACT_EXPOSED  set voxels with at least one face towards an unset voxel or the outside of the grid,
 //                            with the 6-bit mask of those faces: bit = axis * 2 + side, axes X, Y, Z, side 0 = minus
-//                            (visible-surface mesh, :10-131)
+//                            (visible-surface mesh)
+//   mode VP_EXTRACT_FACES    every set voxel WITH that mask: what VoxelsGridToMeshCompressed needs (:10-131 emits every face of every set
+//                            voxel once: the three "front" faces always, a "back" face iff the voxel behind it is unset -- bit side 0)
 // Record = linear voxel index (x + n (y + n z), bits 0..39) | face mask << 40.  Records come out in ascending index
 // order = the exporter's z, y, x scan order, so the host builds byte-identical files from them.
 //
@@ -32,6 +34,7 @@ template <int MODE>
 __device__ __forceinline__ uint32_t select(const Frame& f, const uint32_t* __restrict__ words, size_t wi, uint32_t (&face)[6])
 {
     const uint32_t c = words[wi];
+    for (int q = 0; q < 6; ++q) face[q] = 0u;
     if (MODE == VP_EXTRACT_SET || c == 0u) return c;
     const int xw = (int)(wi % f.w);
     const size_t row = wi / f.w;
@@ -41,7 +44,7 @@ __device__ __forceinline__ uint32_t select(const Frame& f, const uint32_t* __res
     face[0] = c & ~xm; face[1] = c & ~xp;
     face[2] = c & ~word_at(f, words, xw, y - 1, z); face[3] = c & ~word_at(f, words, xw, y + 1, z);
     face[4] = c & ~word_at(f, words, xw, y, z - 1); face[5] = c & ~word_at(f, words, xw, y, z + 1);
-    return face[0] | face[1] | face[2] | face[3] | face[4] | face[5];
+    return MODE == VP_EXTRACT_FACES ? c : (face[0] | face[1] | face[2] | face[3] | face[4] | face[5]);
 }
 
 template <int MODE>
@@ -116,7 +119,7 @@ extract_write(Frame f, const uint32_t* __restrict__ words, size_t nwords, const 
             m &= m - 1;
             const unsigned long long idx = (unsigned long long)(w0 + j) * 32ull + (unsigned)b;
             unsigned long long rec = idx;
-            if (MODE == VP_EXTRACT_EXPOSED) {
+            if (MODE != VP_EXTRACT_SET) {
                 unsigned fm = 0;
                 for (int q = 0; q < 6; ++q) fm |= ((face[j][q] >> b) & 1u) << q;
                 rec |= (unsigned long long)fm << 40;
@@ -143,8 +146,8 @@ int launch_extract_count(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, i
     unsigned long long* off = (unsigned long long*)ctx->ext_off.ptr;
     {
         ProfScope p(ctx, VP_K_EXTRACT);
-        if (mode == VP_EXTRACT_SET) hipLaunchKernelGGL(extract_count<VP_EXTRACT_SET>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, f, d_words, nwords, cnt);
-        else                        hipLaunchKernelGGL(extract_count<VP_EXTRACT_EXPOSED>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, f, d_words, nwords, cnt);
+        if (mode == VP_EXTRACT_EXPOSED) hipLaunchKernelGGL(extract_count<VP_EXTRACT_EXPOSED>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, f, d_words, nwords, cnt);
+        else                            hipLaunchKernelGGL(extract_count<VP_EXTRACT_SET>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, f, d_words, nwords, cnt);   // SET and FACES: every set voxel
         hipLaunchKernelGGL(extract_scan, dim3(1), dim3(1024), 0, ctx->stream, cnt, blocks, off);
     }
     VP_HIP(hipGetLastError());
@@ -167,6 +170,9 @@ int launch_extract_write(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, i
     ProfScope p(ctx, VP_K_EXTRACT);
     if (mode == VP_EXTRACT_SET)
         hipLaunchKernelGGL(extract_write<VP_EXTRACT_SET>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, f, d_words, nwords, off, d_sdf,
+                           (unsigned long long*)d_records, d_values, capacity);
+    else if (mode == VP_EXTRACT_FACES)
+        hipLaunchKernelGGL(extract_write<VP_EXTRACT_FACES>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, f, d_words, nwords, off, d_sdf,
                            (unsigned long long*)d_records, d_values, capacity);
     else
         hipLaunchKernelGGL(extract_write<VP_EXTRACT_EXPOSED>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, f, d_words, nwords, off, d_sdf,

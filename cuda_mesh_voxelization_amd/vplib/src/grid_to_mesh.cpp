@@ -1,5 +1,6 @@
-// grid_to_mesh.cpp -- see grid_to_mesh.h.  Visual exports only; no parity contract beyond the OBJ conventions
-// of the reference (six axis normals in the order +Z,+Y,+X,-Z,-Y,-X, grid_to_mesh.cpp:25-31; colours per vertex).
+// grid_to_mesh.cpp -- see grid_to_mesh.h.  VoxelsGridToMeshCompressed emits the reference's mesh (grid_to_mesh.h:25-92,
+// grid_to_mesh.cpp:10-60: face set, vertex order, winding, normal indices; pinned face by face by tests/test_export.py);
+// the cube and point-cloud exports follow its OBJ conventions (six axis normals in the order +Z,+Y,+X,-Z,-Y,-X, :25-31; colours per vertex).
 //
 // Every exporter is written against a stream of voxel RECORDS (linear index + exposed-face mask) in z, y, x order.
 // The host variants produce the records by walking the grid (what the reference does, grid_to_mesh.cpp:10-201); the
@@ -26,11 +27,12 @@ float Diagonal(float side) { return std::sqrt(side * side * 3.0f); }
 
 constexpr uint64_t kIndexMask = (1ull << 40) - 1;
 
-// host record generator: set voxels (exposedOnly = false) or set voxels with a face towards unset / outside, + face mask
-// (bit = axis * 2 + side; X, Y, Z; side 0 = minus) -- the same records vp_extract produces
+// host record generator, the same records vp_extract produces: mode VP_EXTRACT_SET = set voxels; VP_EXTRACT_EXPOSED = set voxels with a
+// face towards unset / outside, + face mask (bit = axis * 2 + side; X, Y, Z; side 0 = minus); VP_EXTRACT_FACES = every set voxel + that mask
 template <VGType T>
-std::vector<uint64_t> HostRecords(const VoxelsGrid<T>& grid, bool exposedOnly)
+std::vector<uint64_t> HostRecords(const VoxelsGrid<T>& grid, int mode)
 {
+    const bool exposedOnly = mode == VP_EXTRACT_EXPOSED;
     std::vector<uint64_t> out;
     const int64_t n = static_cast<int64_t>(grid.VoxelsPerSide());
     auto set = [&](int64_t x, int64_t y, int64_t z) {
@@ -41,21 +43,21 @@ std::vector<uint64_t> HostRecords(const VoxelsGrid<T>& grid, bool exposedOnly)
             for (int64_t x = 0; x < n; ++x) {
                 if (!grid.Voxel(x, y, z)) continue;
                 const uint64_t idx = static_cast<uint64_t>(x + n * (y + n * z));
-                if (!exposedOnly) { out.push_back(idx); continue; }
+                if (mode == VP_EXTRACT_SET) { out.push_back(idx); continue; }
                 uint64_t mask = 0;
                 for (int axis = 0; axis < 3; ++axis)
                     for (int side = 0; side < 2; ++side) {
                         const int d = side ? 1 : -1;
                         if (!set(x + d * (axis == 0), y + d * (axis == 1), z + d * (axis == 2))) mask |= 1ull << (axis * 2 + side);
                     }
-                if (mask) out.push_back(idx | (mask << 40));
+                if (mask || !exposedOnly) out.push_back(idx | (mask << 40));
             }
     return out;
 }
 
 // device record generator: upload the grid, count, extract, download
 template <VGType T>
-std::vector<uint64_t> DeviceRecords(const VoxelsGrid<T>& grid, bool exposedOnly)
+std::vector<uint64_t> DeviceRecords(const VoxelsGrid<T>& grid, int mode)
 {
     vp_ctx* ctx = vplib::Context();
     vp_frame f{};
@@ -63,7 +65,6 @@ std::vector<uint64_t> DeviceRecords(const VoxelsGrid<T>& grid, bool exposedOnly)
     f.origin[0] = grid.OriginX(); f.origin[1] = grid.OriginY(); f.origin[2] = grid.OriginZ();
     f.z0 = 0; f.z1 = f.n;
     const size_t gridBytes = vp_grid_words(&f) * 4;
-    const int mode = exposedOnly ? VP_EXTRACT_EXPOSED : VP_EXTRACT_SET;
     void *dWords = nullptr, *dRec = nullptr;
     gpuAssert(vp_ctx_workspace(ctx, vplib::kSlotGridA, gridBytes, &dWords));
     gpuAssert(vp_upload(ctx, dWords, grid.Data(), gridBytes));
@@ -79,6 +80,55 @@ std::vector<uint64_t> DeviceRecords(const VoxelsGrid<T>& grid, bool exposedOnly)
 }
 
 // ---- emitters (shared by the host and the device variants) ------------------------------------------------
+// The reference's compressed mesh (grid_to_mesh.cpp:10-60): for every set voxel in z, y, x order the faces XY back / front, XZ back / front,
+// YZ back / front (:37-44), each emitted ONCE -- a face already emitted by the voxel on its other side is skipped (faces_marked,
+// grid_to_mesh.h:36-41); in scan order that is exactly "a back face is skipped iff the voxel behind it is set" (that voxel came first and
+// emitted it as its front face), which is what the face mask of the records says.  Vertices are shared through a map keyed by lattice
+// point and numbered in order of first use, four per face in (v, u) order (:45-65); the two triangles and their winding depend on plane
+// and side (:67-85); six normal indices (front * 3 + plane_index) per face (:87).
+template <VGType T>
+void EmitReferenceFaces(const VoxelsGrid<T>& grid, const std::vector<uint64_t>& records, Mesh& mesh)
+{
+    mesh.Clear();
+    AxisNormals(mesh);
+    const int64_t n = static_cast<int64_t>(grid.VoxelsPerSide());
+    const int64_t nv = n + 1;
+    std::unordered_map<int64_t, uint32_t> vertexOf;
+    auto vertex = [&](int64_t x, int64_t y, int64_t z) -> uint32_t {
+        const int64_t key = (z * nv + y) * nv + x;
+        auto [it, fresh] = vertexOf.try_emplace(key, static_cast<uint32_t>(mesh.Coords.size()));
+        if (fresh)
+            mesh.Coords.emplace_back(grid.OriginX() + (static_cast<unsigned>(x) * grid.VoxelSize()), grid.OriginY() + (static_cast<unsigned>(y) * grid.VoxelSize()),
+                                     grid.OriginZ() + (static_cast<unsigned>(z) * grid.VoxelSize()));
+        return it->second;
+    };
+    // plane: 0 = XY (normal Z), 2 = XZ (normal Y), 1 = YZ (normal X) -- the reference's plane_index (:31)
+    auto face = [&](int64_t x, int64_t y, int64_t z, int plane, int front) {
+        uint32_t q[4];
+        for (int v = 0; v < 2; ++v)
+            for (int u = 0; u < 2; ++u)
+                q[u + 2 * v] = plane == 0 ? vertex(x + u, y + v, z + front) : plane == 2 ? vertex(x + u, y + front, z + v) : vertex(x + front, y + v, z + u);
+        const bool flip = (front != 0) == (plane != 0);             // (:67-85)
+        if (flip) mesh.FacesCoords.insert(mesh.FacesCoords.end(), {q[0], q[2], q[1], q[1], q[2], q[3]});
+        else      mesh.FacesCoords.insert(mesh.FacesCoords.end(), {q[0], q[1], q[2], q[1], q[3], q[2]});
+        mesh.FacesNormals.insert(mesh.FacesNormals.end(), 6, static_cast<uint32_t>(front * 3 + plane));
+    };
+    for (const uint64_t rec : records) {
+        const int64_t idx = static_cast<int64_t>(rec & kIndexMask);
+        const unsigned mask = static_cast<unsigned>(rec >> 40);     // bit axis * 2 + side: that neighbour is unset / outside
+        const int64_t x = idx % n, y = (idx / n) % n, z = idx / (n * n);
+        if ((mask >> 4) & 1u) face(x, y, z, 0, 0);                  // XY back: unless (x, y, z - 1) emitted it
+        face(x, y, z, 0, 1);
+        if ((mask >> 2) & 1u) face(x, y, z, 2, 0);                  // XZ back: (x, y - 1, z)
+        face(x, y, z, 2, 1);
+        if ((mask >> 0) & 1u) face(x, y, z, 1, 0);                  // YZ back: (x - 1, y, z)
+        face(x, y, z, 1, 1);
+    }
+    mesh.Colors.assign(mesh.VerticesSize(), Color(1.0f, 1.0f, 1.0f, 1.0f));
+}
+
+// The visible surface alone (an option of this build, not a reference export): only the faces between a set voxel and an unset /
+// outside neighbour, outward winding.
 template <VGType T>
 void EmitSurface(const VoxelsGrid<T>& grid, const std::vector<uint64_t>& records, Mesh& mesh)
 {
@@ -173,18 +223,22 @@ void EmitPoints(const VoxelsGrid<T>& grid, const Grid<float>& sdf, const std::ve
 
 }  // namespace
 
-template <VGType T> bool VoxelsGridToMeshCompressed(const VoxelsGrid<T>& grid, Mesh& mesh) { EmitSurface(grid, HostRecords(grid, true), mesh); return true; }
-template <VGType T> bool VoxelsGridToMesh(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitCubes(grid, sdf, HostRecords(grid, false), mesh); return true; }
-template <VGType T> bool VoxelsGridToPointCloud(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitPoints(grid, sdf, HostRecords(grid, false), mesh); return true; }
-template <VGType T> bool VoxelsGridToMeshCompressedDevice(const VoxelsGrid<T>& grid, Mesh& mesh) { EmitSurface(grid, DeviceRecords(grid, true), mesh); return true; }
-template <VGType T> bool VoxelsGridToMeshDevice(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitCubes(grid, sdf, DeviceRecords(grid, false), mesh); return true; }
-template <VGType T> bool VoxelsGridToPointCloudDevice(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitPoints(grid, sdf, DeviceRecords(grid, false), mesh); return true; }
+template <VGType T> bool VoxelsGridToMeshCompressed(const VoxelsGrid<T>& grid, Mesh& mesh) { EmitReferenceFaces(grid, HostRecords(grid, VP_EXTRACT_FACES), mesh); return true; }
+template <VGType T> bool VoxelsGridToSurfaceMesh(const VoxelsGrid<T>& grid, Mesh& mesh) { EmitSurface(grid, HostRecords(grid, VP_EXTRACT_EXPOSED), mesh); return true; }
+template <VGType T> bool VoxelsGridToMesh(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitCubes(grid, sdf, HostRecords(grid, VP_EXTRACT_SET), mesh); return true; }
+template <VGType T> bool VoxelsGridToPointCloud(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitPoints(grid, sdf, HostRecords(grid, VP_EXTRACT_SET), mesh); return true; }
+template <VGType T> bool VoxelsGridToMeshCompressedDevice(const VoxelsGrid<T>& grid, Mesh& mesh) { EmitReferenceFaces(grid, DeviceRecords(grid, VP_EXTRACT_FACES), mesh); return true; }
+template <VGType T> bool VoxelsGridToSurfaceMeshDevice(const VoxelsGrid<T>& grid, Mesh& mesh) { EmitSurface(grid, DeviceRecords(grid, VP_EXTRACT_EXPOSED), mesh); return true; }
+template <VGType T> bool VoxelsGridToMeshDevice(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitCubes(grid, sdf, DeviceRecords(grid, VP_EXTRACT_SET), mesh); return true; }
+template <VGType T> bool VoxelsGridToPointCloudDevice(const VoxelsGrid<T>& grid, const Grid<float>& sdf, Mesh& mesh) { EmitPoints(grid, sdf, DeviceRecords(grid, VP_EXTRACT_SET), mesh); return true; }
 
 #define VP_INSTANTIATE(T)                                                                         \
     template bool VoxelsGridToMeshCompressed<T>(const VoxelsGrid<T>&, Mesh&);                     \
+    template bool VoxelsGridToSurfaceMesh<T>(const VoxelsGrid<T>&, Mesh&);                        \
     template bool VoxelsGridToMesh<T>(const VoxelsGrid<T>&, const Grid<float>&, Mesh&);           \
     template bool VoxelsGridToPointCloud<T>(const VoxelsGrid<T>&, const Grid<float>&, Mesh&);     \
     template bool VoxelsGridToMeshCompressedDevice<T>(const VoxelsGrid<T>&, Mesh&);               \
+    template bool VoxelsGridToSurfaceMeshDevice<T>(const VoxelsGrid<T>&, Mesh&);                  \
     template bool VoxelsGridToMeshDevice<T>(const VoxelsGrid<T>&, const Grid<float>&, Mesh&);     \
     template bool VoxelsGridToPointCloudDevice<T>(const VoxelsGrid<T>&, const Grid<float>&, Mesh&);
 VP_INSTANTIATE(uint32_t)

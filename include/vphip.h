@@ -240,13 +240,16 @@ int vp_surface(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words,
  *   mode VP_EXTRACT_SET      every set voxel (point cloud, sdf cubes: grid_to_mesh.cpp:133-201)
  *   mode VP_EXTRACT_EXPOSED  set voxels with a face towards an unset voxel or the outside of the grid, with the mask of
  *                            those faces (visible-surface mesh)
+ *   mode VP_EXTRACT_FACES    every set voxel, with that mask: VoxelsGridToMeshCompressed (grid_to_mesh.cpp:10-60, grid_to_mesh.h:25-92)
+ *                            emits every face of every set voxel ONCE, interior faces included -- the three faces on a voxel's plus sides
+ *                            always, a face on a minus side iff the voxel behind it is unset (else that voxel emitted it already)
  *   record = linear voxel index x + n (y + n z) in bits 0..39 | face mask << 40 (bit = axis * 2 + side; X, Y, Z; 0 = minus)
  * vp_extract_count runs the counting pass and returns the number of records (blocking); vp_extract then writes up to
  * `capacity` records (and, when d_sdf and d_values are given, the sdf value of each voxel) -- it must follow a count call for
  * the same grid and mode, else VP_ERR_INVALID.  "Same grid" means same contents: the count is forgotten as soon as d_words is
  * written through this ABI (vp_voxelize, vp_csg, vp_upload, vp_memset, vp_memcpy_d2d), freed, or handed out again by
  * vp_ctx_workspace; a caller that writes the buffer with its own kernels must count again itself. */
-enum { VP_EXTRACT_SET = 0, VP_EXTRACT_EXPOSED = 1 };
+enum { VP_EXTRACT_SET = 0, VP_EXTRACT_EXPOSED = 1, VP_EXTRACT_FACES = 2 };
 int vp_extract_count(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode, uint64_t* h_count);
 int vp_extract(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode, const float* d_sdf,
                uint64_t* d_records, float* d_values, size_t capacity);

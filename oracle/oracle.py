@@ -19,8 +19,8 @@ _f32p = ctypes.POINTER(ctypes.c_float)
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "vp_oracle.c")
-    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+    srcs = [os.path.join(_HERE, f) for f in ("vp_oracle.c", "oracle_export.c", "vp_oracle.h")]
+    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libvporacle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -52,6 +52,11 @@ def lib():
         L.vpo_sdf_stats.restype = None
         L.vpo_sdf_stats.argtypes = [_f32p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),
                                     ctypes.POINTER(ctypes.c_double), _f32p]
+        L.vpo_grid_to_mesh_compressed.restype = ctypes.c_int
+        L.vpo_grid_to_mesh_compressed.argtypes = [_u32p, ctypes.c_uint, ctypes.c_float, _f32p, ctypes.POINTER(_f32p), ctypes.POINTER(ctypes.c_size_t),
+                                                  ctypes.POINTER(_u32p), ctypes.POINTER(_u32p), ctypes.POINTER(ctypes.c_size_t)]
+        L.vpo_free.restype = None
+        L.vpo_free.argtypes = [ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -136,3 +141,23 @@ def sdf_stats(sdf):
     lib().vpo_sdf_stats(_pf(sdf), sdf.size, counts, sums, mm)
     return {"zeros": int(counts[0]), "pinf": int(counts[1]), "ninf": int(counts[2]),
             "sum_pos": float(sums[0]), "sum_neg": float(sums[1]), "min": float(mm[0]), "max": float(mm[1])}
+
+
+def grid_to_mesh_compressed(words, n: int, voxel_size, origin):
+    """The reference's VoxelsGridToMeshCompressed (oracle_export.c): (coords float32 [V, 3], faces uint32 [F, 3], face normal indices
+    uint32 [F, 3]) -- every face of every set voxel once, in the reference's order."""
+    words = _u32(words)
+    origin = _f32(origin)
+    pc, pf, pn = _f32p(), _u32p(), _u32p()
+    nv, ni = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = lib().vpo_grid_to_mesh_compressed(_pu(words), n, float(voxel_size), _pf(origin), ctypes.byref(pc), ctypes.byref(nv),
+                                           ctypes.byref(pf), ctypes.byref(pn), ctypes.byref(ni))
+    if rc != 0:
+        raise MemoryError("vpo_grid_to_mesh_compressed allocation failed")
+    try:
+        coords = np.ctypeslib.as_array(pc, shape=(nv.value * 3,)).copy().reshape(-1, 3) if nv.value else np.zeros((0, 3), np.float32)
+        faces = np.ctypeslib.as_array(pf, shape=(ni.value,)).copy().reshape(-1, 3) if ni.value else np.zeros((0, 3), np.uint32)
+        normals = np.ctypeslib.as_array(pn, shape=(ni.value,)).copy().reshape(-1, 3) if ni.value else np.zeros((0, 3), np.uint32)
+    finally:
+        lib().vpo_free(pc); lib().vpo_free(pf); lib().vpo_free(pn)
+    return coords, faces, normals

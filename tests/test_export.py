@@ -1,0 +1,128 @@
+"""The `-e` grid export: VoxelsGridToMeshCompressed of the vplib mirror must emit the REFERENCE's mesh -- every face of
+every set voxel once (interior faces included), its vertex numbering, winding and normal indices
+(/root/reference/vplib/src/mesh/grid_to_mesh.h:25-92, grid_to_mesh.cpp:10-60) -- checked against oracle/oracle_export.c, the line-by-line
+restatement of those functions, through the files the CLI writes (ExportMesh, mesh_io.cpp:84-126: 6 decimals, 1-based `f a//n b//n c//n`).
+CPU types run here; the GPU front end (vp_extract records) is gpu-marked."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cuda_mesh_voxelization_amd import build, mesh as M
+from oracle import oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "export_oracle.json")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    return build.build_cli()
+
+
+def _parse_obj(path):
+    v, f, fn = [], [], []
+    for line in open(path):
+        if line.startswith("v "):
+            v.append(line.split()[1:4])
+        elif line.startswith("f "):
+            parts = [p.split("//") for p in line.split()[1:4]]
+            f.append([int(p[0]) - 1 for p in parts])
+            fn.append([int(p[1]) - 1 for p in parts])
+    return v, np.array(f, np.uint32).reshape(-1, 3), np.array(fn, np.uint32).reshape(-1, 3)
+
+
+def _expect(name, n):
+    xyz, tri = M.import_mesh(M.asset(name))
+    origin, vs = O.frame([xyz], n)
+    words = O.voxelize(xyz, tri, n, vs, origin)
+    return words, O.grid_to_mesh_compressed(words, n, vs, origin)
+
+
+def _check_file(path, coords, faces, normals):
+    v, f, fn = _parse_obj(path)
+    assert f.shape == faces.shape and np.array_equal(f, faces)                   # the index buffer, triangle by triangle
+    assert np.array_equal(fn, normals)
+    assert len(v) == coords.shape[0]
+    want = [["%.6f" % float(c) for c in row] for row in coords]                 # ExportMesh: std::fixed, 6 decimals
+    assert v == want
+
+
+@pytest.mark.parametrize("name,n", [("d20.obj", 32), ("torus.obj", 32)])
+def test_oracle_export_counts_and_recorded_hashes(name, n):
+    """What the restatement produces, from first principles: every set voxel contributes its three plus-side faces, and a minus-side face
+    iff the voxel behind it is unset or outside; vertices are shared lattice points.  The hashes are THIS oracle's own outputs, recorded so
+    that a change of the restatement shows (tests/golden/export_oracle.json: not reference outputs -- the reference holds no golden mesh)."""
+    words, (coords, faces, normals) = _expect(name, n)
+    occ = np.unpackbits(words.view(np.uint8), bitorder="little").reshape(n, n, n).astype(bool)
+    pad = np.pad(occ, 1)
+    back = sum(int((occ & ~np.roll(pad, 1, ax)[1:-1, 1:-1, 1:-1]).sum()) for ax in range(3))
+    assert faces.shape[0] == 2 * (3 * int(occ.sum()) + back)
+    assert len(np.unique(coords, axis=0)) == coords.shape[0] and faces.max() == coords.shape[0] - 1
+    assert sorted(np.unique(normals).tolist()) == [0, 1, 2, 3, 4, 5]
+    rec = json.load(open(GOLDEN))["%s@%d" % (name, n)]
+    assert [coords.shape[0], faces.shape[0], O.fnv(faces), O.fnv(normals), O.fnv(coords)] == rec
+
+
+@pytest.mark.parametrize("t", [0, 3])
+@pytest.mark.parametrize("name,n", [("d20.obj", 32), ("torus.obj", 32)])
+def test_cli_export_is_the_reference_mesh(cli, tmp_path, name, n, t):
+    _, (coords, faces, normals) = _expect(name, n)
+    p = subprocess.run([cli, M.asset(name), "-n", str(n), "-t", str(t), "-e"], capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    (out,) = list((tmp_path / "out").iterdir())
+    _check_file(str(out), coords, faces, normals)
+
+
+def test_cli_surface_only_is_the_visible_surface(cli, tmp_path):
+    """--surface-only (this build's addition): only the faces between a set voxel and an unset / outside neighbour, a closed surface"""
+    n = 32
+    words, _ = _expect("torus.obj", n)
+    p = subprocess.run([cli, M.asset("torus.obj"), "-n", str(n), "-t", "0", "-e", "--surface-only"], capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    occ = np.unpackbits(words.view(np.uint8), bitorder="little").reshape(n, n, n).astype(bool)
+    pad = np.pad(occ, 1)
+    exposed = sum(int((occ & ~np.roll(pad, s, ax)[1:-1, 1:-1, 1:-1]).sum()) for ax in range(3) for s in (1, -1))
+    xyz, tri = M.import_mesh(str(tmp_path / "out" / "sequential_torus.obj"))
+    assert tri.shape[0] == 2 * exposed
+    t = tri.astype(np.int64)
+    e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]], 0)
+    assert np.array_equal(np.sort(e[:, 0] * (t.max() + 1) + e[:, 1]), np.sort(e[:, 1] * (t.max() + 1) + e[:, 0]))     # each directed edge has its opposite
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n", [("d20.obj", 32), ("torus.obj", 32), ("bunny.obj", 128)])
+def test_cli_device_front_end_exports_the_reference_mesh(cli, tmp_path, name, n):
+    """-t 2 -e: the walk over the grid is vp_extract (VP_EXTRACT_FACES records); the file is the oracle's mesh"""
+    _, (coords, faces, normals) = _expect(name, n)
+    p = subprocess.run([cli, M.asset(name), "-n", str(n), "-t", "2", "-e"], capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    (out,) = list((tmp_path / "out").iterdir())
+    _check_file(str(out), coords, faces, normals)
+
+
+@pytest.mark.gpu
+def test_extract_faces_records_match_numpy(engine):
+    """VP_EXTRACT_FACES: every set voxel in index order with the mask of its faces towards unset / outside neighbours"""
+    import torch
+    from cuda_mesh_voxelization_amd.capi import EXTRACT_FACES, Frame
+    n = 96
+    rng = np.random.default_rng(5)
+    words = rng.integers(0, 2**32, n * n * n // 32, dtype=np.uint32) & rng.integers(0, 2**32, n * n * n // 32, dtype=np.uint32)
+    fr = Frame.make(n, 0.1, (0.0, 0.0, 0.0))
+    g = engine.to_device(words, np.uint32)
+    cnt = engine.ctx.extract_count(fr, g.data_ptr(), EXTRACT_FACES)
+    occ = np.unpackbits(words.view(np.uint8), bitorder="little").reshape(n, n, n).astype(bool)
+    assert cnt == int(occ.sum())
+    rec = torch.empty(cnt, dtype=torch.int64, device=engine.device)
+    engine.ctx.extract(fr, g.data_ptr(), EXTRACT_FACES, None, rec.data_ptr(), None, cnt)
+    engine.sync()
+    got = rec.cpu().numpy().view(np.uint64)
+    pad = np.pad(occ, 1)
+    mask = np.zeros((n, n, n), np.uint64)
+    for axis, ax in ((0, 2), (1, 1), (2, 0)):                            # record axis X, Y, Z = array axis 2, 1, 0
+        for side, s in ((0, 1), (1, -1)):
+            mask |= (occ & ~np.roll(pad, s, ax)[1:-1, 1:-1, 1:-1]).astype(np.uint64) << np.uint64(axis * 2 + side)
+    idx = np.flatnonzero(occ.reshape(-1)).astype(np.uint64)
+    assert np.array_equal(got, idx | (mask.reshape(-1)[idx.astype(np.int64)] << np.uint64(40)))
