@@ -50,8 +50,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", "--grid-n", dest="n", type=int, default=512, choices=[256, 512, 1024, 2048],
                     help="grid side; 512 = the headline configuration, 1024 / 2048 = the sizes the north star shards.  Under "
                          "torch.distributed.run spell it --grid-n: the launcher's own parser rejects a bare --n as an ambiguous "
