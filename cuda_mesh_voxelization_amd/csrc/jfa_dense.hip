@@ -574,7 +574,7 @@ template <class ID, int CH, int NT, bool F>
 void launch_shape(const DenseArgs& a, bool pairsOk, bool wholeChains)
 {
     constexpr int RY = (ID::kTab == 512 && !F && CH == 8) ? 8 : 4;
-    constexpr bool canFull = CH == 8 && (ID::kTab != 1024 || F);
+    constexpr bool canFull = CH >= 8 && (ID::kTab != 1024 || F);
     auto go = [&](auto pm) {
         constexpr int PM = decltype(pm)::value;
         if constexpr (canFull) {
@@ -582,7 +582,7 @@ void launch_shape(const DenseArgs& a, bool pairsOk, bool wholeChains)
         }
         launch_tile<ID, RY, CH, NT, F, PM>(a);
     };
-    if constexpr (CH == 8) {
+    if constexpr (CH >= 8) {
         if (pairsOk && a.f.n % NT == 0) {
             if constexpr (F) { go(int_c<1>{}); return; }
             else {
@@ -643,6 +643,16 @@ int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const
     // (the remainders of the split above, and the slabs of a pass whose step spans whole slabs): 2-plane tiles
     const bool deep = zlen % 8 == 0 || (zlen > 4 && zlen < 8);
     const bool tiny = !fin && zlen <= 2;
+    // Compact ids: 16-plane tiles where the chains allow it.  The kernel streams over its planes (three output planes are live whatever CH is) and
+    // this format keeps ONE table of z positions, so a longer tile costs neither registers nor LDS, only code: (CH + 2) / CH plane reads per
+    // output plane fall from 1.25 to 1.125 -- n = 2048: tile passes -2.7 %, fused last pass -6.2 % (profiles/r05/ab_ch16_2048.txt).
+    if constexpr (std::is_same<ID, IdC>::value) {
+        if (zlen % 16 == 0 && stride == k) {
+            if (fin) launch_shape<ID, 16, NTD, true>(a, pow2, wholeChains); else launch_shape<ID, 16, NTD, false>(a, pow2 && k >= 2, wholeChains);
+            VP_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (deep) { if (fin) launch_shape<ID, 8, NTD, true>(a, pow2, wholeChains); else launch_shape<ID, 8, NTD, false>(a, pow2 && k >= 2, wholeChains); }
     else if (tiny) launch_shape<ID, 2, NTS, false>(a, false, false);
     else { if (fin) launch_shape<ID, 4, NTS, true>(a, false, false); else launch_shape<ID, 4, NTS, false>(a, false, false); }
