@@ -75,12 +75,13 @@ class Frame(ctypes.Structure):
 
 class Window(ctypes.Structure):
     """vp_window: an id buffer in the library's layout -- `planes` id planes, plane z0 of the frame a call is made with at index `at`."""
-    _fields_ = [("d_ids", ctypes.c_void_p), ("planes", ctypes.c_uint32), ("at", ctypes.c_uint32)]
+    _fields_ = [("d_ids", ctypes.c_void_p), ("bytes", ctypes.c_size_t), ("planes", ctypes.c_uint32), ("at", ctypes.c_uint32)]
 
     @classmethod
-    def make(cls, d_ids, planes, at):
+    def make(cls, d_ids, nbytes, planes, at):
+        """nbytes: the size of the buffer (every call checks it against vp_jfa_window_bytes of `planes` planes)"""
         w = cls()
-        w.d_ids, w.planes, w.at = int(d_ids), int(planes), int(at)
+        w.d_ids, w.bytes, w.planes, w.at = int(d_ids), int(nbytes), int(planes), int(at)
         return w
 
 

@@ -540,6 +540,8 @@ static int window_check(vp_ctx* ctx, const vp_frame* f, const vp_window* w, cons
     VP_TRY(check_aligned(who, {w->d_ids}));
     if (f->n < kTileMinN) return set_error(VP_ERR_UNSUPPORTED, "%s: windows are the layout of the tile kernels (n >= %u)", who, kTileMinN);
     const uint64_t nz = f->z1 - f->z0;
+    if (w->bytes < win_bytes(f->n, w->planes))
+        return set_error(VP_ERR_INVALID, "%s: a window of %u planes needs %zu bytes, %zu given", who, w->planes, win_bytes(f->n, w->planes), w->bytes);
     if (w->planes == 0 || (uint64_t)w->at + nz + above > w->planes || w->at < below)
         return set_error(VP_ERR_INVALID, "%s: planes [%u, %u) at index %u (+%u below, +%u above) do not fit a window of %u planes", who, f->z0, f->z1, w->at, below, above, w->planes);
     out.base = (char*)w->d_ids; out.planes = w->planes; out.at = w->at;
@@ -552,6 +554,7 @@ int vp_jfa_window_clear(vp_ctx* ctx, const vp_frame* f, const vp_window* w)
     VP_TRY(bind_device(ctx));
     VP_TRY(check_frame(f, "vp_jfa_window_clear", false));
     VP_TRY(check_aligned("vp_jfa_window_clear", {w->d_ids}));
+    if (w->bytes < win_bytes(f->n, w->planes)) return set_error(VP_ERR_INVALID, "vp_jfa_window_clear: a window of %u planes needs %zu bytes, %zu given", w->planes, win_bytes(f->n, w->planes), w->bytes);
     IdWin iw; iw.base = (char*)w->d_ids; iw.planes = w->planes; iw.at = 0;
     return launch_win_clear(ctx, f->n, iw);
 }

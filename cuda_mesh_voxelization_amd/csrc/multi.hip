@@ -98,7 +98,7 @@ int ensure_windows(Rank& r, const vp_frame& G, uint32_t planes)
     fresh = fresh || poison != nullptr;
 #endif
     if (fresh)
-        for (int i = 0; i < 2; ++i) { const vp_window w{r.ids[i].ptr, planes, 0}; VP_TRY(vp_jfa_window_clear(r.ctx, &G, &w)); }
+        for (int i = 0; i < 2; ++i) { const vp_window w{r.ids[i].ptr, r.ids[i].bytes, planes, 0}; VP_TRY(vp_jfa_window_clear(r.ctx, &G, &w)); }
 #ifdef VP_TEST_HOOKS
     if (poison)
         for (Buffer& b : r.ids) VP_HIP(hipMemsetAsync(b.ptr, (int)strtol(poison, nullptr, 0) & 0xFF, (size_t)planes * G.n * G.n * 4, r.ctx->stream));
@@ -286,7 +286,7 @@ int jfa_halo(vp_multi* m, float fill)
     for (uint32_t r = 0; r < world; ++r) {
         Rank& me = m->ranks[r];
         const vp_frame f = slab_frame(G, me.z0, me.z1);
-        const vp_window w{me.ids[cur].ptr, planes, at};
+        const vp_window w{me.ids[cur].ptr, me.ids[cur].bytes, planes, at};
         VP_TRY(vp_jfa_window_init(me.ctx, &f, (const uint32_t*)slab_words(m, me), r > 0 ? (const uint32_t*)me.below.ptr : nullptr,
                                   r + 1 < world ? (const uint32_t*)me.above.ptr : nullptr, &w));
     }
@@ -307,7 +307,7 @@ int jfa_halo(vp_multi* m, float fill)
         for (uint32_t r = 0; r < world; ++r) {
             Rank& me = m->ranks[r];
             const vp_frame f = slab_frame(G, me.z0, me.z1);
-            const vp_window in{me.ids[cur].ptr, planes, at}, out{me.ids[cur ^ 1].ptr, planes, at};
+            const vp_window in{me.ids[cur].ptr, me.ids[cur].bytes, planes, at}, out{me.ids[cur ^ 1].ptr, me.ids[cur ^ 1].bytes, planes, at};
             if (k == 1) VP_TRY(vp_jfa_window_last_pass(me.ctx, &f, &in, &out, stride, (const uint32_t*)slab_words(m, me), fill, (float*)me.sdf.ptr));
             else        VP_TRY(vp_jfa_window_pass(me.ctx, &f, k, &in, &out, stride));
         }
@@ -338,11 +338,11 @@ int jfa_ghost(vp_multi* m, float fill)
         const uint32_t* words = (const uint32_t*)me.words.ptr;
         int cur = 0;
         VP_TRY(vp_surface(me.ctx, &G, words, nullptr, nullptr, (uint32_t*)me.border.ptr));
-        { const vp_window w{me.ids[cur].ptr, n, 0}; VP_TRY(vp_jfa_window_first_two(me.ctx, &G, (const uint32_t*)me.border.ptr, &w)); }
+        { const vp_window w{me.ids[cur].ptr, me.ids[cur].bytes, n, 0}; VP_TRY(vp_jfa_window_first_two(me.ctx, &G, (const uint32_t*)me.border.ptr, &w)); }
         for (size_t i = 2; i < regs.size(); ++i) {
             const Region& g = regs[i];
             const vp_frame f = slab_frame(G, g.b0, g.b1);
-            const vp_window in{me.ids[cur].ptr, n, g.b0}, out{me.ids[cur ^ 1].ptr, n, g.b0};
+            const vp_window in{me.ids[cur].ptr, me.ids[cur].bytes, n, g.b0}, out{me.ids[cur ^ 1].ptr, me.ids[cur ^ 1].bytes, n, g.b0};
             if (i + 1 == regs.size()) VP_TRY(vp_jfa_window_last_pass(me.ctx, &f, &in, &out, 1, words + (size_t)g.b0 * (planeWords / 4), fill, (float*)me.sdf.ptr));
             else                      VP_TRY(vp_jfa_window_pass(me.ctx, &f, g.k, &in, &out, g.k));
             cur ^= 1;
@@ -401,7 +401,7 @@ int jfa_hybrid(vp_multi* m, float fill)
     const size_t nwide = plans[0].wide.size(), nnarrow = plans[0].narrow.size();     // the same on every rank (they depend on nz only)
     std::vector<int> cur(world, 0);
     // window `which` of rank r, positioned for a frame that starts at global plane g
-    auto win = [&](uint32_t r, int which, uint32_t g) { return vp_window{m->ranks[r].ids[which].ptr, plans[r].hi - plans[r].lo, g - plans[r].lo}; };
+    auto win = [&](uint32_t r, int which, uint32_t g) { return vp_window{m->ranks[r].ids[which].ptr, m->ranks[r].ids[which].bytes, plans[r].hi - plans[r].lo, g - plans[r].lo}; };
     // ---- wide passes: ghost planes inside the window, no exchange
     for (uint32_t r = 0; r < world; ++r) {
         Rank& me = m->ranks[r];

@@ -78,7 +78,7 @@ class HipSlabBackend:
         memory nobody wrote.  `poison` (tests) overwrites the word planes with an arbitrary byte afterwards to show that the results do
         not depend on what those planes hold."""
         t = torch.empty(self.ctx.jfa_window_bytes(frame, planes), dtype=torch.uint8, device=self.device)
-        self.ctx.jfa_window_clear(frame, Window.make(t.data_ptr(), planes, 0))
+        self.ctx.jfa_window_clear(frame, Window.make(t.data_ptr(), t.numel(), planes, 0))
         if self.poison is not None:
             t[:planes * frame.n * frame.n * 4].fill_(int(self.poison) & 0xFF)
         return IdWindow(t, planes)
@@ -89,7 +89,7 @@ class HipSlabBackend:
 
     @staticmethod
     def _w(w, at):
-        return Window.make(w.t.data_ptr(), w.planes, at)
+        return Window.make(w.t.data_ptr(), w.t.numel(), w.planes, at)
 
     def win_init(self, region, words_region, below, above, w, at):
         self.ctx.jfa_window_init(region, words_region.data_ptr(), self._p(below), self._p(above), self._w(w, at))

@@ -211,8 +211,9 @@ int vp_jfa_last_pass(vp_ctx* ctx, const vp_frame* f, const void* d_in, const voi
  *   vp_jfa_window_last_pass    step 1 fused with the id -> sdf conversion; d_words_region / d_sdf_region hold the planes [z0, z1) only
  * Same results as the plain-id calls, bit for bit. */
 typedef struct vp_window {
-    void*    d_ids;       /* vp_jfa_window_bytes(f, planes) bytes, 16-byte aligned */
-    uint32_t planes;      /* id planes the buffer holds */
+    void*    d_ids;       /* the buffer, 16-byte aligned */
+    size_t   bytes;       /* its size: at least vp_jfa_window_bytes(f, planes) -- checked by every call (VP_ERR_INVALID) */
+    uint32_t planes;      /* id planes the buffer holds (the layout depends on it: above n = 1024 the byte planes follow `planes` word planes) */
     uint32_t at;          /* index inside the buffer of plane z0 of the frame given with it */
 } vp_window;
 size_t vp_jfa_window_bytes(const vp_frame* f, uint32_t planes);

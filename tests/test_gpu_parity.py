@@ -730,6 +730,43 @@ def test_extract_records_match_numpy(engine):
                 assert np.array_equal(r2[:10].view(np.uint64), exp[:10]) and (r2[10:] == -1).all()
 
 
+def test_window_calls_check_their_arguments(engine):
+    """vp_jfa_window_*: a window that is too small for its `planes`, planes of the frame that do not fit it, halo planes a pass would read
+    outside it, windows of different geometry, a bad stride, n below the tile kernels -- all VP_ERR_INVALID / UNSUPPORTED, nothing launched
+    (the whole-volume calls of round 4 took neither a size nor an alignment check)."""
+    from cuda_mesh_voxelization_amd.capi import Window
+    ctx = engine.ctx
+    n = 128
+    fr = Frame.make(n, 0.1, (0.0, 0.0, 0.0))
+    nb = ctx.jfa_window_bytes(fr, 64)
+    assert nb == 64 * n * n * 4 and ctx.jfa_window_bytes(Frame.make(1152, 0.1, (0, 0, 0)), 8) == 8 * 1152 * 1152 * 5
+    a = torch.empty(nb, dtype=torch.uint8, device=engine.device)
+    b = torch.empty(nb, dtype=torch.uint8, device=engine.device)
+    slab = fr.slab(32, 64)
+    ok = lambda t, at=16, planes=64, nbytes=None: Window.make(t.data_ptr(), nb if nbytes is None else nbytes, planes, at)
+    ctx.jfa_window_clear(fr, ok(a)); ctx.jfa_window_clear(fr, ok(b))
+    ctx.jfa_window_pass(slab, 16, ok(a), ok(b))                              # planes 16 .. 80 of the grid at indices 0 .. 64: fits exactly
+    with pytest.raises(capi.VPError, match="bytes"):
+        ctx.jfa_window_pass(slab, 16, ok(a, nbytes=nb - 16), ok(b))          # buffer smaller than its planes say
+    with pytest.raises(capi.VPError, match="do not fit"):
+        ctx.jfa_window_pass(slab, 16, ok(a, at=40), ok(b, at=40))            # the slab + its upper halo run past the window
+    with pytest.raises(capi.VPError, match="do not fit"):
+        ctx.jfa_window_pass(slab, 32, ok(a), ok(b))                          # 32 halo planes below index 16
+    with pytest.raises(capi.VPError, match="same planes"):
+        ctx.jfa_window_pass(slab, 16, ok(a), ok(b, at=8))
+    with pytest.raises(capi.VPError, match="bad windows"):
+        ctx.jfa_window_pass(slab, 16, ok(a), ok(a))
+    with pytest.raises(capi.VPError, match="stride"):
+        ctx.jfa_window_pass(slab, 16, ok(a), ok(b), stride=8)                # a stride other than the step needs a step of at least the slab height
+    with pytest.raises(capi.VPError, match="aligned"):
+        ctx.jfa_window_clear(fr, Window.make(a.data_ptr() + 4, nb - 4, 32, 0))
+    with pytest.raises(capi.VPError, match="n >= 96"):
+        ctx.jfa_window_pass(Frame.make(64, 0.1, (0, 0, 0)), 8, ok(a), ok(b))
+    with pytest.raises(capi.VPError, match="whole-grid"):
+        ctx.jfa_window_first_two(slab, engine.new_grid(fr).data_ptr(), ok(a))
+    engine.sync()
+
+
 def _coords_plain64(t):
     """(x, scr(y), scr(z), none) of plain 8-byte ids (jfa_common.h: Id64 -- .x = scr(z) << 2 | x << 13, .y = scr(y) << 2, "none" = all ones)"""
     lo, hi = (t & 0xFFFFFFFF), ((t >> 32) & 0xFFFFFFFF)
@@ -784,7 +821,7 @@ def test_jfa_every_pass_ids_tiled_equals_naive(engine, n, kind):
     ctx.jfa_init(fr, g.data_ptr(), None, None, cur.data_ptr())
     wa = torch.empty(wbytes, dtype=torch.uint8, device=engine.device)
     wb = torch.empty(wbytes, dtype=torch.uint8, device=engine.device)
-    W = lambda t: Window.make(t.data_ptr(), n, 0)
+    W = lambda t: Window.make(t.data_ptr(), t.numel() * t.element_size(), n, 0)
 
     def same(win, plain, what):
         engine.sync()

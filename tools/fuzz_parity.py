@@ -82,7 +82,7 @@ def check_ids(fr, g, n):
             if k == first and idb == 4 and can(fr, ALGO_TILED):                  # (a window of 4-byte ids IS an array of plain ids)
                 border = torch.empty(fr.words, dtype=torch.int32, device=eng.device)
                 eng.ctx.surface(fr, g.data_ptr(), None, None, border.data_ptr())
-                fn(fr, border.data_ptr(), Window.make(x.data_ptr(), n, 0)); eng.sync()
+                fn(fr, border.data_ptr(), Window.make(x.data_ptr(), x.numel() * x.element_size(), n, 0)); eng.sync()
                 if not torch.equal(x, y): return "from-the-mask form at k=%d: %d ids differ" % (k, int((x != y).sum().item()))
         cur, x = x, cur
         k //= 2
