@@ -653,6 +653,16 @@ int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const
             return 0;
         }
     }
+    // ... and the fused last pass of the 2-KB-table format at n = 512: 4 x 16 tiles on 512-thread workgroups (one x iteration per row; 46 KB of
+    // tables + mask words: three workgroups per CU, the same six waves per SIMD): 0.319 -> 0.291 ms (-8.9 %); the id passes gain nothing from
+    // it (profiles/r05/ab_id9_ch16_512.txt), and with the 4-KB tables 16 planes cost two of three workgroups per CU (+12 %, ab_id10_ch16_1024.txt).
+    if constexpr (ID::kTab == 512) {
+        if (fin && n == 512 && zlen % 16 == 0 && stride == k) {
+            launch_shape<ID, 16, 512, true>(a, pow2, wholeChains);
+            VP_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (deep) { if (fin) launch_shape<ID, 8, NTD, true>(a, pow2, wholeChains); else launch_shape<ID, 8, NTD, false>(a, pow2 && k >= 2, wholeChains); }
     else if (tiny) launch_shape<ID, 2, NTS, false>(a, false, false);
     else { if (fin) launch_shape<ID, 4, NTS, true>(a, false, false); else launch_shape<ID, 4, NTS, false>(a, false, false); }
