@@ -98,7 +98,11 @@ jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, co
     static_assert(!CLOSED || !FINAL, "closed tiles: id passes");
     constexpr int NC = PM ? 2 : 3;                                 // id columns a lane loads per source row
     constexpr int NI = NR * NC;
-    constexpr int CHT = CPT ? 1 : CH;                              // z tables: squared differences per output plane / one table of positions
+#ifndef VP_EXP_ZPOS
+#define VP_EXP_ZPOS 0
+#endif
+    constexpr bool ZPOS = CPT || (VP_EXP_ZPOS && FINAL && ID::kTab == 1024);
+    constexpr int CHT = ZPOS ? 1 : CH;                             // z tables: squared differences per output plane / one table of positions
     using B = typename std::conditional<FINAL, float, double>::type;
     __shared__ float PX[PXT];
     __shared__ float TY[RY][TAB];
@@ -155,7 +159,7 @@ jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, co
             const float sy = axis_pos(f.oy, i, f.vs), sz = axis_pos(f.oz, i, f.vs);
 #pragma unroll
             for (int j = 0; j < RY; ++j) { const float d = sy - py[j]; TY[j][si] = d * d; }
-            if (CPT) TZ[0][si] = sz;
+            if (ZPOS) TZ[0][si] = sz;
             else {
 #pragma unroll
                 for (int j = 0; j < CHT; ++j) { const float d = sz - pz[j]; TZ[j][si] = d * d; }
@@ -302,7 +306,7 @@ jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, co
             // bank conflicts, +6 .. +16 % time, profiles/r02/ab*.txt)
 #pragma unroll
             for (int a = alo; a <= ahi; ++a) d.dy2[a] = lds_f32(ty + a * (TAB * 4) + yo);
-            if constexpr (CPT) {
+            if constexpr (ZPOS) {
                 const float sz = lds_f32(tz + zo);                          // seed z position; the squares per output plane are formed here
 #pragma unroll
                 for (int o = olo; o <= ohi; ++o) { const float dzv = sz - pz[o]; d.dz2[o] = dzv * dzv; }
@@ -573,7 +577,10 @@ template <int V> using int_c = std::integral_constant<int, V>;
 template <class ID, int CH, int NT, bool F>
 void launch_shape(const DenseArgs& a, bool pairsOk, bool wholeChains)
 {
-    constexpr int RY = (ID::kTab == 512 && !F && CH == 8) ? 8 : 4;
+#ifndef VP_EXP_ID9_8x16
+#define VP_EXP_ID9_8x16 0
+#endif
+    constexpr int RY = (ID::kTab == 512 && !F && (CH == 8 || (VP_EXP_ID9_8x16 && CH == 16))) ? 8 : 4;
     constexpr bool canFull = CH >= 8 && (ID::kTab != 1024 || F);
     auto go = [&](auto pm) {
         constexpr int PM = decltype(pm)::value;
@@ -662,7 +669,23 @@ int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const
             VP_HIP(hipGetLastError());
             return 0;
         }
+#if VP_EXP_ID9_8x16
+        if (!fin && n == 512 && zlen % 16 == 0 && stride == k) {
+            launch_shape<ID, 16, 512, false>(a, pow2 && k >= 2, wholeChains);
+            VP_HIP(hipGetLastError());
+            return 0;
+        }
+#endif
     }
+#if VP_EXP_ZPOS == 2
+    if constexpr (ID::kTab == 1024) {
+        if (fin && zlen % 16 == 0 && stride == k) {
+            launch_shape<ID, 16, NTD, true>(a, pow2, wholeChains);
+            VP_HIP(hipGetLastError());
+            return 0;
+        }
+    }
+#endif
     if (deep) { if (fin) launch_shape<ID, 8, NTD, true>(a, pow2, wholeChains); else launch_shape<ID, 8, NTD, false>(a, pow2 && k >= 2, wholeChains); }
     else if (tiny) launch_shape<ID, 2, NTS, false>(a, false, false);
     else { if (fin) launch_shape<ID, 4, NTS, true>(a, false, false); else launch_shape<ID, 4, NTS, false>(a, false, false); }
