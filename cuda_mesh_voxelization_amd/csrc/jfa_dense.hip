@@ -98,11 +98,8 @@ jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, co
     static_assert(!CLOSED || !FINAL, "closed tiles: id passes");
     constexpr int NC = PM ? 2 : 3;                                 // id columns a lane loads per source row
     constexpr int NI = NR * NC;
-#ifndef VP_EXP_ZPOS
-#define VP_EXP_ZPOS 0
-#endif
-    constexpr bool ZPOS = CPT || (VP_EXP_ZPOS && FINAL && ID::kTab == 1024);
-    constexpr int CHT = ZPOS ? 1 : CH;                             // z tables: squared differences per output plane / one table of positions
+    constexpr int CHT = CPT ? 1 : CH;                              // z tables: squared differences per output plane / one table of positions
+                                                                   // (one table for the fused last pass at n = 1024 too: +4 .. +7 %, profiles/r05/ab_zpos_last_1024.txt)
     using B = typename std::conditional<FINAL, float, double>::type;
     __shared__ float PX[PXT];
     __shared__ float TY[RY][TAB];
@@ -159,7 +156,7 @@ jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, co
             const float sy = axis_pos(f.oy, i, f.vs), sz = axis_pos(f.oz, i, f.vs);
 #pragma unroll
             for (int j = 0; j < RY; ++j) { const float d = sy - py[j]; TY[j][si] = d * d; }
-            if (ZPOS) TZ[0][si] = sz;
+            if (CPT) TZ[0][si] = sz;
             else {
 #pragma unroll
                 for (int j = 0; j < CHT; ++j) { const float d = sz - pz[j]; TZ[j][si] = d * d; }
@@ -306,7 +303,7 @@ jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, co
             // bank conflicts, +6 .. +16 % time, profiles/r02/ab*.txt)
 #pragma unroll
             for (int a = alo; a <= ahi; ++a) d.dy2[a] = lds_f32(ty + a * (TAB * 4) + yo);
-            if constexpr (ZPOS) {
+            if constexpr (CPT) {
                 const float sz = lds_f32(tz + zo);                          // seed z position; the squares per output plane are formed here
 #pragma unroll
                 for (int o = olo; o <= ohi; ++o) { const float dzv = sz - pz[o]; d.dz2[o] = dzv * dzv; }
@@ -543,14 +540,16 @@ static uint32_t tail_split(const vp_ctx* ctx, uint32_t tiles, uint32_t wgPerCu)
     return std::min(tiles / 2u, slots * 4u / 3u);
 }
 
-namespace {
-
 struct DenseArgs {
     vp_ctx* ctx; Frame f; uint32_t k, ka;
     const char *in, *inB; char *out, *outB; const char* none_row;
     const uint32_t* words; float fill; float* sdf;
     uint32_t nresY, ylen, nres, zlen;                              // residue classes and chain lengths of the rows / of the frame's planes
 };
+// the 8 x 16 tiles of the 2-KB-table format at n = 512: a build part of their own (the largest kernels of the file)
+int launch_dense_id9_tile16(const DenseArgs& a, bool pairsOk);
+
+namespace {
 
 template <class ID, int RY, int CH, int NT, bool F, int PM, int CL = 0, bool FULL = false>
 void launch_tile(const DenseArgs& a)
@@ -574,17 +573,16 @@ void launch_tile(const DenseArgs& a)
 // form (7 % faster there: 0.370 vs 0.396 ms; with the 4-KB tables pairs win by 3 %).
 template <int V> using int_c = std::integral_constant<int, V>;
 
-template <class ID, int CH, int NT, bool F>
+// ALWAYS_FULL: the caller only comes with whole chains (no instantiation of the run-time row / plane counts).
+template <class ID, int CH, int NT, bool F, bool ALWAYS_FULL = false>
 void launch_shape(const DenseArgs& a, bool pairsOk, bool wholeChains)
 {
-#ifndef VP_EXP_ID9_8x16
-#define VP_EXP_ID9_8x16 0
-#endif
-    constexpr int RY = (ID::kTab == 512 && !F && (CH == 8 || (VP_EXP_ID9_8x16 && CH == 16))) ? 8 : 4;
+    constexpr int RY = (ID::kTab == 512 && !F && CH >= 8) ? 8 : 4;
     constexpr bool canFull = CH >= 8 && (ID::kTab != 1024 || F);
     auto go = [&](auto pm) {
         constexpr int PM = decltype(pm)::value;
-        if constexpr (canFull) {
+        if constexpr (ALWAYS_FULL) { launch_tile<ID, RY, CH, NT, F, PM, 0, true>(a); return; }
+        else if constexpr (canFull) {
             if (wholeChains && a.ylen % RY == 0) { launch_tile<ID, RY, CH, NT, F, PM, 0, true>(a); return; }
         }
         launch_tile<ID, RY, CH, NT, F, PM>(a);
@@ -602,12 +600,14 @@ void launch_shape(const DenseArgs& a, bool pairsOk, bool wholeChains)
     go(int_c<0>{});
 }
 
-template <class ID>
+// FIN: the last pass (fused with the id -> sdf conversion); a template parameter so that the id passes and the last pass of a format are
+// separate build parts.
+template <class ID, bool FIN>
 int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride,
                  const uint32_t* d_words, float fill, float* d_sdf)
 {
     const uint32_t nz = f.z1 - f.z0, n = f.n;
-    const bool fin = d_sdf != nullptr;
+    constexpr bool fin = FIN;
     const uint32_t nres = std::min(k, nz), zlen = (nz + k - 1) / k;
     const uint32_t nresY = std::min(k, n), ylen = (n + k - 1) / k;
     // Plane chains that are not a multiple of eight (the regions of the multi-GPU pipelines: 288 planes at k = 32 are chains of nine).  A
@@ -622,8 +622,8 @@ int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const
         IdWin inB = in, outB = out;
         inB.at += planesA; outB.at += planesA;
         const size_t wordPlane = (size_t)n * f.w, sdfPlane = (size_t)n * n;
-        VP_TRY(launch_dense<ID>(ctx, fa, k, in, out, stride, d_words, fill, d_sdf));
-        return launch_dense<ID>(ctx, fb, k, inB, outB, stride, d_words ? d_words + planesA * wordPlane : nullptr, fill, d_sdf ? d_sdf + planesA * sdfPlane : nullptr);
+        VP_TRY((launch_dense<ID, FIN>(ctx, fa, k, in, out, stride, d_words, fill, d_sdf)));
+        return launch_dense<ID, FIN>(ctx, fb, k, inB, outB, stride, d_words ? d_words + planesA * wordPlane : nullptr, fill, d_sdf ? d_sdf + planesA * sdfPlane : nullptr);
     }
     VP_TRY(ensure_none_rows(ctx));
     DenseArgs a{ctx, f, k, stride, win_words(in, n, in.at), win_compact(n) ? win_bytes_plane(in, n, in.at) : nullptr,
@@ -640,76 +640,78 @@ int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const
     // 86 KB of tables need 1024 threads -- 128 VGPRs + 25 spilled -- and buy 5 % of that one pass; 8-row tiles for every pass cost 20 .. 38 %:
     // profiles/r05/ab_idc_tiles_2048.txt.)
     if constexpr (!std::is_same<ID, IdC>::value) {
-        if (pow2 && !fin && stride == k && f.z0 == 0 && f.z1 == n && n == 8u * k && n % NTD == 0) {
-            launch_tile<ID, 8, 8, NTD, false, 8, 3, ID::kTab == 512>(a);
-            VP_HIP(hipGetLastError());
-            return 0;
+        if constexpr (!fin) {
+            if (pow2 && stride == k && f.z0 == 0 && f.z1 == n && n == 8u * k && n % NTD == 0) {
+                launch_tile<ID, 8, 8, NTD, false, 8, 3, ID::kTab == 512>(a);
+                VP_HIP(hipGetLastError());
+                return 0;
+            }
         }
     }
     // one 8-plane tile per chain also where the chain has 5 .. 7 members (10 plane iterations against 2 x 6); chains of one or two planes
     // (the remainders of the split above, and the slabs of a pass whose step spans whole slabs): 2-plane tiles
     const bool deep = zlen % 8 == 0 || (zlen > 4 && zlen < 8);
-    const bool tiny = !fin && zlen <= 2;
+    const bool tiny = zlen <= 2;
     // Compact ids: 16-plane tiles where the chains allow it.  The kernel streams over its planes (three output planes are live whatever CH is) and
     // this format keeps ONE table of z positions, so a longer tile costs neither registers nor LDS, only code: (CH + 2) / CH plane reads per
     // output plane fall from 1.25 to 1.125 -- n = 2048: tile passes -2.7 %, fused last pass -6.2 % (profiles/r05/ab_ch16_2048.txt).
     if constexpr (std::is_same<ID, IdC>::value) {
         if (zlen % 16 == 0 && stride == k) {
-            if (fin) launch_shape<ID, 16, NTD, true>(a, pow2, wholeChains); else launch_shape<ID, 16, NTD, false>(a, pow2 && k >= 2, wholeChains);
+            launch_shape<ID, 16, NTD, fin>(a, pow2 && (fin || k >= 2), wholeChains);
             VP_HIP(hipGetLastError());
             return 0;
         }
     }
-    // ... and the fused last pass of the 2-KB-table format at n = 512: 4 x 16 tiles on 512-thread workgroups (one x iteration per row; 46 KB of
-    // tables + mask words: three workgroups per CU, the same six waves per SIMD): 0.319 -> 0.291 ms (-8.9 %); the id passes gain nothing from
-    // it (profiles/r05/ab_id9_ch16_512.txt), and with the 4-KB tables 16 planes cost two of three workgroups per CU (+12 %, ab_id10_ch16_1024.txt).
+    // ... and the 2-KB-table format at n = 512, on 512-thread workgroups (one x iteration per row).  The fused last pass on 4 x 16 tiles (46 KB
+    // of tables + mask words: three workgroups per CU, the same six waves per SIMD): 0.319 -> 0.291 ms (-8.9 %, profiles/r05/ab_id9_ch16_512.txt).
+    // The id passes on 8 x 16 tiles (50 KB: two workgroups per CU = the four waves per SIMD of the 8 x 8 tiles; halo factor 1.41 instead of
+    // 1.56): -1.6 % (ab_id9_8x16_512.txt; on 4 x 16 tiles +-0).  With the 4-KB tables 16 planes cost two of three workgroups per CU: +12 %
+    // (ab_id10_ch16_1024.txt).
     if constexpr (ID::kTab == 512) {
-        if (fin && n == 512 && zlen % 16 == 0 && stride == k) {
-            launch_shape<ID, 16, 512, true>(a, pow2, wholeChains);
-            VP_HIP(hipGetLastError());
-            return 0;
-        }
-#if VP_EXP_ID9_8x16
-        if (!fin && n == 512 && zlen % 16 == 0 && stride == k) {
-            launch_shape<ID, 16, 512, false>(a, pow2 && k >= 2, wholeChains);
-            VP_HIP(hipGetLastError());
-            return 0;
-        }
-#endif
-    }
-#if VP_EXP_ZPOS == 2
-    if constexpr (ID::kTab == 1024) {
-        if (fin && zlen % 16 == 0 && stride == k) {
-            launch_shape<ID, 16, NTD, true>(a, pow2, wholeChains);
+        if (n == 512 && zlen % 16 == 0 && stride == k && wholeChains) {      // (n = 512 = 2^9: every chain is whole)
+            if constexpr (fin) launch_shape<ID, 16, 512, true, true>(a, pow2, true);
+            else VP_TRY(launch_dense_id9_tile16(a, pow2 && k >= 2));
             VP_HIP(hipGetLastError());
             return 0;
         }
     }
-#endif
-    if (deep) { if (fin) launch_shape<ID, 8, NTD, true>(a, pow2, wholeChains); else launch_shape<ID, 8, NTD, false>(a, pow2 && k >= 2, wholeChains); }
-    else if (tiny) launch_shape<ID, 2, NTS, false>(a, false, false);
-    else { if (fin) launch_shape<ID, 4, NTS, true>(a, false, false); else launch_shape<ID, 4, NTS, false>(a, false, false); }
+    if (deep) launch_shape<ID, 8, NTD, fin>(a, pow2 && (fin || k >= 2), wholeChains);
+    else if constexpr (!fin) { if (tiny) launch_shape<ID, 2, NTS, false>(a, false, false); else launch_shape<ID, 4, NTS, false>(a, false, false); }
+    else launch_shape<ID, 4, NTS, true>(a, false, false);
     VP_HIP(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-// launch_dense<ID> per id format, one build part each (-DVP_DENSE_PART=1|2|3; undefined: all of them in one unit)
+// launch_dense<ID, FIN> per id format and pass kind, one build part each (-DVP_DENSE_PART=1..7; undefined: all of them in one unit)
 #ifndef VP_DENSE_PART
 #define VP_DENSE_PART 0
 #endif
+#define VP_DENSE_ENTRY(PART, NAME, ID, FIN)                                                                                                \
+    int NAME(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf) \
+    { return launch_dense<ID, FIN>(ctx, f, k, in, out, stride, d_words, fill, d_sdf); }
 #if VP_DENSE_PART == 0 || VP_DENSE_PART == 1
-int launch_dense_id9(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf)
-{ return launch_dense<Id9>(ctx, f, k, in, out, stride, d_words, fill, d_sdf); }
+VP_DENSE_ENTRY(1, launch_dense_id9_pass, Id9, false)
 #endif
 #if VP_DENSE_PART == 0 || VP_DENSE_PART == 2
-int launch_dense_id10(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf)
-{ return launch_dense<Id10>(ctx, f, k, in, out, stride, d_words, fill, d_sdf); }
+VP_DENSE_ENTRY(2, launch_dense_id9_last, Id9, true)
 #endif
 #if VP_DENSE_PART == 0 || VP_DENSE_PART == 3
-int launch_dense_idc(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf)
-{ return launch_dense<IdC>(ctx, f, k, in, out, stride, d_words, fill, d_sdf); }
+VP_DENSE_ENTRY(3, launch_dense_id10_pass, Id10, false)
 #endif
+#if VP_DENSE_PART == 0 || VP_DENSE_PART == 4
+VP_DENSE_ENTRY(4, launch_dense_id10_last, Id10, true)
+#endif
+#if VP_DENSE_PART == 0 || VP_DENSE_PART == 5
+VP_DENSE_ENTRY(5, launch_dense_idc_pass, IdC, false)
+#endif
+#if VP_DENSE_PART == 0 || VP_DENSE_PART == 6
+VP_DENSE_ENTRY(6, launch_dense_idc_last, IdC, true)
+#endif
+#if VP_DENSE_PART == 0 || VP_DENSE_PART == 7
+int launch_dense_id9_tile16(const DenseArgs& a, bool pairsOk) { launch_shape<Id9, 16, 512, false, true>(a, pairsOk, true); return 0; }
+#endif
+#undef VP_DENSE_ENTRY
 
 }  // namespace vp

@@ -545,9 +545,14 @@ int launch_win_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, co
                     const uint32_t* d_words, float fill, float* d_sdf)
 {
     ProfScope p(ctx, d_sdf ? VP_K_JFA_LAST : k * 4 >= f.n ? VP_K_JFA_SPARSE : VP_K_JFA_DENSE);
-    if (win_compact(f.n)) return launch_dense_idc(ctx, f, k, in, out, stride, d_words, fill, d_sdf);
-    if (f.n <= 512)       return launch_dense_id9(ctx, f, k, in, out, stride, d_words, fill, d_sdf);
-    return launch_dense_id10(ctx, f, k, in, out, stride, d_words, fill, d_sdf);
+    if (d_sdf) {
+        if (win_compact(f.n)) return launch_dense_idc_last(ctx, f, k, in, out, stride, d_words, fill, d_sdf);
+        if (f.n <= 512)       return launch_dense_id9_last(ctx, f, k, in, out, stride, d_words, fill, d_sdf);
+        return launch_dense_id10_last(ctx, f, k, in, out, stride, d_words, fill, d_sdf);
+    }
+    if (win_compact(f.n)) return launch_dense_idc_pass(ctx, f, k, in, out, stride, d_words, fill, d_sdf);
+    if (f.n <= 512)       return launch_dense_id9_pass(ctx, f, k, in, out, stride, d_words, fill, d_sdf);
+    return launch_dense_id10_pass(ctx, f, k, in, out, stride, d_words, fill, d_sdf);
 }
 
 bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo)

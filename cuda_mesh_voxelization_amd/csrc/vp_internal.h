@@ -156,9 +156,11 @@ int launch_win_clear(vp_ctx* ctx, uint32_t n, const IdWin& w);
 // above it in the window (stride = k for a window of consecutive planes).  d_sdf != nullptr: the last pass, fused with the id -> sdf conversion.
 int launch_win_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride,
                     const uint32_t* d_words, float fill, float* d_sdf);
-int launch_dense_id9(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf);
-int launch_dense_id10(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf);
-int launch_dense_idc(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf);
+#define VP_DENSE_DECL(NAME) int NAME(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t stride, const uint32_t* d_words, float fill, float* d_sdf)
+VP_DENSE_DECL(launch_dense_id9_pass);  VP_DENSE_DECL(launch_dense_id9_last);      // per id format; _last = fused with the id -> sdf conversion
+VP_DENSE_DECL(launch_dense_id10_pass); VP_DENSE_DECL(launch_dense_id10_last);
+VP_DENSE_DECL(launch_dense_idc_pass);  VP_DENSE_DECL(launch_dense_idc_last);
+#undef VP_DENSE_DECL
 // jfa_first_two.hip: passes n/2 and n/4 of a whole grid from its border mask into a window of n planes
 int launch_win_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, const IdWin& out);
 int launch_extract_count(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, int mode, uint64_t* h_count);
