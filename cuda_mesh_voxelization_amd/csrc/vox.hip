@@ -500,14 +500,20 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
             ctx->vox_total_pending = false;
             ctx->vox_total_seen = std::max<uint64_t>(ctx->vox_total_seen, ctx->vox_total_host[0]);
             ctx->vox_nbig_seen = std::max<uint64_t>(ctx->vox_nbig_seen, ctx->vox_total_host[1]);
+            ctx->vox_counts_known = true;
         }
+        // A context that has never met a large triangle (every count read back so far was zero: fine meshes, like the benchmark's) gives the
+        // record list no room and leaves the three list kernels out -- they would find nothing to do and cost their launches (0.02 ms of a
+        // 0.07-ms voxelization at n = 512).  Should a large triangle turn up all the same, vox_setup walks it in place (slow for that one call,
+        // correct: the path of a full record list), its count comes back, and every later call takes the tile stage again.
+        const bool noLists = ctx->vox_counts_known && ctx->vox_nbig_seen == 0;
         const size_t want = std::max<size_t>((size_t)1 << 20, (size_t)ctx->vox_total_seen + ctx->vox_total_seen / 4);
         VP_TRY(reserve(ctx, ctx->pairs, want * 4));
         // record list: 64 Ki records (5 MiB) or what earlier calls needed + 25 %, never more than one per triangle
         const size_t wantRec = std::min<size_t>(ntris, std::max<size_t>((size_t)1 << 16, (size_t)ctx->vox_nbig_seen + ctx->vox_nbig_seen / 4));
         VP_TRY(reserve(ctx, ctx->rec, wantRec * (size_t)kRecDwords * 4));
         uint4* rec = (uint4*)ctx->rec.ptr;
-        uint32_t rcap = (uint32_t)std::min<size_t>(ctx->rec.bytes / ((size_t)kRecDwords * 4), ntris);
+        uint32_t rcap = noLists ? 0u : (uint32_t)std::min<size_t>(ctx->rec.bytes / ((size_t)kRecDwords * 4), ntris);
 #ifdef VP_TEST_HOOKS   // test builds only (libvphip_hooks.so): force the walk-in-place path
         if (const char* e = getenv("VP_VOX_REC_CAP")) rcap = std::min<uint32_t>(rcap, (uint32_t)strtoul(e, nullptr, 10));
 #endif
@@ -522,7 +528,7 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
             hipLaunchKernelGGL(vox_setup, dim3(tblocks), dim3(256), 0, st, f, d_xyz, nverts, d_tri, ntris, rec, rcap,
                                d_nbig, cnt, tog);
         }
-        {
+        if (!noLists) {
             ProfScope p(ctx, VP_K_VOX_SCAN);
             hipLaunchKernelGGL(vox_scan, dim3(1), dim3(1024), 0, st, cnt, numTiles, off, cur);
         }
@@ -532,16 +538,16 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
             VP_HIP(hipEventCreateWithFlags(&ctx->vox_total_event, hipEventDisableTiming));
         }
         if (!ctx->vox_total_pending) {                             // lazily: the next call may grow the queue from it
-            VP_HIP(hipMemcpyAsync(ctx->vox_total_host, off + numTiles, 4, hipMemcpyDeviceToHost, st));
+            if (!noLists) VP_HIP(hipMemcpyAsync(ctx->vox_total_host, off + numTiles, 4, hipMemcpyDeviceToHost, st));   // (no scan: the old figure stays)
             VP_HIP(hipMemcpyAsync(ctx->vox_total_host + 1, d_nbig, 4, hipMemcpyDeviceToHost, st));
             VP_HIP(hipEventRecord(ctx->vox_total_event, st));
             ctx->vox_total_pending = true;
         }
-        {
+        if (!noLists) {
             ProfScope p(ctx, VP_K_VOX_SCATTER);
             hipLaunchKernelGGL(vox_scatter, dim3(std::min<unsigned>(tblocks, 1024u)), dim3(256), 0, st, f, rec, d_nbig, rcap, cur, pairs, pcap);
         }
-        {
+        if (!noLists) {
             ProfScope p(ctx, VP_K_VOX_TILE);
             hipLaunchKernelGGL(vox_tile, dim3(numTiles), dim3(256), 0, st, f, rec, d_nbig, rcap, off, pairs, pcap, tog);
         }

@@ -73,6 +73,7 @@ struct vp_ctx {
     bool vox_total_pending = false;
     uint64_t vox_total_seen = 0;
     uint64_t vox_nbig_seen = 0;                // large triangles an earlier call counted (sizes the record list)
+    bool vox_counts_known = false;             // at least one such count has come back
     // profiling
     bool prof_on = false;
     uint64_t prof_mask = ~0ull;                                    // timing keys that get events (vp_prof_select)

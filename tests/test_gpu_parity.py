@@ -167,6 +167,46 @@ def test_voxelize_record_list_overflow_path(engine):
         assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (cap, p.stdout[-500:], p.stderr[-2000:])
 
 
+def test_voxelize_without_list_kernels_and_the_first_large_triangle(engine):
+    """A context that has only ever counted zero large triangles leaves the three list kernels out (the record list gets no room).  The
+    first mesh WITH large triangles after that is walked in place by the setup kernel -- correct, slow once --, its count comes back, and
+    the tile stage runs again from the next call on.  Fresh context; bitmasks against the oracle at every step."""
+    ctx = capi.Context(0)
+    try:
+        ctx.set_stream(torch.cuda.current_stream(engine.device).cuda_stream, external=True)
+        n = 256
+        fine = M.import_mesh(M.asset("bunny.obj"))
+        coarse = M.import_mesh(M.asset("d20.obj"))                    # 20 grid-spanning triangles
+
+        def run(mesh, prof=False):
+            xyz, tri = mesh
+            origin, vs = M.frame([xyz], n)
+            fr = Frame.make(n, vs, origin)
+            dx, dt = engine.mesh_to_device(xyz, tri)
+            g = engine.new_grid(fr)
+            if prof:
+                ctx.prof_reset(); ctx.prof_enable(True)
+            ctx.voxelize(fr, g.data_ptr(), dx.data_ptr(), dx.shape[0], dt.data_ptr(), dt.shape[0], ALGO_TILED, False)
+            ctx.sync()
+            keys = set()
+            if prof:
+                ctx.prof_enable(False); keys = set(ctx.prof())
+            assert np.array_equal(engine.words_to_numpy(g), O.voxelize(xyz, tri, n, vs, origin))
+            return keys
+
+        assert "vox_tile" in run(fine, prof=True)                      # first call: nothing known yet, the whole sequence
+        run(fine)                                                     # its counts (zero large triangles) have landed by now ...
+        keys = run(fine, prof=True)
+        assert "vox_setup" in keys and not ({"vox_scan", "vox_scatter", "vox_tile"} & keys)      # ... so the list kernels stay out
+        keys = run(coarse, prof=True)                                 # large triangles all the same: walked in place by vox_setup
+        assert not ({"vox_scan", "vox_scatter", "vox_tile"} & keys)
+        run(coarse)
+        assert "vox_tile" in run(coarse, prof=True)                    # the count came back: the tile stage is on again, for good
+        assert "vox_tile" in run(fine, prof=True)
+    finally:
+        ctx.close()
+
+
 def test_prof_select_times_only_the_named_kernels(engine):
     """vp_prof_select: bench.py brackets only the dominant kernel inside its timed region; the launch counts are exact."""
     n = 256
