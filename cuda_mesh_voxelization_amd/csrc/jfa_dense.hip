@@ -82,7 +82,7 @@ constexpr int dense_waves()
 }
 template <class ID, int RY, int CH, int NT, bool FINAL, int PM, int CLOSED = 0, bool FULL = false>
 __global__ void __launch_bounds__(NT, (dense_waves<ID, RY, NT, FINAL>()))
-jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, const char* __restrict__ inB, char* __restrict__ out, char* __restrict__ outB,
+jfa_pass_dense(Frame f, uint32_t kArg, uint32_t ka, const char* __restrict__ in, const char* __restrict__ inB, char* __restrict__ out, char* __restrict__ outB,
                const char* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf,
                uint32_t tilesY, uint32_t tiles, uint32_t splitTiles)
 {
@@ -109,6 +109,7 @@ jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, co
     __shared__ uint32_t WM[(FINAL && !GM) ? RY * CH * (TAB / 32) : 1];
 
     const int N = (int)f.n;
+    const uint32_t k = FINAL ? 1u : kArg;                          // the fused last pass IS the pass with k = 1 (launch_dense refuses anything else)
     const int K = (int)k;
     const int nzl = (int)(f.z1 - f.z0);
     const uint32_t tid = threadIdx.x;
@@ -440,11 +441,13 @@ jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, co
             uint32_t mw[RY] = {};
             if constexpr (FINAL && GM) {         // bitmask words of the rows stored after this plane: requested before its evaluation
                 if (P >= 1 && P - 1 < nout) {
+                    // one resource per output plane (its rows from ybase on), the row as the scalar offset of the load: no address arithmetic per row
+                    const char* wpl = opaque_uniform(reinterpret_cast<const char*>(words) + ((size_t)(lbase + (P - 1) * K) * N + ybase) * (size_t)(f.w * 4u));
+                    const __amdgpu_buffer_rsrc_t wr = row_resource(wpl, (uint32_t)(RY * K) * f.w * 4u);
 #pragma unroll
                     for (int a = 0; a < RY; ++a) {
                         if (a >= yout) continue;
-                        const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (P - 1) * K) * N + (ybase + a * K);
-                        mw[a] = words[rowIdx * f.w + (x >> 5)];
+                        mw[a] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wr, (int)((x >> 5) << 2), (int)((uint32_t)(a * K) * f.w * 4u), 0);
                     }
                 }
             }
@@ -456,12 +459,16 @@ jfa_pass_dense(Frame f, uint32_t k, uint32_t ka, const char* __restrict__ in, co
             if (!(CZ && (P == -1 || P == CH))) scatter(P, w);        // closed tiles have no plane before the first or after the last
             if constexpr (FINAL) {
                 if (P >= 1 && P - 1 < nout) {
+                    // one resource per output plane, the row as the scalar offset of the store (with the mask loads above: 2,556 -> 1,560 scalar instructions
+                    // per tile, no 64-bit vector address; fused last pass -1.8 % / -5.6 % / -1.9 % at n = 512 / 1024 / 2048, profiles/r05/ab_last_salu.txt)
+                    const char* spl = opaque_uniform(reinterpret_cast<const char*>(sdf) + ((size_t)(lbase + (P - 1) * K) * N + ybase) * (size_t)rowBytes);
+                    const __amdgpu_buffer_rsrc_t sr = row_resource(spl, (uint32_t)((RY - 1) * K + 1) * rowBytes);
 #pragma unroll
                     for (int a = 0; a < RY; ++a) {
                         if (a >= yout) continue;
-                        const size_t rowIdx = (size_t)(opaque_uniform((size_t)lbase) + (P - 1) * K) * N + (ybase + a * K);
                         const bool set = ((GM ? mw[a] : WM[(a * CH + (P - 1)) * (TAB / 32) + (x >> 5)]) >> (x & 31)) & 1u;
-                        row_store<kStoreAux>(set ? best[a][P - 1] : copysignf(best[a][P - 1], fill), row_resource(sdf + rowIdx * N, (uint32_t)N * 4u), x * 4u);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(set ? best[a][P - 1] : copysignf(best[a][P - 1], fill)), sr, (int)xo,
+                                                              (int)((uint32_t)(a * K) * rowBytes), kStoreAux);
                     }
                 }
             } else {
@@ -625,6 +632,7 @@ int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const
         VP_TRY((launch_dense<ID, FIN>(ctx, fa, k, in, out, stride, d_words, fill, d_sdf)));
         return launch_dense<ID, FIN>(ctx, fb, k, inB, outB, stride, d_words ? d_words + planesA * wordPlane : nullptr, fill, d_sdf ? d_sdf + planesA * sdfPlane : nullptr);
     }
+    if (FIN && k != 1) return set_error(VP_ERR_INVALID, "jfa_pass_dense: the fused last pass is the pass with k = 1");
     VP_TRY(ensure_none_rows(ctx));
     DenseArgs a{ctx, f, k, stride, win_words(in, n, in.at), win_compact(n) ? win_bytes_plane(in, n, in.at) : nullptr,
                 win_words(out, n, out.at), win_compact(n) ? win_bytes_plane(out, n, out.at) : nullptr,
