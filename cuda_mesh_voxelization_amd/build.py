@@ -19,7 +19,7 @@ LIB = os.path.join(PKG, "libvphip.so")
 CLI = os.path.join(PKG, "vpcli")
 
 HIP_SOURCES = ["capi.hip", "vox.hip", "csg.hip", "jfa_seed.hip", "jfa_first_two.hip", "jfa_dense.hip", "extract.hip", "multi.hip"]
-DENSE_PARTS = 7                  # jfa_dense.hip is compiled once per id format and pass kind, side by side (-DVP_DENSE_PART=1..7, see the end of the file)
+DENSE_PARTS = 10                 # jfa_dense.hip is compiled once per id format and pass kind, side by side (-DVP_DENSE_PART=1..10, see the end of the file)
 HOOK_SOURCES = ["vox.hip", "multi.hip"]     # the sources that read test hooks from the environment under -DVP_TEST_HOOKS (libvphip_hooks.so)
 HOOKS_LIB = os.path.join(PKG, "libvphip_hooks.so")
 # -ffp-contract=off is part of the parity contract: an FMA changes the bitmask / sdf bits.

@@ -14,10 +14,10 @@ HOOKS_LIB_PATH = os.path.join(PKG, "libvphip_hooks.so")
 ALGO_NAIVE, ALGO_TILED = 1, 2
 OP_VOID, OP_UNION, OP_INTERSECTION, OP_DIFFERENCE = 0, 1, 2, 3
 EXTRACT_SET, EXTRACT_EXPOSED, EXTRACT_FACES = 0, 1, 2
-MULTI_HALO, MULTI_GHOST, MULTI_HYBRID = 0, 1, 2
+MULTI_HALO, MULTI_GHOST, MULTI_HYBRID, MULTI_TRANSPOSE = 0, 1, 2, 3
 
 KERNELS = ["vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
-           "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract", "vox_zero"]
+           "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract", "vox_zero", "jfa_redeal"]
 JFA_PASS_KEYS = ("jfa_pass", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last")
 
 # every symbol include/vphip.h declares (tests check the library exports all of them)
@@ -29,6 +29,7 @@ SYMBOLS = [
     "vp_jfa_finalize", "vp_jfa_last_pass", "vp_jfa_can_start_from_mask", "vp_jfa_can_fuse_first_two",
     "vp_jfa_window_bytes", "vp_jfa_window_span", "vp_jfa_window_clear", "vp_jfa_window_init", "vp_jfa_window_first_pass", "vp_jfa_window_first_two",
     "vp_jfa_window_pass", "vp_jfa_window_last_pass",
+    "vp_jfa_cyclic_passes", "vp_jfa_window_first_two_cyclic", "vp_jfa_window_pass_cyclic", "vp_jfa_window_interleave",
     "vp_surface", "vp_extract_count", "vp_extract", "vp_voxelize_host", "vp_csg_host", "vp_jfa_host",
     "vp_prof_enable", "vp_prof_select", "vp_prof_reset", "vp_prof_get", "vp_prof_name",
     "vp_multi_create", "vp_multi_destroy", "vp_multi_count", "vp_multi_ctx", "vp_multi_sync", "vp_multi_set_mesh", "vp_multi_voxelize",
@@ -150,6 +151,10 @@ def lib():
         "vp_jfa_window_first_two": (ctypes.c_int, [_vp, fp, _vp, wp]),
         "vp_jfa_window_pass": (ctypes.c_int, [_vp, fp, ctypes.c_uint32, wp, wp, ctypes.c_uint32]),
         "vp_jfa_window_last_pass": (ctypes.c_int, [_vp, fp, wp, wp, ctypes.c_uint32, _vp, ctypes.c_float, _vp]),
+        "vp_jfa_cyclic_passes": (ctypes.c_int, [fp, ctypes.c_uint32]),
+        "vp_jfa_window_first_two_cyclic": (ctypes.c_int, [_vp, fp, _vp, wp, ctypes.c_uint32, ctypes.c_uint32]),
+        "vp_jfa_window_pass_cyclic": (ctypes.c_int, [_vp, fp, ctypes.c_uint32, wp, wp, ctypes.c_uint32, ctypes.c_uint32]),
+        "vp_jfa_window_interleave": (ctypes.c_int, [_vp, fp, wp, wp, ctypes.c_uint32, ctypes.c_uint32]),
         "vp_surface": (ctypes.c_int, [_vp, fp, _vp, _vp, _vp, _vp]),
         "vp_extract_count": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
         "vp_extract": (ctypes.c_int, [_vp, fp, _vp, ctypes.c_int, _vp, _vp, _vp, _sz]),
@@ -330,6 +335,21 @@ class Context:
     def jfa_window_last_pass(self, frame: Frame, win_in: Window, win_scratch: Window, d_words_region: int, fill: float, d_sdf_region: int, stride: int = 1):
         check(lib().vp_jfa_window_last_pass(self._h, ctypes.byref(frame), ctypes.byref(win_in), ctypes.byref(win_scratch), stride,
                                             _vp(d_words_region), fill, _vp(d_sdf_region)))
+
+    # -- cyclic plane distribution (the first phase of the transposed multi-GPU pipeline)
+    @staticmethod
+    def jfa_cyclic_passes(frame: Frame, ranks: int) -> int:
+        """passes of the sequence n/2, n/4, ... whose step is a multiple of `ranks`, counted from the first (0: the grid cannot be dealt cyclically)"""
+        return int(lib().vp_jfa_cyclic_passes(ctypes.byref(frame), ranks))
+
+    def jfa_window_first_two_cyclic(self, frame: Frame, d_border_grid: int, win: Window, ranks: int, rank: int):
+        check(lib().vp_jfa_window_first_two_cyclic(self._h, ctypes.byref(frame), _vp(d_border_grid), ctypes.byref(win), ranks, rank))
+
+    def jfa_window_pass_cyclic(self, frame: Frame, k: int, win_in: Window, win_out: Window, ranks: int, rank: int):
+        check(lib().vp_jfa_window_pass_cyclic(self._h, ctypes.byref(frame), k, ctypes.byref(win_in), ctypes.byref(win_out), ranks, rank))
+
+    def jfa_window_interleave(self, frame: Frame, win_in: Window, win_out: Window, ranks: int, count: int):
+        check(lib().vp_jfa_window_interleave(self._h, ctypes.byref(frame), ctypes.byref(win_in), ctypes.byref(win_out), ranks, count))
 
     def surface(self, frame: Frame, d_words: int, d_below, d_above, d_border: int):
         check(lib().vp_surface(self._h, ctypes.byref(frame), _vp(d_words), _vp(d_below or None),

@@ -129,7 +129,7 @@ static void grid_written(vp_ctx* ctx, const void* d_ptr, size_t bytes)
 
 static const char* kNames[VP_K_COUNT] = {
     "vox_setup", "vox_scan", "vox_scatter", "vox_tile", "vox_naive", "vox_fill",
-    "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract", "vox_zero"
+    "csg_words", "jfa_init", "jfa_pass", "jfa_final", "surface", "jfa_first", "jfa_sparse", "jfa_dense", "jfa_last", "extract", "vox_zero", "jfa_redeal"
 };
 
 }  // namespace vp
@@ -548,6 +548,10 @@ static int window_check(vp_ctx* ctx, const vp_frame* f, const vp_window* w, cons
     return 0;
 }
 
+// Every vp_jfa_window_* call that writes ids: the output window is a write through the ABI like any other (it may lie inside the workspace
+// a vp_jfa_start left its state in, or be a grid a vp_extract_count counted): the records are dropped.
+static void window_written(vp_ctx* ctx, const vp_window* w) { grid_written(ctx, w->d_ids, w->bytes); }
+
 int vp_jfa_window_clear(vp_ctx* ctx, const vp_frame* f, const vp_window* w)
 {
     if (!ctx || !w || !w->d_ids || !w->planes) return set_error(VP_ERR_INVALID, "vp_jfa_window_clear: null argument");
@@ -556,6 +560,7 @@ int vp_jfa_window_clear(vp_ctx* ctx, const vp_frame* f, const vp_window* w)
     VP_TRY(check_aligned("vp_jfa_window_clear", {w->d_ids}));
     if (w->bytes < win_bytes(f->n, w->planes)) return set_error(VP_ERR_INVALID, "vp_jfa_window_clear: a window of %u planes needs %zu bytes, %zu given", w->planes, win_bytes(f->n, w->planes), w->bytes);
     IdWin iw; iw.base = (char*)w->d_ids; iw.planes = w->planes; iw.at = 0;
+    window_written(ctx, w);
     return launch_win_clear(ctx, f->n, iw);
 }
 
@@ -566,6 +571,7 @@ int vp_jfa_window_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, 
     IdWin w;
     VP_TRY(window_check(ctx, f, out, "vp_jfa_window_init", 0, 0, w));
     VP_TRY(check_aligned("vp_jfa_window_init", {d_words, d_plane_below, d_plane_above}));
+    window_written(ctx, out);
     return launch_win_init(ctx, make_frame(f), d_words, d_plane_below, d_plane_above, w);
 }
 
@@ -577,6 +583,7 @@ int vp_jfa_window_first_pass(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_b
     VP_TRY(check_aligned("vp_jfa_window_first_pass", {d_border_grid}));
     const Frame fr = make_frame(f);
     if (!jfa_can_start_from_mask(fr, VP_ALGO_TILED)) return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_window_first_pass: needs n %% 128 == 0");
+    window_written(ctx, out);
     return launch_win_first_pass(ctx, fr, d_border_grid, w);
 }
 
@@ -589,7 +596,77 @@ int vp_jfa_window_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_bo
     const Frame fr = make_frame(f);
     if (!jfa_can_fuse_first_two(fr, VP_ALGO_TILED) || w.planes != f->n || w.at != 0)
         return set_error(VP_ERR_INVALID, "vp_jfa_window_first_two: whole-grid frame and a window of n planes (at = 0) required");
+    window_written(ctx, out);
     return launch_win_first_two(ctx, fr, d_border_grid, w);
+}
+
+// ---- cyclic plane distribution (the first phase of the transposed multi-GPU pipeline) ----
+int vp_jfa_cyclic_passes(const vp_frame* f, uint32_t ranks)
+{
+    if (!f || check_frame(f, "vp_jfa_cyclic_passes", true) != 0) return 0;
+    return (int)jfa_cyclic_passes(f->n, ranks);
+}
+
+// a whole-grid frame and a window of the n / ranks planes of one rank, at = 0
+static int cyclic_check(vp_ctx* ctx, const vp_frame* f, const vp_window* w, uint32_t ranks, uint32_t rank, const char* who, IdWin& out)
+{
+    if (!ctx || !w || !w->d_ids) return set_error(VP_ERR_INVALID, "%s: null argument", who);
+    VP_TRY(bind_device(ctx));
+    VP_TRY(check_frame(f, who, true));
+    VP_TRY(check_aligned(who, {w->d_ids}));
+    if (jfa_cyclic_passes(f->n, ranks) == 0 || rank >= ranks)
+        return set_error(VP_ERR_UNSUPPORTED, "%s: n = %u cannot be dealt cyclically to %u ranks (rank %u): a power of two, n / ranks a multiple of 8, n/4 a multiple of it", who, f->n, ranks, rank);
+    if (w->planes != f->n / ranks || w->at != 0 || w->bytes < win_bytes(f->n, w->planes))
+        return set_error(VP_ERR_INVALID, "%s: a window of n / ranks = %u planes (at = 0, %zu bytes) required", who, f->n / ranks, win_bytes(f->n, f->n / ranks));
+    out.base = (char*)w->d_ids; out.planes = w->planes; out.at = 0;
+    return 0;
+}
+
+int vp_jfa_window_first_two_cyclic(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, const vp_window* out, uint32_t ranks, uint32_t rank)
+{
+    if (!d_border_grid) return set_error(VP_ERR_INVALID, "vp_jfa_window_first_two_cyclic: null argument");
+    IdWin w;
+    VP_TRY(cyclic_check(ctx, f, out, ranks, rank, "vp_jfa_window_first_two_cyclic", w));
+    VP_TRY(check_aligned("vp_jfa_window_first_two_cyclic", {d_border_grid}));
+    window_written(ctx, out);
+    return launch_win_first_two(ctx, make_frame(f), d_border_grid, w, ranks, rank);
+}
+
+int vp_jfa_window_pass_cyclic(vp_ctx* ctx, const vp_frame* f, uint32_t k, const vp_window* in, const vp_window* out, uint32_t ranks, uint32_t rank)
+{
+    const char* who = "vp_jfa_window_pass_cyclic";
+    IdWin wi, wo;
+    VP_TRY(cyclic_check(ctx, f, in, ranks, rank, who, wi));
+    VP_TRY(cyclic_check(ctx, f, out, ranks, rank, who, wo));
+    if (overlaps(in->d_ids, win_bytes(f->n, in->planes), out->d_ids, win_bytes(f->n, out->planes))) return set_error(VP_ERR_INVALID, "%s: the two windows overlap", who);
+    // one of the leading steps of the halving sequence, beyond the two of the fused start
+    bool found = false;
+    uint32_t c = jfa_cyclic_passes(f->n, ranks), kk = f->n / 2;
+    for (uint32_t i = 0; i < c; ++i, kk /= 2) if (kk == k && i >= 2) found = true;
+    if (!found) return set_error(VP_ERR_INVALID, "%s: step %u is not one of the steps n/8 .. of n = %u that are multiples of %u ranks", who, k, f->n, ranks);
+    window_written(ctx, out);
+    return launch_win_pass_cyclic(ctx, make_frame(f), k, wi, wo, ranks, rank);
+}
+
+int vp_jfa_window_interleave(vp_ctx* ctx, const vp_frame* f, const vp_window* in, const vp_window* out, uint32_t ranks, uint32_t count)
+{
+    const char* who = "vp_jfa_window_interleave";
+    if (!ctx || !in || !out || !in->d_ids || !out->d_ids || !ranks || !count) return set_error(VP_ERR_INVALID, "%s: null argument", who);
+    VP_TRY(bind_device(ctx));
+    VP_TRY(check_frame(f, who, false));
+    VP_TRY(check_aligned(who, {in->d_ids, out->d_ids}));
+    if (f->n < kTileMinN) return set_error(VP_ERR_UNSUPPORTED, "%s: windows are the layout of the tile kernels (n >= %u)", who, kTileMinN);
+    const uint64_t planes = (uint64_t)ranks * count;
+    if (in->planes != planes || in->bytes < win_bytes(f->n, in->planes))
+        return set_error(VP_ERR_INVALID, "%s: the source must be a window of exactly ranks x count = %llu planes", who, (unsigned long long)planes);
+    if ((uint64_t)out->at + planes > out->planes || out->bytes < win_bytes(f->n, out->planes))
+        return set_error(VP_ERR_INVALID, "%s: %llu planes at index %u do not fit a window of %u planes", who, (unsigned long long)planes, out->at, out->planes);
+    if (overlaps(in->d_ids, win_bytes(f->n, in->planes), out->d_ids, win_bytes(f->n, out->planes))) return set_error(VP_ERR_INVALID, "%s: the two windows overlap", who);
+    IdWin wi, wo;
+    wi.base = (char*)in->d_ids; wi.planes = in->planes; wi.at = 0;
+    wo.base = (char*)out->d_ids; wo.planes = out->planes; wo.at = out->at;
+    window_written(ctx, out);
+    return launch_win_interleave(ctx, f->n, wi, wo, ranks, count);
 }
 
 // planes a pass with step k reads below / above the planes of f, in window planes
@@ -609,6 +686,9 @@ static int window_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const vp_wind
 {
     if (!in || !out || !in->d_ids || !out->d_ids || in->d_ids == out->d_ids) return set_error(VP_ERR_INVALID, "%s: bad windows", who);
     if (in->planes != out->planes || in->at != out->at) return set_error(VP_ERR_INVALID, "%s: the two windows must have the same planes / at", who);
+    // two windows carved from one allocation that partly overlap would have the pass read planes it is overwriting
+    if (f && f->n && overlaps(in->d_ids, win_bytes(f->n, in->planes), out->d_ids, win_bytes(f->n, out->planes)))
+        return set_error(VP_ERR_INVALID, "%s: the two windows overlap", who);
     if (!f || k == 0 || k >= f->n) return set_error(VP_ERR_INVALID, "%s: step %u out of range", who, k);
     if (stride == 0 || (stride != k && (k < f->z1 - f->z0 || stride < f->z1 - f->z0)))
         return set_error(VP_ERR_INVALID, "%s: stride %u: either the step itself or, for a step of at least the slab height, the distance of the slabs in the window", who, stride);
@@ -617,6 +697,7 @@ static int window_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const vp_wind
     IdWin wi, wo;
     VP_TRY(window_check(ctx, f, in, who, below, above, wi));
     VP_TRY(window_check(ctx, f, out, who, 0, 0, wo));
+    window_written(ctx, out);
     return launch_win_pass(ctx, make_frame(f), k, wi, wo, stride, d_words, fill, d_sdf);
 }
 

@@ -80,12 +80,19 @@ constexpr int dense_waves()
 {
     return std::is_same<ID, IdC>::value ? 4 : RY > 4 ? 4 : (FINAL && !final_mask_global<ID>()) ? (ID::kTab == 512 ? 5 : 4) : (ID::kTab == 512 || NT == 512) ? 6 : 4;
 }
-template <class ID, int RY, int CH, int NT, bool FINAL, int PM, int CLOSED = 0, bool FULL = false>
+// CYC (round 6): the planes of the frame are those of ONE rank of a CYCLIC distribution of the grid over 2^zsh ranks (the first phase of
+// the transposed multi-GPU pipeline): frame plane l is the global plane zoff + (l << zsh).  A pass whose step k is a
+// multiple of the rank count finds the planes z - k, z, z + k of every plane it owns on the same rank, k >> zsh frame planes away: the
+// tile's plane chain, its bounds and the window offsets are those of a grid of n >> zsh planes walked with the step k >> zsh, rows and
+// columns keep the step k, and only the POSITIONS of the output planes (pz) are taken from the global plane number -- the ids carry global
+// coordinates as everywhere else.  `cyc` = zsh | zoff << 8.
+template <class ID, int RY, int CH, int NT, bool FINAL, int PM, int CLOSED = 0, bool FULL = false, bool CYC = false>
 __global__ void __launch_bounds__(NT, (dense_waves<ID, RY, NT, FINAL>()))
 jfa_pass_dense(Frame f, uint32_t kArg, uint32_t ka, const char* __restrict__ in, const char* __restrict__ inB, char* __restrict__ out, char* __restrict__ outB,
                const char* __restrict__ none_row, const uint32_t* __restrict__ words, float fill, float* __restrict__ sdf,
-               uint32_t tilesY, uint32_t tiles, uint32_t splitTiles)
+               uint32_t tilesY, uint32_t tiles, uint32_t splitTiles, uint32_t cyc)
 {
+    static_assert(!CYC || !FINAL, "the last pass (k = 1) is never a multiple of the rank count");
     using T = typename ID::T;
     constexpr bool CPT = std::is_same<ID, IdC>::value;             // word plane + byte plane
     constexpr uint32_t IDB = 4u;                                   // bytes per voxel in the (word) plane the offsets below refer to
@@ -111,6 +118,10 @@ jfa_pass_dense(Frame f, uint32_t kArg, uint32_t ka, const char* __restrict__ in,
     const int N = (int)f.n;
     const uint32_t k = FINAL ? 1u : kArg;                          // the fused last pass IS the pass with k = 1 (launch_dense refuses anything else)
     const int K = (int)k;
+    // step between chain members and number of planes of the grid, in FRAME planes (CYC: those of the rank's share)
+    const int zsh = CYC ? (int)(cyc & 31u) : 0, zoff = CYC ? (int)(cyc >> 8) : 0;
+    const int KZ = CYC ? K >> zsh : K, NZ = CYC ? N >> zsh : N;
+    auto zglobal = [&](int l) { return CYC ? zoff + (l << zsh) : l; };
     const int nzl = (int)(f.z1 - f.z0);
     const uint32_t tid = threadIdx.x;
     const int nresY = min(K, N);
@@ -135,13 +146,13 @@ jfa_pass_dense(Frame f, uint32_t kArg, uint32_t ka, const char* __restrict__ in,
         if (K < 8 && lin < whole8) lin = (lin & 7u) * (whole8 >> 3) + (lin >> 3);
     }
     if (rev) lin = total - 1u - lin;
-    const int nres = min(K, nzl);
+    const int nres = min(KZ, nzl);
     // Tile order: y residue fastest -- consecutive tiles are adjacent rows of the volume and share nothing.
     uint32_t bx, by, bxq, bxr, byq, byr;
     udivmod(lin, tilesY, by, bx); udivmod(bx, (uint32_t)nresY, bxq, bxr);
     const int ybase = (int)bxr + (int)bxq * RY * K;
     udivmod(by, (uint32_t)nres, byq, byr);
-    const int lbase = (int)byr + (int)byq * CH * K;
+    const int lbase = (int)byr + (int)byq * CH * KZ;
     if (ybase >= N || lbase >= nzl) return;
     const int zbase = lbase + (int)f.z0;
     const int KA = (int)ka;                                        // planes between two chain members inside the window (see the header)
@@ -149,7 +160,7 @@ jfa_pass_dense(Frame f, uint32_t kArg, uint32_t ka, const char* __restrict__ in,
 #pragma unroll
     for (int j = 0; j < RY; ++j) py[j] = axis_pos(f.oy, ybase + j * K, f.vs);
 #pragma unroll
-    for (int j = 0; j < CH; ++j) pz[j] = axis_pos(f.oz, zbase + j * K, f.vs);
+    for (int j = 0; j < CH; ++j) pz[j] = axis_pos(f.oz, zglobal(zbase + j * KZ), f.vs);
     for (uint32_t i = tid; i < (uint32_t)PXT; i += NT) PX[i] = i < (uint32_t)N ? axis_pos(f.ox, i, f.vs) : INFINITY;
     for (uint32_t i = tid; i < (uint32_t)TAB; i += NT) {
         if (i < (uint32_t)N) {
@@ -175,8 +186,8 @@ jfa_pass_dense(Frame f, uint32_t kArg, uint32_t ka, const char* __restrict__ in,
         // row numbers of the tile's source rows: entry (pj + 1) * NR + rr = chain member pj (global plane zbase + pj k, window plane
         // lbase + pj ka from `in`), row ybase + (rr - HY) k (0 where outside)
         for (uint32_t i = tid; i < (uint32_t)((CH + 2) * NR); i += NT) {
-            const int pj = (int)(i / NR) - 1, zg = zbase + pj * K, yy = ybase + ((int)(i % NR) - HY) * K;
-            const bool ok = zg >= (int)f.z0 - K && zg < (int)f.z1 + K && zg >= 0 && zg < N && yy >= 0 && yy < N;
+            const int pj = (int)(i / NR) - 1, zg = zbase + pj * KZ, yy = ybase + ((int)(i % NR) - HY) * K;
+            const bool ok = zg >= (int)f.z0 - KZ && zg < (int)f.z1 + KZ && zg >= 0 && zg < NZ && yy >= 0 && yy < N;
             RB[i] = ok ? (uint32_t)((lbase + pj * KA) * N + yy) : 0u;  // negative for the planes below the frame: read back as int
         }
     }
@@ -204,7 +215,7 @@ jfa_pass_dense(Frame f, uint32_t kArg, uint32_t ka, const char* __restrict__ in,
 #pragma unroll
         for (int j = 1; j < RY; ++j) yout += (ybase + j * K < N) ? 1 : 0;
 #pragma unroll
-        for (int j = 1; j < CH; ++j) nout += (zbase + j * K < (int)f.z1) ? 1 : 0;
+        for (int j = 1; j < CH; ++j) nout += (zbase + j * KZ < (int)f.z1) ? 1 : 0;
     }
     const uint32_t kb = k * IDB;
     // 32-bit ids: ranks and the gather are relative to the first source plane of the tile that lies in the grid (chain member plo
@@ -231,7 +242,7 @@ jfa_pass_dense(Frame f, uint32_t kArg, uint32_t ka, const char* __restrict__ in,
         // (v_readlane / v_writelane were 6 % of the VALU instructions of the loop).
         const int zbase = (int)opaque_uniform((size_t)(uint32_t)zbase0), lbase = (int)opaque_uniform((size_t)(uint32_t)lbase0);
         const int ybase = (int)opaque_uniform((size_t)(uint32_t)ybase0);
-        const int plo = zbase - K >= 0 ? -1 : 0;
+        const int plo = zbase - KZ >= 0 ? -1 : 0;
         const char* gbase = in + (ptrdiff_t)(lbase + plo * KA) * (ptrdiff_t)planeBytes;
         uint32_t ro[NR];
         bool yv[NR];
@@ -254,8 +265,8 @@ jfa_pass_dense(Frame f, uint32_t kArg, uint32_t ka, const char* __restrict__ in,
         struct Plane { const char* base; const char* baseB; bool ok; };
         auto plane_of = [&](int P, bool needed) {
             Plane pl;
-            const int zg = zbase + P * K;
-            pl.ok = needed && zg >= 0 && zg < N;
+            const int zg = zbase + P * KZ;
+            pl.ok = needed && zg >= 0 && zg < NZ;
             const ptrdiff_t wp = pl.ok ? (ptrdiff_t)(lbase + P * KA) : 0;       // window plane relative to `in`
             pl.base = opaque_uniform(in + wp * (ptrdiff_t)planeBytes);
             pl.baseB = CPT ? opaque_uniform(inB + wp * (ptrdiff_t)((size_t)N * N)) : nullptr;
@@ -552,13 +563,14 @@ struct DenseArgs {
     const char *in, *inB; char *out, *outB; const char* none_row;
     const uint32_t* words; float fill; float* sdf;
     uint32_t nresY, ylen, nres, zlen;                              // residue classes and chain lengths of the rows / of the frame's planes
+    uint32_t cyc = 0;                                              // cyclic plane distribution: log2(ranks) | rank << 8 (see jfa_pass_dense, CYC)
 };
 // the 8 x 16 tiles of the 2-KB-table format at n = 512: a build part of their own (the largest kernels of the file)
 int launch_dense_id9_tile16(const DenseArgs& a, bool pairsOk);
 
 namespace {
 
-template <class ID, int RY, int CH, int NT, bool F, int PM, int CL = 0, bool FULL = false>
+template <class ID, int RY, int CH, int NT, bool F, int PM, int CL = 0, bool FULL = false, bool CYC = false>
 void launch_tile(const DenseArgs& a)
 {
     const uint32_t ty = a.nresY * ((a.ylen + RY - 1) / RY), t = ty * a.nres * ((a.zlen + CH - 1) / CH);
@@ -567,8 +579,8 @@ void launch_tile(const DenseArgs& a)
                              : ID::kTab == 512 ? (RY == 8 ? 4u : (F && !final_mask_global<ID>()) ? 5u : 6u)
                              : NT == 512 ? (RY == 8 ? 2u : 3u) : 4u;
     const uint32_t sp = a.f.n > (uint32_t)NT ? tail_split(a.ctx, t, perCu) : 0u;     // a row of <= NT voxels has no halves
-    hipLaunchKernelGGL((jfa_pass_dense<ID, RY, CH, NT, F, PM, CL, FULL>), dim3(t + sp), dim3(NT), 0, a.ctx->stream, a.f, a.k, a.ka,
-                       a.in, a.inB, a.out, a.outB, a.none_row, a.words, a.fill, a.sdf, ty, t, sp);
+    hipLaunchKernelGGL((jfa_pass_dense<ID, RY, CH, NT, F, PM, CL, FULL, CYC>), dim3(t + sp), dim3(NT), 0, a.ctx->stream, a.f, a.k, a.ka,
+                       a.in, a.inB, a.out, a.outB, a.none_row, a.words, a.fill, a.sdf, ty, t, sp, a.cyc);
 }
 
 // Tile shape and lane pairing for one launch.  RY: 8 rows for the id passes with the 2-KB tables (109 VGPRs, four waves per SIMD, but half
@@ -581,18 +593,20 @@ void launch_tile(const DenseArgs& a)
 template <int V> using int_c = std::integral_constant<int, V>;
 
 // ALWAYS_FULL: the caller only comes with whole chains (no instantiation of the run-time row / plane counts).
-template <class ID, int CH, int NT, bool F, bool ALWAYS_FULL = false>
+// CYC: the passes of a cyclic plane distribution -- their chains are always whole (n / k is a power of two >= 8, see launch_dense), so each
+// format instantiates ONE of the two forms: compile-time counts where the format uses them at all, run-time counts otherwise.
+template <class ID, int CH, int NT, bool F, bool ALWAYS_FULL = false, bool CYC = false>
 void launch_shape(const DenseArgs& a, bool pairsOk, bool wholeChains)
 {
     constexpr int RY = (ID::kTab == 512 && !F && CH >= 8) ? 8 : 4;
     constexpr bool canFull = CH >= 8 && (ID::kTab != 1024 || F);
     auto go = [&](auto pm) {
         constexpr int PM = decltype(pm)::value;
-        if constexpr (ALWAYS_FULL) { launch_tile<ID, RY, CH, NT, F, PM, 0, true>(a); return; }
+        if constexpr (ALWAYS_FULL || (CYC && canFull)) { launch_tile<ID, RY, CH, NT, F, PM, 0, true, CYC>(a); return; }
         else if constexpr (canFull) {
             if (wholeChains && a.ylen % RY == 0) { launch_tile<ID, RY, CH, NT, F, PM, 0, true>(a); return; }
         }
-        launch_tile<ID, RY, CH, NT, F, PM>(a);
+        launch_tile<ID, RY, CH, NT, F, PM, 0, false, CYC>(a);
     };
     if constexpr (CH >= 8) {
         if (pairsOk && a.f.n % NT == 0) {
@@ -690,9 +704,50 @@ int launch_dense(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const
     return 0;
 }
 
+// One pass of a CYCLIC plane distribution (jfa_pass_dense, CYC): f is the whole-grid frame, the windows hold the n / ranks planes of rank
+// `rank` (frame plane l = global plane rank + l * ranks), k is a multiple of `ranks`.  The chains of such a pass are always whole: every
+// step of the halving sequence down to a multiple of `ranks` divides n exactly, so a chain of rows or planes has n / k = 2^j members,
+// j >= 3 (the passes n/2 and n/4 are the fused start, jfa_first_two) -- 8-plane tiles (16 for the compact ids where n / k allows), closed
+// 8 x 8 tiles at k = n/8 on power-of-two grids, pair mode as on one GPU.
+template <class ID>
+int launch_dense_cyclic(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t ranks, uint32_t rank)
+{
+    const uint32_t n = f.n, zsh = (uint32_t)__builtin_ctz(ranks);
+    const uint32_t nzl = n >> zsh, kz = k >> zsh;
+    if ((ranks & (ranks - 1)) != 0 || rank >= ranks || n % ranks != 0 || k % ranks != 0 || n % k != 0 || n / k < 8 || ((n / k) & (n / k - 1)) != 0)
+        return set_error(VP_ERR_INVALID, "jfa_pass_dense (cyclic): n = %u, k = %u, %u ranks", n, k, ranks);
+    VP_TRY(ensure_none_rows(ctx));
+    Frame fl = f;                                                  // the rank's share as a frame of its own: planes [0, n / ranks)
+    fl.z0 = 0; fl.z1 = nzl;
+    const uint32_t zlen = nzl / kz, ylen = n / k;                  // = n / k both
+    DenseArgs a{ctx, fl, k, kz, win_words(in, n, in.at), win_compact(n) ? win_bytes_plane(in, n, in.at) : nullptr,
+                win_words(out, n, out.at), win_compact(n) ? win_bytes_plane(out, n, out.at) : nullptr,
+                (const char*)(std::is_same<ID, Id9>::value ? none_row_id9(ctx) : std::is_same<ID, Id10>::value ? none_row_id10(ctx) : none_row_idc(ctx)),
+                nullptr, 0.0f, nullptr, std::min(k, n), ylen, std::min(kz, nzl), zlen, zsh | (rank << 8)};
+    const bool pow2 = (n & (n - 1)) == 0;
+    constexpr int NTD = ID::kTab == 512 ? 256 : 512;
+    if constexpr (!std::is_same<ID, IdC>::value) {
+        if (pow2 && n == 8u * k && n % NTD == 0) {
+            launch_tile<ID, 8, 8, NTD, false, 8, 3, ID::kTab == 512, true>(a);
+            VP_HIP(hipGetLastError());
+            return 0;
+        }
+    }
+    if constexpr (std::is_same<ID, IdC>::value) {
+        if (zlen % 16 == 0) {
+            launch_shape<ID, 16, NTD, false, false, true>(a, pow2 && k >= 2, true);
+            VP_HIP(hipGetLastError());
+            return 0;
+        }
+    }
+    launch_shape<ID, 8, NTD, false, false, true>(a, pow2 && k >= 2, true);
+    VP_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
-// launch_dense<ID, FIN> per id format and pass kind, one build part each (-DVP_DENSE_PART=1..7; undefined: all of them in one unit)
+// launch_dense<ID, FIN> per id format and pass kind, one build part each (-DVP_DENSE_PART=1..10; undefined: all of them in one unit)
 #ifndef VP_DENSE_PART
 #define VP_DENSE_PART 0
 #endif
@@ -721,5 +776,18 @@ VP_DENSE_ENTRY(6, launch_dense_idc_last, IdC, true)
 int launch_dense_id9_tile16(const DenseArgs& a, bool pairsOk) { launch_shape<Id9, 16, 512, false, true>(a, pairsOk, true); return 0; }
 #endif
 #undef VP_DENSE_ENTRY
+#define VP_CYCLIC_ENTRY(NAME, ID)                                                                                                        \
+    int NAME(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t ranks, uint32_t rank)                 \
+    { return launch_dense_cyclic<ID>(ctx, f, k, in, out, ranks, rank); }
+#if VP_DENSE_PART == 0 || VP_DENSE_PART == 8
+VP_CYCLIC_ENTRY(launch_cyclic_id9_pass, Id9)
+#endif
+#if VP_DENSE_PART == 0 || VP_DENSE_PART == 9
+VP_CYCLIC_ENTRY(launch_cyclic_id10_pass, Id10)
+#endif
+#if VP_DENSE_PART == 0 || VP_DENSE_PART == 10
+VP_CYCLIC_ENTRY(launch_cyclic_idc_pass, IdC)
+#endif
+#undef VP_CYCLIC_ENTRY
 
 }  // namespace vp

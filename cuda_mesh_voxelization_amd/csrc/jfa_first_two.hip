@@ -120,10 +120,15 @@ __device__ __forceinline__ void ft_store(uint2* p, uint2 v)
 // instead of ID's own; inside the kernel the ids stay ID's (Id64).
 constexpr int kTilesPerWg = 2;    // tiles per workgroup.  Round 3, without the census fast path (profiles/r03/ab_tpw_*.txt): 1 / 2 / 4 / 8 tiles = 0.371 /
                                   // 0.373 / 0.370 / 0.406 ms at n = 512; with the census (round 4, ab_fttpw_*.txt) two tiles: -11 %, four: +-0 / +9 %
-template <class ID, int XR, int NT, int TPW, bool CPT = false>
+// CYC (round 6): the launch produces the planes of ONE rank of a cyclic distribution of the grid over 2^zsh ranks (cyc = zsh | rank << 8; the
+// first phase of the transposed multi-GPU pipeline).  n/4 is a multiple of the rank count, so the four planes of a
+// closed chain belong to one rank: the rank takes the tiles whose z residue is its own modulo the rank count -- rz below is then the
+// residue's index among them, rzg the residue itself -- reads the border bits of those planes from the whole-grid mask and writes
+// plane z at index z >> zsh of `out`.  Ids, positions and ranks are global as everywhere else.
+template <class ID, int XR, int NT, int TPW, bool CPT = false, bool CYC = false>
 __global__ void __launch_bounds__(NT)
 jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __restrict__ out, unsigned char* __restrict__ outB,
-              uint32_t tilesX, uint32_t tiles, uint32_t shifts, FastDiv divTilesX, FastDiv divK)
+              uint32_t tilesX, uint32_t tiles, uint32_t shifts, FastDiv divTilesX, FastDiv divK, uint32_t cyc)
 {
     static_assert(!CPT || std::is_same<ID, Id64>::value, "compact output: from 8-byte ids");
     using T = typename ID::T;
@@ -138,6 +143,9 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
     __shared__ uint32_t cnt[2];
     __shared__ uint32_t latCnt[TPW][XR], latSeed[TPW][XR];         // border voxels per lattice of each tile, the slot of one of them
     const uint32_t tid = threadIdx.x, lane = tid & 63u, N = f.n, k = N / 4u;
+    const uint32_t zsh = CYC ? cyc & 31u : 0u, zoff = CYC ? cyc >> 8 : 0u;
+    const uint32_t kzl = k >> zsh;                                 // planes between chain members in `out`
+    auto zres = [&](uint32_t rz) { return CYC ? zoff + (rz << zsh) : rz; };      // index of a z residue among the rank's -> the residue
     // slot tid + i NT = row-plane (rpb + i G) x column `col` (see jfa_pass_seeds): row addresses are scalar work
     constexpr uint32_t RPW = 4u * XR;
     constexpr uint32_t G = NT / RPW;
@@ -182,11 +190,12 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
     for (int u = 0; u < TPW; ++u) {
         uint32_t rx0, ry, rz;
         tile_origin(min(tile0 + u, tiles - 1u), rx0, ry, rz);
+        const uint32_t rzg = zres(rz);
         const uint32_t myx = rx0 + col % XR + __umul24(col / XR, k);
         const bool xin = rx0 + col % XR < k;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const uint32_t rp = rpb + (uint32_t)i * G, y = ry + (rp & 3u) * k, z = rz + (rp >> 2) * k;
+            const uint32_t rp = rpb + (uint32_t)i * G, y = ry + (rp & 3u) * k, z = rzg + (rp >> 2) * k;
             mw[u][i] = xin ? border[(z * N + y) * f.w + (myx >> 5)] : 0u;          // < 2^28 words at n = 2048: 32-bit index arithmetic
         }
     }
@@ -200,6 +209,7 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
         if (tile >= tiles) break;                                  // uniform
         uint32_t rx0, ry, rz;
         tile_origin(tile, rx0, ry, rz);
+        const uint32_t rzg = zres(rz);
         const uint32_t myx = rx0 + col % XR + __umul24(col / XR, k);
         const bool xin = rx0 + col % XR < k;
         // The 64 voxels of one residue class (x, y, z mod k) -- a LATTICE, 4 x 4 x 4 chain positions -- only ever see each other in these
@@ -223,13 +233,13 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
             }
             if (!__syncthreads_or(multi ? 1 : 0)) {
                 const uint32_t sSlot = latSeed[u][res];               // valid where latCnt[u][res] == 1
-                const T one = ID::pack(rx0 + res + __umul24((sSlot / XR) & 3u, k), ry + ((sSlot / (4u * XR)) & 3u) * k, rz + (sSlot / (16u * XR)) * k);
+                const T one = ID::pack(rx0 + res + __umul24((sSlot / XR) & 3u, k), ry + ((sSlot / (4u * XR)) & 3u) * k, rzg + (sSlot / (16u * XR)) * k);
                 const T id = latCnt[u][res] ? one : ID::none();
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
                     if (!xin) continue;
                     const uint32_t rp = rpb + (uint32_t)i * G;
-                    const size_t vox = (size_t)((rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx;
+                    const size_t vox = (size_t)((rz + (rp >> 2) * kzl) * N + (ry + (rp & 3u) * k)) * N + myx;
                     if constexpr (CPT) {
                         const uint2 c = IdC::from64(id);
                         ft_store(reinterpret_cast<uint32_t*>(out) + vox, c.x);
@@ -244,7 +254,7 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
         if (tid < 2) cnt[tid] = 0;
         {                                                          // positions of the tile's 4 XR columns, 4 rows, 4 planes (see ChainPosLds)
             if (tid < RPW) posX[tid] = axis_pos(f.ox, myx, f.vs);  // tid < RPW: col == tid
-            if (tid < 4) { posY[tid] = axis_pos(f.oy, ry + tid * k, f.vs); posZ[tid] = axis_pos(f.oz, rz + tid * k, f.vs); }
+            if (tid < 4) { posY[tid] = axis_pos(f.oy, ry + tid * k, f.vs); posZ[tid] = axis_pos(f.oz, rzg + tid * k, f.vs); }
         }
         __syncthreads();                                           // also: the previous tile's output stage has read keys / idOf
         // every entry of the list proposes the seed that sits at slot q (its coordinates are those of q) from slot s
@@ -272,7 +282,7 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const uint32_t s = tid + (uint32_t)i * NT;
-            const uint32_t rp = rpb + (uint32_t)i * G, y = ry + (rp & 3u) * k, z = rz + (rp >> 2) * k;
+            const uint32_t rp = rpb + (uint32_t)i * G, y = ry + (rp & 3u) * k, z = rzg + (rp >> 2) * k;
             flag[i] = xin && ((mw[u][i] >> (myx & 31u)) & 1u);
             keys[s] = kEmpty;
             idOf[s] = ID::pack(myx, y, z);
@@ -304,7 +314,7 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
             // was measured: -1 % at n = 512, +4 % at n = 1024, profiles/r04/ab_ft3_*.txt: such a tile is bound by its fixed stages, not by
             // the number of proposals.)
             const uint32_t rp = rpb + (uint32_t)i * G;
-            const size_t vox = (size_t)((rz + (rp >> 2) * k) * N + (ry + (rp & 3u) * k)) * N + myx;
+            const size_t vox = (size_t)((rz + (rp >> 2) * kzl) * N + (ry + (rp & 3u) * k)) * N + myx;
             if constexpr (CPT) {
                 const uint2 c = IdC::from64(id);
                 ft_store(reinterpret_cast<uint32_t*>(out) + vox, c.x);
@@ -322,10 +332,29 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
 // The chains {r, r + n/4, r + n/2, r + 3n/4} are closed for any n % 4 == 0 (every legal n), and a tile whose 16 / 32 residues reach past n/4
 // masks the excess lanes: the fused start serves EVERY whole grid the tile kernels serve (profiles/r04/size_sweep.txt: whole step
 // 2.89 -> 2.47 ms at n = 480, 29.3 -> 23.6 at 960 against init ids + two region passes).
-int launch_win_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, const IdWin& out)
+// ranks > 1: the planes of rank `rank` of a cyclic distribution over `ranks` ranks (a power of two dividing n/4) into a window of
+// n / ranks planes (see the kernel, CYC).
+int launch_win_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, const IdWin& out, uint32_t ranks, uint32_t rank)
 {
     ProfScope p(ctx, VP_K_JFA_FIRST);
     const uint32_t k = f.n / 4;
+    if (ranks > 1) {
+        if ((ranks & (ranks - 1)) != 0 || k % ranks != 0 || rank >= ranks) return set_error(VP_ERR_INVALID, "jfa_first_two (cyclic): n = %u, %u ranks", f.n, ranks);
+        const uint32_t zsh = (uint32_t)__builtin_ctz(ranks), cyc = zsh | (rank << 8);
+        const bool small = f.n <= 512;
+        const uint32_t xr = small ? 16u : 32u;
+        const uint32_t tilesX = (k + xr - 1) / xr, tiles = tilesX * k * (k >> zsh);
+        const dim3 grid((tiles + kTilesPerWg - 1) / kTilesPerWg);
+        auto pow2 = [](uint32_t v) { return v != 0 && (v & (v - 1)) == 0; };
+        const uint32_t shifts = (pow2(tilesX) && pow2(k)) ? ((uint32_t)__builtin_ctz(tilesX) | ((uint32_t)__builtin_ctz(k) << 8) | (1u << 16)) : 0u;
+        char* w = win_words(out, f.n, 0);
+        unsigned char* b = (unsigned char*)win_bytes_plane(out, f.n, 0);
+        if (win_compact(f.n)) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, kTilesPerWg, true, true>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)w, b, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k), cyc);
+        else if (small) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, kTilesPerWg, false, true>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)w, nullptr, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k), cyc);
+        else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512, kTilesPerWg, false, true>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)w, nullptr, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k), cyc);
+        VP_HIP(hipGetLastError());
+        return 0;
+    }
     // tile = 4 x 4 x 4 chain positions x XR residues.  Measured (profiles/r02/ab33.txt, r04/ab_ftxr_*.txt): 16 residues x 256 threads is the
     // best shape at n <= 512, 32 x 512 above.  A workgroup takes kTilesPerWg consecutive tiles.
     const bool small = f.n <= 512;
@@ -336,9 +365,9 @@ int launch_win_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, 
     const uint32_t shifts = (pow2(tilesX) && pow2(k)) ? ((uint32_t)__builtin_ctz(tilesX) | ((uint32_t)__builtin_ctz(k) << 8) | (1u << 16)) : 0u;
     char* w = win_words(out, f.n, 0);
     unsigned char* b = (unsigned char*)win_bytes_plane(out, f.n, 0);
-    if (win_compact(f.n)) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, kTilesPerWg, true>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)w, b, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k));
-    else if (small) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, kTilesPerWg>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)w, nullptr, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k));
-    else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512, kTilesPerWg>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)w, nullptr, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k));
+    if (win_compact(f.n)) hipLaunchKernelGGL((jfa_first_two<Id64, 32, 512, kTilesPerWg, true>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint2*)w, b, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k), 0u);
+    else if (small) hipLaunchKernelGGL((jfa_first_two<Id9, 16, 256, kTilesPerWg>), grid, dim3(256), 0, ctx->stream, f, d_border, (uint32_t*)w, nullptr, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k), 0u);
+    else            hipLaunchKernelGGL((jfa_first_two<Id10, 32, 512, kTilesPerWg>), grid, dim3(512), 0, ctx->stream, f, d_border, (uint32_t*)w, nullptr, tilesX, tiles, shifts, make_fastdiv(tilesX), make_fastdiv(k), 0u);
     VP_HIP(hipGetLastError());
     return 0;
 }

@@ -555,6 +555,25 @@ int launch_win_pass(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, co
     return launch_dense_id10_pass(ctx, f, k, in, out, stride, d_words, fill, d_sdf);
 }
 
+// Passes of the halving sequence whose step is a multiple of `ranks`, counted from the first: those can run on planes dealt cyclically
+// (plane z on rank z mod ranks), every plane finding its z -+ k on its own rank.  The first two are the fused start, so fewer than two
+// (or a grid the tile kernels do not serve, or a rank count that is not a power of two dividing n into multiples of 8 planes) is 0.
+uint32_t jfa_cyclic_passes(uint32_t n, uint32_t ranks)
+{
+    if (n < kTileMinN || ranks < 2 || (ranks & (ranks - 1)) != 0 || n % ranks != 0 || (n / ranks) % 8 != 0) return 0;
+    uint32_t c = 0;
+    for (uint32_t k = n / 2; k >= 1 && k % ranks == 0; k /= 2) ++c;
+    return c >= 2 ? c : 0;
+}
+
+int launch_win_pass_cyclic(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t ranks, uint32_t rank)
+{
+    ProfScope p(ctx, VP_K_JFA_DENSE);
+    if (win_compact(f.n)) return launch_cyclic_idc_pass(ctx, f, k, in, out, ranks, rank);
+    if (f.n <= 512)       return launch_cyclic_id9_pass(ctx, f, k, in, out, ranks, rank);
+    return launch_cyclic_id10_pass(ctx, f, k, in, out, ranks, rank);
+}
+
 bool jfa_pass_can_fuse_final(const Frame& f, uint32_t k, int algo)
 {
     (void)k;
@@ -570,38 +589,45 @@ int launch_jfa_pass_ex(vp_ctx* ctx, const Frame& f, uint32_t k, const void* d_in
                        const void* d_plus, void* d_out, int algo, const uint32_t* d_words, float fill, float* d_sdf)
 {
     const uint32_t nz = f.z1 - f.z0;
-    if (algo == VP_ALGO_NAIVE) {
-        ProfScope p(ctx, VP_K_JFA_PASS);
-        const dim3 blocks(f.n * f.n / 256, nz);
-        if (wide(f))
-            hipLaunchKernelGGL(jfa_pass_direct<Id64>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint2*)d_in,
-                               (const uint2*)d_minus, (const uint2*)d_plus, (uint2*)d_out);
-        else if (f.n <= 512)
-            hipLaunchKernelGGL(jfa_pass_direct<Id9>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
-                               (const uint32_t*)d_minus, (const uint32_t*)d_plus, (uint32_t*)d_out);
-        else
-            hipLaunchKernelGGL(jfa_pass_direct<Id10>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
-                               (const uint32_t*)d_minus, (const uint32_t*)d_plus, (uint32_t*)d_out);
-        VP_HIP(hipGetLastError());
-        return 0;
-    }
+    // the direct kernel (one thread per voxel, any buffers); as the last pass it is followed by the id -> sdf conversion of its output
+    auto direct = [&]() -> int {
+        {
+            ProfScope p(ctx, VP_K_JFA_PASS);
+            const dim3 blocks(f.n * f.n / 256, nz);
+            if (wide(f))
+                hipLaunchKernelGGL(jfa_pass_direct<Id64>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint2*)d_in,
+                                   (const uint2*)d_minus, (const uint2*)d_plus, (uint2*)d_out);
+            else if (f.n <= 512)
+                hipLaunchKernelGGL(jfa_pass_direct<Id9>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
+                                   (const uint32_t*)d_minus, (const uint32_t*)d_plus, (uint32_t*)d_out);
+            else
+                hipLaunchKernelGGL(jfa_pass_direct<Id10>, blocks, dim3(256), 0, ctx->stream, f, k, (const uint32_t*)d_in,
+                                   (const uint32_t*)d_minus, (const uint32_t*)d_plus, (uint32_t*)d_out);
+            VP_HIP(hipGetLastError());
+        }
+        return d_sdf ? launch_jfa_final(ctx, f, d_words, d_out, fill, d_sdf) : 0;
+    };
+    if (algo == VP_ALGO_NAIVE) return direct();
     if (f.n < kTileMinN) {
-        ProfScope p(ctx, VP_K_JFA_PASS);
-        const int RY = (int)(256 / f.n);
-        const dim3 grid((f.n + RY - 1) / RY, nz);
-        const size_t lds = (size_t)(2 + RY) * kTableKernelTab * sizeof(float);
-        hipLaunchKernelGGL(jfa_pass_table, grid, dim3(256), lds, ctx->stream, f, k, (const uint32_t*)d_in, (const uint32_t*)d_minus,
-                           (const uint32_t*)d_plus, (uint32_t*)d_out, RY);
-        VP_HIP(hipGetLastError());
-        return 0;
+        {
+            ProfScope p(ctx, VP_K_JFA_PASS);
+            const int RY = (int)(256 / f.n);
+            const dim3 grid((f.n + RY - 1) / RY, nz);
+            const size_t lds = (size_t)(2 + RY) * kTableKernelTab * sizeof(float);
+            hipLaunchKernelGGL(jfa_pass_table, grid, dim3(256), lds, ctx->stream, f, k, (const uint32_t*)d_in, (const uint32_t*)d_minus,
+                               (const uint32_t*)d_plus, (uint32_t*)d_out, RY);
+            VP_HIP(hipGetLastError());
+        }
+        return d_sdf ? launch_jfa_final(ctx, f, d_words, d_out, fill, d_sdf) : 0;
     }
-    if (wide(f))
-        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_pass: above n = 1024 the tile kernels keep their state in a window (vp_jfa_window_*); plain 8-byte ids: VP_ALGO_NAIVE");
+    // The tile kernel runs on PLAIN ids only where they ARE a window: 4-byte ids (n <= 1024) and the three buffers one run of consecutive
+    // planes.  Anything else -- 8-byte ids, halo buffers of their own -- is served by the direct kernel: same ids, bit for bit (ABI v4
+    // served these cases; v5 refused them).
     const size_t plane = win_plane_bytes(f.n);
     const char* in = (const char*)d_in;
     const uint32_t pbase = std::max(f.z1, f.z0 + k);
-    if ((f.z0 > 0 && (const char*)d_minus + (size_t)k * plane != in) || (f.z1 < f.n && (const char*)d_plus != in + (size_t)(pbase - f.z0) * plane))
-        return set_error(VP_ERR_UNSUPPORTED, "vp_jfa_pass: the tile kernels need the halo planes right below / above the slab (one run of consecutive planes); use a window (vp_jfa_window_*) or VP_ALGO_NAIVE");
+    if (wide(f) || (f.z0 > 0 && (const char*)d_minus + (size_t)k * plane != in) || (f.z1 < f.n && (const char*)d_plus != in + (size_t)(pbase - f.z0) * plane))
+        return direct();
     // the same planes seen as windows that start at global plane 0 (never dereferenced outside the planes a pass reads)
     IdWin wi, wo;
     wi.base = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(d_in) - (uintptr_t)f.z0 * plane); wi.planes = f.n; wi.at = f.z0;
@@ -623,6 +649,38 @@ int launch_jfa_final(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, const
     if (wide(f)) hipLaunchKernelGGL(jfa_final<Id64>, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint2*)d_ids, fill, (float4*)d_sdf);
     else if (f.n <= 512) hipLaunchKernelGGL(jfa_final<Id9>, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint32_t*)d_ids, fill, (float4*)d_sdf);
     else         hipLaunchKernelGGL(jfa_final<Id10>, dim3(blocks), dim3(256), 0, ctx->stream, f, d_words, (const uint32_t*)d_ids, fill, (float4*)d_sdf);
+    VP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ interleave
+// The re-deal of the transposed pipeline: after the all-to-all a rank holds `ranks` chunks of `count` planes, chunk s = the planes
+// b0 + s, b0 + s + ranks, ... of its (widened) slab as rank s kept them; this weaves them into consecutive planes.  A plain copy at 16
+// bytes per lane; one workgroup column per destination plane.
+namespace {
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+win_interleave(const u32x4* __restrict__ in, u32x4* __restrict__ out, uint32_t quadsPerPlane, uint32_t ranks, uint32_t count)
+{
+    const uint32_t p = blockIdx.y;                                 // destination plane j * ranks + s
+    const uint32_t s = p % ranks, j = p / ranks;
+    const u32x4* src = in + (size_t)(s * count + j) * quadsPerPlane;
+    u32x4* dst = out + (size_t)p * quadsPerPlane;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < quadsPerPlane; i += gridDim.x * 256u)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+}
+}  // namespace
+
+int launch_win_interleave(vp_ctx* ctx, uint32_t n, const IdWin& in, const IdWin& out, uint32_t ranks, uint32_t count)
+{
+    ProfScope p(ctx, VP_K_JFA_REDEAL);
+    const uint32_t planes = ranks * count;
+    const uint32_t qWord = n * n / 4, qByte = n * n / 16;          // 16-byte quads per word plane / byte plane (n % 32 == 0)
+    const dim3 grid(std::min(64u, (qWord + 255u) / 256u), planes);
+    hipLaunchKernelGGL(win_interleave, grid, dim3(256), 0, ctx->stream, (const u32x4*)win_words(in, n, 0), (u32x4*)win_words(out, n, out.at), qWord, ranks, count);
+    if (win_compact(n))
+        hipLaunchKernelGGL(win_interleave, dim3(std::min(64u, (qByte + 255u) / 256u), planes), dim3(256), 0, ctx->stream,
+                           (const u32x4*)win_bytes_plane(in, n, 0), (u32x4*)win_bytes_plane(out, n, out.at), qByte, ranks, count);
     VP_HIP(hipGetLastError());
     return 0;
 }

@@ -163,7 +163,19 @@ VP_DENSE_DECL(launch_dense_id10_pass); VP_DENSE_DECL(launch_dense_id10_last);
 VP_DENSE_DECL(launch_dense_idc_pass);  VP_DENSE_DECL(launch_dense_idc_last);
 #undef VP_DENSE_DECL
 // jfa_first_two.hip: passes n/2 and n/4 of a whole grid from its border mask into a window of n planes
-int launch_win_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, const IdWin& out);
+// ranks > 1: the planes of rank `rank` of a cyclic distribution of the grid over `ranks` ranks into a window of n / ranks planes
+int launch_win_first_two(vp_ctx* ctx, const Frame& f, const uint32_t* d_border, const IdWin& out, uint32_t ranks = 1, uint32_t rank = 0);
+// ---- cyclic plane distribution (the first phase of the transposed multi-GPU pipeline; include/vphip.h, vp_jfa_window_*_cyclic) ----
+// passes of the sequence n/2, n/4, ... that can run on planes dealt cyclically to `ranks` ranks (their steps are multiples of `ranks`): 0 or >= 2
+uint32_t jfa_cyclic_passes(uint32_t n, uint32_t ranks);
+// one pass with step k (a multiple of `ranks`) over the n / ranks planes of rank `rank`: jfa_dense.hip, jfa_pass_dense<CYC>
+int launch_win_pass_cyclic(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t ranks, uint32_t rank);
+#define VP_CYCLIC_DECL(NAME) int NAME(vp_ctx* ctx, const Frame& f, uint32_t k, const IdWin& in, const IdWin& out, uint32_t ranks, uint32_t rank)
+VP_CYCLIC_DECL(launch_cyclic_id9_pass); VP_CYCLIC_DECL(launch_cyclic_id10_pass); VP_CYCLIC_DECL(launch_cyclic_idc_pass);
+#undef VP_CYCLIC_DECL
+// plane at + j * ranks + s of `out` := plane s * count + j of `in` (s < ranks, j < count): `ranks` chunks of `count` planes each, chunk s
+// holding every ranks-th plane from s on, woven into consecutive planes (jfa_seed.hip)
+int launch_win_interleave(vp_ctx* ctx, uint32_t n, const IdWin& in, const IdWin& out, uint32_t ranks, uint32_t count);
 int launch_extract_count(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, int mode, uint64_t* h_count);
 int launch_extract_write(vp_ctx* ctx, const Frame& f, const uint32_t* d_words, int mode, const float* d_sdf,
                          uint64_t* d_records, float* d_values, size_t capacity);

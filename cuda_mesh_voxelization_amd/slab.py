@@ -16,6 +16,11 @@ asks for.  Rank r owns the planes [r*nz, (r+1)*nz), nz = n / world.
 Every stage is a pure function of the previous buffers, so the concatenated slabs are bit-identical
 to the single-GPU result for any world size -- that is the parity test (tests/test_slab_*.py).
 
+Four pipelines feed a pass its planes z -+ k: SlabPipeline (halos before every pass), GhostSlabPipeline (ghost
+planes recomputed, nothing exchanged), HybridSlabPipeline (ghost planes for the wide passes, halos for the narrow ones) and
+TransposeSlabPipeline (planes dealt CYCLICALLY for every pass whose step is a multiple of the rank count -- no exchange, no ghost
+planes -- then ONE all-to-all into slabs for the last log2(world) passes).
+
 The compute backend is pluggable only so that the exchange logic can be exercised on CPU with gloo
 in the test-suite; the product backend (HipSlabBackend) calls libvphip.so and nothing else.
 """
@@ -107,6 +112,20 @@ class HipSlabBackend:
         self.ctx.jfa_window_last_pass(region, self._w(w_in, at), self._w(w_scratch, at), words_region.data_ptr(), fill, sdf.data_ptr(), stride)
 
 
+    # -- cyclic plane distribution (TransposeSlabPipeline) ----------------------------------------
+    def cyclic_passes(self, frame, world):
+        return self.ctx.jfa_cyclic_passes(frame, world)
+
+    def win_first_two_cyclic(self, frame, border_full, w, world, rank):
+        self.ctx.jfa_window_first_two_cyclic(frame, border_full.data_ptr(), self._w(w, 0), world, rank)
+
+    def win_pass_cyclic(self, frame, k, w_in, w_out, world, rank):
+        self.ctx.jfa_window_pass_cyclic(frame, k, self._w(w_in, 0), self._w(w_out, 0), world, rank)
+
+    def win_interleave(self, frame, w_in, w_out, at, world, count):
+        self.ctx.jfa_window_interleave(frame, self._w(w_in, 0), self._w(w_out, at), world, count)
+
+
 class HostStagedDist:
     """Test rigs only (bench.py with VP_BENCH_SHARE_GPU=1: ranks share a GPU and rendezvous over gloo, whose send / recv take CPU
     tensors): the point-to-point subset the pipelines use, staged through host memory.  On a real node the pipelines get
@@ -141,6 +160,11 @@ class HostStagedDist:
                 host = torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
                 out.append(self._Req([self.dist.irecv(host, o.peer)], o.tensor, host))
         return out
+
+    def all_to_all_single(self, output, input, output_split_sizes=None, input_split_sizes=None):
+        host_out = torch.empty(output.shape, dtype=output.dtype)
+        self.dist.all_to_all_single(host_out, input.cpu(), output_split_sizes, input_split_sizes)
+        output.copy_(host_out)
 
     def barrier(self):
         self.dist.barrier()
@@ -564,9 +588,195 @@ class HybridSlabPipeline:
 
 
 # =============================================================================================
+# Transposed: cyclic planes while the steps are multiples of the rank count, one all-to-all, slabs for the rest
+# =============================================================================================
+def cyclic_passes(n: int, world: int, min_n: int = 96) -> int:
+    """Passes of the sequence n/2, n/4, ... (jfa/sequential.cpp:72) whose step is a multiple of `world`, counted from the first: with the
+    planes dealt cyclically (plane z on rank z mod world) such a pass finds the planes z - k, z, z + k (:92-94) of every plane a rank owns
+    on that rank.  0 where the distribution does not apply: fewer than the two passes of the fused start, a rank count that is not a power
+    of two, slabs that are not a multiple of 8 planes, grids below the tile kernels' range (min_n; the numpy backend of the tests has
+    none).  (= vp_jfa_cyclic_passes)"""
+    if n < min_n or world < 2 or world & (world - 1) or n % world or (n // world) % 8:
+        return 0
+    c, k = 0, n // 2
+    while k >= 1 and k % world == 0:
+        c, k = c + 1, k // 2
+    return c if c >= 2 else 0
+
+
+def transpose_plan(n: int, rank: int, world: int, min_n: int = 96):
+    """What rank `rank` does in the transposed pipeline, or None where it does not apply (cyclic_passes == 0):
+      cyclic   the steps that run on the cyclic distribution (local plane l = global plane rank + l * world), no exchange
+      regions  [(k, b0, b1)] the remaining steps on the slab widened by the reach of the later ones -- ghost_regions restricted to them
+      recv     [t0, t1): the global planes the all-to-all delivers to this rank -- the slab widened by the reach g of ALL remaining steps,
+               rounded outwards to a multiple of world so that every source holds the same local range [t0 / world, t1 / world) of it
+      window   [lo, hi): the planes the two slab-phase id windows hold: recv and what the (outward-rounded) regions read beyond it"""
+    c = cyclic_passes(n, world, min_n)
+    if c == 0:
+        return None
+    regs = ghost_regions(n, rank, world)
+    ks = [k for k, _, _ in regs]
+    z0, z1 = slab_range(n, rank, world)
+    g = sum(ks[c:])
+    t0, t1 = max(0, (z0 - g) // world * world), min(n, -(-(z1 + g) // world) * world)
+    lo = min([t0] + [max(0, b0 - k) for k, b0, _ in regs[c:]])
+    hi = max([t1] + [min(n, b1 + k) for k, _, b1 in regs[c:]])
+    return {"cyclic": ks[:c], "regions": regs[c:], "recv": (t0, t1), "window": (lo, hi)}
+
+
+class TransposeSlabPipeline:
+    """Z-slab strong scaling with ONE exchange.
+
+    The reference's pass with step k reads the planes z - k, z, z + k of a voxel's plane z and nothing else (jfa/sequential.cpp:72,
+    :92-94).  Phase A: the planes are dealt cyclically -- rank r keeps the planes z = r (mod world) in two windows of n / world planes --
+    and every pass whose step is a multiple of world (all of them down to k = world on a power-of-two grid) runs without any exchange or
+    ghost plane: each rank does exactly 1 / world of the pass, on chains of full length.  Every rank voxelizes the whole grid and takes
+    its border mask, as the ghost pipeline does (0.1 ms at n = 1024); the fused start writes only the rank's planes.  Phase B: one
+    all-to-all -- the planes of rank t's widened slab that rank s holds are a CONTIGUOUS range of s's local planes -- re-deals the state
+    into slabs widened by the reach of the remaining steps (world - 1 planes: 7 for 8 ranks, rounded to 8), a local kernel weaves the
+    received chunks into consecutive planes, and the passes k < world run on the widened slab exactly like the last regions of the ghost
+    pipeline.  Per rank at n = 1024 x 8: 1,280 + 3 x 16 plane-passes against 3,220 (ghost), 0.56 GiB received against 3.5 GiB (halo), id
+    state 2 x 0.5 + 3 x 0.6 GiB.  Grids whose step sequence leaves the multiples of world early (sides that are not powers of two) simply
+    switch to the slab phase earlier, with a wider margin; where fewer than two passes qualify the pipeline IS the ghost pipeline."""
+
+    def __init__(self, backend, frame: Frame, rank: int, world: int, dist):
+        self.be, self.dist = backend, dist
+        self.rank, self.world = rank, world
+        self.global_frame = frame
+        self.be.check_frame(frame)
+        self.z0, self.z1 = slab_range(frame.n, rank, world)
+        self.frame = frame.slab(self.z0, self.z1)
+        min_n = getattr(backend, "tile_min_n", 96)
+        self.plan = transpose_plan(frame.n, rank, world, min_n)
+        self.fallback = None
+        self.bytes_received = 0
+        if self.plan is None:                                      # nothing to deal cyclically: ghost planes
+            self.fallback = GhostSlabPipeline(backend, frame, rank, world)
+            self.words, self.sdf = self.fallback.words, self.fallback.sdf
+            return
+        assert self.be.cyclic_passes(frame, world) == len(self.plan["cyclic"]), "the library counts the cyclic passes differently"
+        n = frame.n
+        self.nzl = n // world                                       # planes of the cyclic share
+        self.words = self.be.empty_u32(frame.words)                 # whole grid: every rank rasterises it
+        self.border = self.be.empty_u32(frame.words)
+        self.sdf = self.be.empty_f32(self.frame.voxels)
+        t0, t1 = self.plan["recv"]
+        lo, hi = self.plan["window"]
+        self.count = (t1 - t0) // world                             # planes every source sends me
+        # what I send to rank t: my local planes [a, b) = the planes = rank (mod world) of t's recv range
+        self.send_ranges = []
+        for t in range(world):
+            p = transpose_plan(n, t, world, min_n)
+            self.send_ranges.append((p["recv"][0] // world, p["recv"][1] // world))
+        # id windows, allocated at first use and kept (a steady-state step allocates nothing): the two of the cyclic phase, the packed
+        # send buffer, the staging buffer the all-to-all fills, the two of the slab phase
+        self._planes = {"cyc0": self.nzl, "cyc1": self.nzl, "send": sum(b - a for a, b in self.send_ranges), "staging": self.count * world,
+                        "ids0": hi - lo, "ids1": hi - lo}
+        self.win = {}
+        self.planes_computed = self.nzl * len(self.plan["cyclic"]) + sum(b1 - b0 for _, b0, b1 in self.plan["regions"])
+
+    def _w(self, name):
+        if name not in self.win:
+            self.win[name] = self.be.window(self.global_frame, self._planes[name])
+        return self.win[name]
+
+    def release(self, *names):
+        """drop id windows (tests that walk the ranks of a large job one after the other on one GPU)"""
+        for nm in names or list(self.win):
+            self.win.pop(nm, None)
+
+    def describe(self):
+        if self.fallback is not None:
+            return self.fallback.describe() + " (no step of this grid is a multiple of the rank count twice: transposed = ghost)"
+        return "x%d transposed: planes dealt cyclically for the %d passes k >= %d (no exchange), one RCCL all-to-all, z-slabs for k < %d" % (
+            self.world, len(self.plan["cyclic"]), self.plan["cyclic"][-1], self.plan["cyclic"][-1])
+
+    def report(self):
+        if self.fallback is not None:
+            return dict(self.fallback.report(), pipeline="transpose->ghost")
+        n, passes = self.global_frame.n, len(self.plan["cyclic"]) + len(self.plan["regions"])
+        return {"pipeline": "transpose", "slab_planes": self.z1 - self.z0, "cyclic_steps": list(self.plan["cyclic"]),
+                "slab_regions": [[k, b0, b1] for k, b0, b1 in self.plan["regions"]], "recv_planes": list(self.plan["recv"]),
+                "window_planes": list(self.plan["window"]), "plane_passes_this_rank": int(self.planes_computed),
+                "plane_passes_one_gpu": n * passes, "plane_pass_ratio": round(n * passes / self.planes_computed, 3),
+                "bytes_received_total": int(self.bytes_received), "hbm_bytes_this_rank": hbm_bytes(self)}
+
+    def voxelize(self, d_xyz, d_tri, algo=ALGO_TILED, out=None):
+        if self.fallback is not None:
+            return self.fallback.voxelize(d_xyz, d_tri, algo, out)
+        out = self.words if out is None else out
+        self.be.voxelize(self.global_frame, out, d_xyz, d_tri, algo)
+        return out
+
+    def csg(self, other, op: int):
+        self.be.csg(self.words, other, op)
+        return self.words
+
+    # -- the four stages of a JFA (jfa() below runs them in order; tests drive them one by one) -----------------------------
+    def phase_a(self):
+        """cyclic planes, no exchange: border mask of the whole grid, the fused start for the rank's planes, every further step that is a
+        multiple of the rank count; returns the window that holds the result"""
+        G, be, w, r = self.global_frame, self.be, self.world, self.rank
+        a, b = self._w("cyc0"), self._w("cyc1")
+        be.surface(G, self.words, self.border)
+        be.win_first_two_cyclic(G, self.border, a, w, r)
+        for k in self.plan["cyclic"][2:]:
+            be.win_pass_cyclic(G, k, a, b, w, r)
+            a, b = b, a
+        return a
+
+    def pack(self, src):
+        """my planes of every rank's widened slab, one contiguous piece per destination (the ranges overlap -- the margins of neighbouring
+        slabs -- and an all-to-all wants disjoint pieces)"""
+        G, be = self.global_frame, self.be
+        send, at = self._w("send"), 0
+        for a, b in self.send_ranges:
+            for dst, piece in zip(be.win_spans(G, send, at, at + (b - a)), be.win_spans(G, src, a, b)):
+                dst.copy_(piece)
+            at += b - a
+
+    def exchange(self):
+        """THE exchange of the job: one all_to_all_single (two above n = 1024: the word part and the byte part of the windows).  Chunk s of
+        the staging window = the planes t0 + s, t0 + s + world, ... of my widened slab, as rank s kept them"""
+        G, be, w = self.global_frame, self.be, self.world
+        send, staging = self._w("send"), self._w("staging")
+        outs = be.win_spans(G, staging, 0, staging.planes)
+        ins = be.win_spans(G, send, 0, send.planes)
+        for o, i in zip(outs, ins):
+            per_plane = o.numel() // staging.planes
+            self.dist.all_to_all_single(o, i, [self.count * per_plane] * w, [(b - a) * per_plane for a, b in self.send_ranges])
+            self.bytes_received += (w - 1) * self.count * per_plane * o.element_size()
+
+    def phase_b(self, fill=-math.inf, out=None):
+        """the weave into consecutive planes, then the remaining steps on the widened slab (as the last regions of the ghost pipeline)"""
+        out = self.sdf if out is None else out
+        G, be = self.global_frame, self.be
+        pw = G.n * G.n // 32
+        lo, _ = self.plan["window"]
+        a, b = self._w("ids0"), self._w("ids1")
+        be.win_interleave(G, self._w("staging"), a, self.plan["recv"][0] - lo, self.world, self.count)
+        regs = self.plan["regions"]
+        for i, (k, b0, b1) in enumerate(regs):
+            region = G.slab(b0, b1)
+            if i == len(regs) - 1:
+                be.win_last_pass(region, a, b, b0 - lo, self.words[b0 * pw:b1 * pw], fill, out)
+                return out
+            be.win_pass(region, k, a, b, b0 - lo)
+            a, b = b, a
+        return out
+
+    def jfa(self, fill=-math.inf, out=None):
+        if self.fallback is not None:
+            return self.fallback.jfa(fill, out)
+        self.pack(self.phase_a())
+        self.exchange()
+        return self.phase_b(fill, out)
+
+
+# =============================================================================================
 def make_pipeline(kind: str, engine, frame: Frame, rank: int, world: int, dist):
-    """bench.py / callers: 'ghost' (no exchange), 'halo' (RCCL point-to-point halos before every pass) or 'hybrid' (ghost planes
-    for the wide passes, overlapped halos for the narrow ones) on the HIP backend."""
+    """bench.py / callers: 'ghost' (no exchange), 'halo' (RCCL point-to-point halos before every pass), 'hybrid' (ghost planes
+    for the wide passes, overlapped halos for the narrow ones) or 'transpose' (cyclic planes, one RCCL all-to-all, slabs) on the HIP backend."""
     be = HipSlabBackend(engine)
     if kind == "ghost":
         return GhostSlabPipeline(be, frame, rank, world)
@@ -574,4 +784,6 @@ def make_pipeline(kind: str, engine, frame: Frame, rank: int, world: int, dist):
         return SlabPipeline(be, frame, rank, world, dist)
     if kind == "hybrid":
         return HybridSlabPipeline(be, frame, rank, world, dist)
+    if kind == "transpose":
+        return TransposeSlabPipeline(be, frame, rank, world, dist)
     raise ValueError("unknown multi-GPU pipeline %r" % kind)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 5
+#define VP_ABI_VERSION 6
 
 enum {
     VP_OK = 0,
@@ -169,9 +169,10 @@ int vp_jfa_run(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, float fi
  *          start (plane p of d_minus is global plane z0-k+p).
  *   finalize: ids -> float sdf for the slab.
  * VP_ALGO_NAIVE serves any such buffers (the direct kernel: one thread per voxel -- the independent form the tile kernels are tested
- * against, pass by pass).  VP_ALGO_TILED: any buffers below n = 96; from there on the tile kernel, which needs 4-byte ids (n <= 1024) and
- * the three buffers to be ONE run of consecutive planes (d_minus + k planes == d_in, d_plus == d_in + the slab: whole grids, and slabs
- * with their halo planes right below / above them) -- anything else is VP_ERR_UNSUPPORTED: hand it over as a window. */
+ * against, pass by pass).  VP_ALGO_TILED: any buffers as well -- the tile kernel where the plain ids ARE a window (4-byte ids, n <= 1024,
+ * and the three buffers ONE run of consecutive planes: d_minus + k planes == d_in, d_plus == d_in + the slab -- whole grids, and slabs
+ * with their halo planes right below / above them), the table kernel below n = 96, the direct kernel for everything else (8-byte ids,
+ * halo buffers of their own): same ids bit for bit, but not the tile kernel's speed -- hand such state over as a window for that. */
 int vp_jfa_init(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words,
                 const uint32_t* d_plane_below, const uint32_t* d_plane_above, void* d_ids);
 int vp_jfa_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const void* d_in,
@@ -228,6 +229,29 @@ int vp_jfa_window_first_two(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_bo
 int vp_jfa_window_pass(vp_ctx* ctx, const vp_frame* f, uint32_t k, const vp_window* in, const vp_window* out, uint32_t stride);
 int vp_jfa_window_last_pass(vp_ctx* ctx, const vp_frame* f, const vp_window* in, const vp_window* scratch, uint32_t stride,
                             const uint32_t* d_words_region, float fill_unset, float* d_sdf_region);
+
+/* CYCLIC plane distribution -- the first phase of the transposed multi-GPU pipeline (VP_MULTI_TRANSPOSE below).
+ * The reference's pass with step k reads, for a voxel of plane z, the planes z - k, z, z + k and nothing else (jfa/sequential.cpp:72: k = n/2
+ * .. 1; :86-94: neighbours at -+k).  With the planes dealt cyclically over G ranks -- plane z on rank z mod G, kept at index z / G of that
+ * rank's window of n / G planes -- every pass whose step is a multiple of G finds all three planes on the rank that owns z: no exchange at
+ * all, chains of full length, and each rank does exactly 1/G of the pass.  G a power of two, n / G a multiple of 8 planes.
+ *   vp_jfa_cyclic_passes            how many passes of the sequence n/2, n/4, ... have such a step, counted from the first (0: none, or fewer
+ *                                   than the two the fused start produces -- use another pipeline)
+ *   vp_jfa_window_first_two_cyclic  the passes k = n/2 and k = n/4 of rank `rank`'s planes from the border bitmask of the WHOLE grid
+ *                                   (vp_jfa_window_first_two restricted to the tiles of the rank's z residues); whole-grid frame, a window of
+ *                                   n / ranks planes, at = 0
+ *   vp_jfa_window_pass_cyclic       one pass with step k (a multiple of `ranks`, one of the first vp_jfa_cyclic_passes steps) over rank `rank`'s
+ *                                   planes; whole-grid frame, two windows of n / ranks planes, at = 0.  Ids hold global coordinates, so the
+ *                                   planes can be handed to the slab form of the calls above as they are
+ *   vp_jfa_window_interleave        the re-deal into slabs: `in` holds `ranks` chunks of `count` planes, chunk s = the planes b0 + s, b0 + s +
+ *                                   ranks, ... of some run of ranks * count consecutive planes as rank s kept them (what an all-to-all of
+ *                                   contiguous plane ranges delivers); plane out->at + j * ranks + s of `out` := plane s * count + j of `in`.
+ *                                   `in` is a window of exactly ranks * count planes (in->at ignored)
+ * Same results as the consecutive-plane calls, id for id. */
+int vp_jfa_cyclic_passes(const vp_frame* f, uint32_t ranks);
+int vp_jfa_window_first_two_cyclic(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_border_grid, const vp_window* out, uint32_t ranks, uint32_t rank);
+int vp_jfa_window_pass_cyclic(vp_ctx* ctx, const vp_frame* f, uint32_t k, const vp_window* in, const vp_window* out, uint32_t ranks, uint32_t rank);
+int vp_jfa_window_interleave(vp_ctx* ctx, const vp_frame* f, const vp_window* in, const vp_window* out, uint32_t ranks, uint32_t count);
 
 /* "Surface" output (README.md:9): the border-voxel mask that JFA seeds
  * from (jfa/sequential.cpp:24-64), as a bitmask with the grid's layout. */
@@ -327,6 +351,7 @@ enum {
     VP_K_JFA_LAST,      /* k = 1 fused with the id -> sdf conversion: S n^3 + 4 n^3 + n^3/8 */
     VP_K_EXTRACT,       /* vp_extract_count / vp_extract: 2 n^3/8 + records */
     VP_K_VOX_ZERO,      /* the voxelizer's zero-fill of the toggle grid (+ the tile histogram): n^3/8 */
+    VP_K_JFA_REDEAL,    /* vp_jfa_window_interleave: 2 S x the planes woven */
     VP_K_COUNT
 };
 int vp_prof_enable(vp_ctx* ctx, int on);

@@ -18,6 +18,8 @@ class CpuSlabBackend:
     """The backend interface of slab.py (HipSlabBackend) on numpy: an id window is `planes` x n x n int32 linear voxel indices (NONE = no
     seed) -- the layout is the backend's own business, the pipelines only move whole planes of it (win_spans)."""
 
+    tile_min_n = 0                            # no tile kernels here: every grid can be dealt cyclically (slab.cyclic_passes)
+
     def __init__(self, mesh_host, poison=None):
         self.mesh_host = mesh_host            # (xyz, tri) numpy: 'device' mesh handles are ignored
         self.poison = poison                  # tests: a voxel index every entry of a fresh window starts as: a (wrong) seed that would spoil the
@@ -87,6 +89,45 @@ class CpuSlabBackend:
 
         _np(w_out.t).reshape(w_out.planes, n, n)[at:at + (z1 - z0)] = self._pass(region, k, plane)
 
+    # -- cyclic plane distribution (TransposeSlabPipeline): local plane l of rank r = global plane r + l * world ----------
+    def cyclic_passes(self, frame, world):
+        from cuda_mesh_voxelization_amd.slab import cyclic_passes
+        return cyclic_passes(frame.n, world, self.tile_min_n)
+
+    def win_first_two_cyclic(self, frame, border_full, w, world, rank):
+        """passes n/2 and n/4 of the rank's planes (z = rank mod world) from the whole-grid border mask"""
+        from cuda_mesh_voxelization_amd.slab import IdWindow
+        n = frame.n
+        assert w.planes == n // world and (n // 4) % world == 0
+        bits = np.unpackbits(_np(border_full).view(np.uint8), bitorder="little").astype(bool).reshape(n, n, n)
+        lin = np.arange(n * n * n, dtype=np.int32).reshape(n, n, n)
+        mine = np.where(bits, lin, NONE).astype(np.int32)[rank::world]
+        tmp = [IdWindow(torch.from_numpy(mine.reshape(-1).copy()), w.planes), IdWindow(torch.zeros(w.planes * n * n, dtype=torch.int32), w.planes)]
+        self.win_pass_cyclic(frame, n // 2, tmp[0], tmp[1], world, rank)
+        self.win_pass_cyclic(frame, n // 4, tmp[1], w, world, rank)
+
+    def win_pass_cyclic(self, frame, k, w_in, w_out, world, rank):
+        n = frame.n
+        assert k % world == 0 and w_in.planes == w_out.planes == n // world
+        A = _np(w_in.t).reshape(w_in.planes, n, n)
+        none_plane = np.full((n, n), NONE, np.int32)
+        zs = [rank + world * l for l in range(w_in.planes)]
+
+        def plane(z, d):
+            zz = z + d * k
+            if zz < 0 or zz >= n:
+                return none_plane
+            assert (zz - rank) % world == 0, "cyclic pass with step %d reads plane %d, which rank %d of %d does not hold" % (k, zz, rank, world)
+            return A[(zz - rank) // world]
+
+        _np(w_out.t).reshape(w_out.planes, n, n)[:] = self._pass(frame, k, plane, zs)
+
+    def win_interleave(self, frame, w_in, w_out, at, world, count):
+        n = frame.n
+        assert w_in.planes == world * count and 0 <= at and at + world * count <= w_out.planes
+        src = _np(w_in.t).reshape(world, count, n, n)
+        _np(w_out.t).reshape(w_out.planes, n, n)[at:at + world * count] = src.transpose(1, 0, 2, 3).reshape(world * count, n, n)
+
     def win_last_pass(self, region, w_in, w_scratch, at, words_region, fill, sdf, stride=1):
         n, nz = region.n, region.z1 - region.z0
         self.win_pass(region, 1, w_in, w_scratch, at, stride)
@@ -137,20 +178,22 @@ class CpuSlabBackend:
         sz = oz + (safe // (n * n)).astype(f32) * vs
         return ((sx - px) * (sx - px) + (sy - py) * (sy - py)) + (sz - pz) * (sz - pz)
 
-    def _pass(self, frame, k, plane):
-        n, z0, z1 = frame.n, frame.z0, frame.z1
-        nz = z1 - z0
+    def _pass(self, frame, k, plane, zs=None):
+        """one pass with step k over the output planes zs (global plane numbers; default: the planes of the frame); plane(z, d) = the id
+        plane z + d k as the caller's window holds it"""
+        n = frame.n
+        zs = list(range(frame.z0, frame.z1)) if zs is None else list(zs)
         f32 = np.float32
         vs, ox, oy, oz = f32(frame.voxel_size), f32(frame.origin[0]), f32(frame.origin[1]), f32(frame.origin[2])
-        S = np.stack([plane(zg, 0) for zg in range(z0, z1)], 0)
-        zz, yy, xx = np.meshgrid(np.arange(z0, z1), np.arange(n), np.arange(n), indexing="ij")
+        S = np.stack([plane(zg, 0) for zg in zs], 0)
+        zz, yy, xx = np.meshgrid(np.array(zs), np.arange(n), np.arange(n), indexing="ij")
         px = ox + xx.astype(f32) * vs
         py = oy + yy.astype(f32) * vs
         pz = oz + zz.astype(f32) * vs
         best = S.copy()
         bestd = np.where(best == NONE, f32(np.inf), self._dist(frame, best, px, py, pz)).astype(f32)
         for dz in (-1, 0, 1):
-            stack = np.stack([plane(zg, dz) for zg in range(z0, z1)], 0)
+            stack = np.stack([plane(zg, dz) for zg in zs], 0)
             pad = np.pad(stack, ((0, 0), (k, k), (k, k)), constant_values=NONE)
             for dy in (-1, 0, 1):
                 for dx in (-1, 0, 1):

@@ -70,7 +70,7 @@ def test_header_symbols_all_exported():
     L = ctypes.CDLL(capi.LIB_PATH)
     for s in declared:
         assert hasattr(L, s), s
-    assert capi.lib().vp_abi_version() == 5
+    assert capi.lib().vp_abi_version() == 6
 
 
 def test_no_gpu_is_a_loud_error_not_a_fallback():

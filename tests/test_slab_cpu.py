@@ -246,3 +246,88 @@ def test_hybrid_plan_feeds_itself():
             assert nz * len(ks) <= work <= ghost
     wide, narrow = hybrid_plan(64, 0, 1)
     assert narrow == [] and [r[1:] for r in wide] == [(0, 64)] * 6
+
+
+# ---------------------------------------------------------------------------------------------- transposed pipeline
+def _transpose_worker(rank, world, port, n, asset, outdir, poison=None):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuda_mesh_voxelization_amd import mesh as M
+        from cuda_mesh_voxelization_amd.capi import Frame
+        from cuda_mesh_voxelization_amd.slab import TransposeSlabPipeline
+        from slab_cpu_backend import CpuSlabBackend
+        mesh = M.import_mesh(M.asset(asset))
+        origin, vs = M.frame([mesh[0]], n)
+        pipe = TransposeSlabPipeline(CpuSlabBackend(mesh, poison=poison), Frame.make(n, vs, origin), rank, world, dist)
+        pipe.voxelize(None, None)
+        sdf = pipe.jfa()
+        dist.barrier()
+        np.save(os.path.join(outdir, "sdf_%d.npy" % rank), sdf.numpy())
+        np.save(os.path.join(outdir, "rep_%d.npy" % rank), np.array([pipe.bytes_received, pipe.planes_computed if pipe.fallback is None else -1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,asset,poison", [(2, 32, "sphere.obj", None), (4, 64, "torus.obj", None), (2, 64, "bunny.obj", 777), (4, 64, "d20.obj", 0),
+                                                  (2, 96, "torus.obj", None)])
+def test_transpose_pipeline_matches_single_domain_oracle(tmp_path, world, n, asset, poison):
+    """Planes dealt cyclically for the passes whose step is a multiple of the rank count (the numpy backend asserts that such a pass
+    reads nothing but planes of its own rank), ONE all_to_all_single over gloo, the weave into consecutive planes, the remaining passes on
+    the widened slab (the backend asserts that no pass reads outside the window).  `poison`: what the planes of a fresh window that
+    nobody ever produces hold -- the result must not depend on it.  n = 96: the step sequence 48, 24, 12, 6, 3, 1 leaves the multiples
+    of two after four passes."""
+    sys.path.insert(0, ROOT)
+    from cuda_mesh_voxelization_amd import mesh as M
+    from cuda_mesh_voxelization_amd.slab import transpose_plan
+    from oracle import oracle as O
+    mp.spawn(_transpose_worker, args=(world, _free_port(), n, asset, str(tmp_path), poison), nprocs=world, join=True)
+    xyz, tri = M.import_mesh(M.asset(asset))
+    origin, vs = M.frame([xyz], n)
+    exp = O.jfa(O.voxelize(xyz, tri, n, vs, origin), n, vs, origin)
+    got = np.concatenate([np.load(tmp_path / ("sdf_%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    for r in range(world):
+        rx, planes = [int(v) for v in np.load(tmp_path / ("rep_%d.npy" % r))]
+        plan = transpose_plan(n, r, world, 0)
+        t0, t1 = plan["recv"]
+        assert rx == (world - 1) * ((t1 - t0) // world) * n * n * 4          # one exchange: the planes of the widened slab the others hold
+        assert planes == (n // world) * len(plan["cyclic"]) + sum(b1 - b0 for _, b0, b1 in plan["regions"])
+
+
+def test_transpose_plan_feeds_itself():
+    """Cyclic steps: multiples of the rank count, from n/2 on, at least two.  Slab regions: as in the ghost plan, each produces the slab
+    widened by the reach of the later steps and reads only what the all-to-all delivered or the region before it produced; the window
+    holds everything any region reads.  Plane-passes per rank stay within 1.25 x the ideal n / world per pass on power-of-two grids."""
+    sys.path.insert(0, ROOT)
+    from cuda_mesh_voxelization_amd.slab import cyclic_passes, ghost_regions, slab_range, transpose_plan
+    for n, world in ((512, 2), (512, 4), (512, 8), (1024, 2), (1024, 4), (1024, 8), (2048, 8), (2048, 4), (96, 2), (1152, 8), (1280, 8), (288, 4), (256, 16)):
+        for rank in range(world):
+            plan = transpose_plan(n, rank, world)
+            z0, z1 = slab_range(n, rank, world)
+            ks = plan["cyclic"] + [k for k, _, _ in plan["regions"]]
+            assert ks == [k for k, _, _ in ghost_regions(n, rank, world)] and len(plan["cyclic"]) == cyclic_passes(n, world) >= 2
+            assert all(k % world == 0 and n % k == 0 for k in plan["cyclic"]) and plan["regions"][0][0] % world != 0
+            t0, t1 = plan["recv"]
+            lo, hi = plan["window"]
+            g = sum(k for k, _, _ in plan["regions"])
+            assert t0 % world == 0 and t1 % world == 0 and 0 <= lo <= t0 <= max(0, z0 - g) and min(n, z1 + g) <= t1 <= hi <= n
+            valid = (t0, t1)
+            for i, (k, b0, b1) in enumerate(plan["regions"]):
+                gi = sum(kk for kk, _, _ in plan["regions"][i + 1:])
+                u0, u1 = max(0, z0 - gi), min(n, z1 + gi)                 # planes whose values matter
+                assert b0 % 8 == 0 and b1 % 8 == 0 and lo <= b0 <= u0 < u1 <= b1 <= hi
+                assert valid[0] <= max(0, u0 - k) and min(n, u1 + k) <= valid[1], (n, world, rank, k)
+                assert lo <= max(0, b0 - k) and min(n, b1 + k) <= hi        # what the rounded region reads lies inside the window
+                valid = (u0, u1)
+            assert plan["regions"][-1] == (1, z0, z1)
+            work = (n // world) * len(plan["cyclic"]) + sum(b1 - b0 for _, b0, b1 in plan["regions"])
+            if n & (n - 1) == 0 and n // world >= 64:
+                assert work <= 1.25 * (n // world) * len(ks), (n, world, work)
+    # below the tile kernels, one rank, slabs that are not a multiple of 8 planes, a rank count that is not a power of two
+    # (slabs of a multiple of 8 planes make n/4 a multiple of the rank count: where the split is legal at all there are two cyclic passes)
+    assert all(transpose_plan(*a) is None for a in ((64, 0, 2), (512, 0, 1), (96, 0, 8), (384, 0, 3)))
+    assert cyclic_passes(96, 4) == 3 and cyclic_passes(128, 8) == 4 and cyclic_passes(1024, 8) == 7 and cyclic_passes(160, 4) == 3

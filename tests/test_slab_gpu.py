@@ -12,7 +12,7 @@ import torch
 from cuda_mesh_voxelization_amd import mesh as M
 from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, Frame
 from cuda_mesh_voxelization_amd.pipeline import Engine
-from cuda_mesh_voxelization_amd.slab import HipSlabBackend, HybridSlabPipeline, SlabPipeline
+from cuda_mesh_voxelization_amd.slab import HipSlabBackend, HybridSlabPipeline, SlabPipeline, TransposeSlabPipeline
 
 pytestmark = pytest.mark.gpu
 
@@ -48,13 +48,24 @@ class LoopbackDist:
                 reqs.append(_Req(rx))
         return reqs
 
+    def all_to_all_single(self, output, input, output_split_sizes=None, input_split_sizes=None):
+        world = max(b for _, b in self.queues) + 1
+        at = 0
+        for t in range(world):
+            self.queues[(self.rank, t)].put(input[at:at + input_split_sizes[t]].clone())
+            at += input_split_sizes[t]
+        at = 0
+        for s in range(world):
+            output[at:at + output_split_sizes[s]].copy_(self.queues[(s, self.rank)].get(timeout=300))
+            at += output_split_sizes[s]
+
 
 def _run_slabs(world, frame, xyz, tri, algo, kind="halo", poison=None):
     queues = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
     engines = [Engine(0) for _ in range(world)]
     pipes, errors = [], []
     for r in range(world):
-        cls = SlabPipeline if kind == "halo" else HybridSlabPipeline
+        cls = {"halo": SlabPipeline, "hybrid": HybridSlabPipeline, "transpose": TransposeSlabPipeline}[kind]
         pipes.append(cls(HipSlabBackend(engines[r], poison=poison), frame, r, world, LoopbackDist(r, queues)))
     meshes = [engines[r].mesh_to_device(xyz, tri) for r in range(world)]
 
@@ -73,7 +84,7 @@ def _run_slabs(world, frame, xyz, tri, algo, kind="halo", poison=None):
     for t in threads:
         t.join(600)
     assert not errors, errors
-    if kind == "hybrid":                                         # every rank holds the whole bitmask there
+    if kind in ("hybrid", "transpose"):                          # every rank holds the whole bitmask there
         pw = frame.n * frame.n // 32
         words = np.concatenate([Engine.words_to_numpy(p.words[p.z0 * pw:p.z1 * pw]) for p in pipes])
     else:
@@ -175,6 +186,130 @@ def test_ghost_windows_equal_whole_grid(engine, world, n, poison):
     gc.collect(); torch.cuda.empty_cache()
 
 
+def _window_parts(t, n, planes):
+    """(word planes as [planes, n*n] int32, byte planes as [planes, n*n] uint8 or None) of an id window tensor"""
+    vox = planes * n * n
+    words = t[:vox * 4].view(torch.int32).view(planes, n * n)
+    return words, (t[vox * 4:vox * 5].view(planes, n * n) if n > 1024 else None)
+
+
+@pytest.mark.parametrize("world,n,name", [(2, 96, "bunny.obj"), (4, 128, "torus.obj"), (8, 128, "d20.obj"), (8, 256, "bunny.obj"), (2, 512, "bimba.obj"),
+                                          (8, 512, "bunny.obj"), (4, 160, "sphere.obj"), (8, 1024, "bimba.obj"), (8, 1152, "bunny.obj"), (4, 1280, "bimba.obj")])
+def test_cyclic_passes_equal_whole_grid_passes(engine, world, n, name):
+    """Every pass of the cyclic phase, id for id: the window of rank r after the fused start and after each vp_jfa_window_pass_cyclic must
+    hold exactly the planes r, r + world, ... of the whole-grid window after the same pass (vp_jfa_window_first_two / vp_jfa_window_pass:
+    closed tiles at k = n/8, pair mode, compact ids above n = 1024, steps that are not powers of two at n = 96 / 160 / 1152 / 1280)."""
+    import gc
+    from cuda_mesh_voxelization_amd.capi import Window
+    from cuda_mesh_voxelization_amd.slab import cyclic_passes
+    gc.collect(); torch.cuda.empty_cache()
+    ctx = engine.ctx
+    xyz, tri = M.import_mesh(M.asset(name))
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    words = engine.voxelize(fr, dx, dt)
+    border = torch.empty_like(words)
+    ctx.surface(fr, words.data_ptr(), None, None, border.data_ptr())
+    c = cyclic_passes(n, world)
+    assert c >= 2 and ctx.jfa_cyclic_passes(fr, world) == c
+    nzl = n // world
+    whole = [torch.empty(ctx.jfa_window_bytes(fr, n), dtype=torch.uint8, device=engine.device) for _ in range(2)]
+    mine = [[torch.empty(ctx.jfa_window_bytes(fr, nzl), dtype=torch.uint8, device=engine.device) for _ in range(2)] for _ in range(world)]
+    W = lambda t, planes: Window.make(t.data_ptr(), t.numel(), planes, 0)
+
+    def compare(cur, step):
+        rw, rb = _window_parts(whole[cur], n, n)
+        for r in range(world):
+            gw, gb = _window_parts(mine[r][cur], n, nzl)
+            assert torch.equal(gw, rw[r::world]), ("words", step, r)
+            if rb is not None:
+                assert torch.equal(gb, rb[r::world]), ("bytes", step, r)
+
+    ctx.jfa_window_first_two(fr, border.data_ptr(), W(whole[0], n))
+    for r in range(world):
+        ctx.jfa_window_first_two_cyclic(fr, border.data_ptr(), W(mine[r][0], nzl), world, r)
+    compare(0, n // 4)
+    cur, k = 0, n // 8
+    for _ in range(c - 2):
+        ctx.jfa_window_pass(fr, k, W(whole[cur], n), W(whole[cur ^ 1], n))
+        for r in range(world):
+            ctx.jfa_window_pass_cyclic(fr, k, W(mine[r][cur], nzl), W(mine[r][cur ^ 1], nzl), world, r)
+        cur ^= 1
+        compare(cur, k)
+        k //= 2
+    assert k % world != 0 or k == 0
+    # what the call refuses: a step that is not one of the cyclic ones, windows of the wrong size, overlapping windows
+    from cuda_mesh_voxelization_amd.capi import VPError
+    with pytest.raises(VPError):
+        ctx.jfa_window_pass_cyclic(fr, k if k else 1, W(mine[0][0], nzl), W(mine[0][1], nzl), world, 0)
+    with pytest.raises(VPError):
+        ctx.jfa_window_pass_cyclic(fr, n // 8, W(whole[0], n), W(whole[1], n), world, 0)
+    with pytest.raises(VPError):
+        ctx.jfa_window_pass_cyclic(fr, n // 8, W(mine[0][0], nzl), W(mine[0][0], nzl), world, 0)
+    del whole, mine
+    gc.collect(); torch.cuda.empty_cache()
+
+
+def test_window_interleave(engine):
+    """vp_jfa_window_interleave: plane at + j * ranks + s of the output := plane s * count + j of the input, word planes and (n > 1024) byte planes"""
+    from cuda_mesh_voxelization_amd.capi import VPError, Window
+    ctx = engine.ctx
+    for n, ranks, count, at, planes in ((128, 4, 3, 5, 20), (1056, 2, 2, 1, 6)):
+        fr = Frame.make(n, 0.01, (0.0, 0.0, 0.0))
+        src = torch.randint(0, 255, (ctx.jfa_window_bytes(fr, ranks * count),), dtype=torch.uint8, device=engine.device)
+        dst = torch.zeros(ctx.jfa_window_bytes(fr, planes), dtype=torch.uint8, device=engine.device)
+        ctx.jfa_window_interleave(fr, Window.make(src.data_ptr(), src.numel(), ranks * count, 0), Window.make(dst.data_ptr(), dst.numel(), planes, at), ranks, count)
+        sw, sb = _window_parts(src, n, ranks * count)
+        dw, db = _window_parts(dst, n, planes)
+        for kind, a, b in (("w", sw, dw), ("b", sb, db)):
+            if a is None:
+                continue
+            want = torch.zeros_like(b)
+            want[at:at + ranks * count] = a.view(ranks, count, -1).transpose(0, 1).reshape(ranks * count, -1)
+            assert torch.equal(b, want), (n, kind)
+        with pytest.raises(VPError):
+            ctx.jfa_window_interleave(fr, Window.make(src.data_ptr(), src.numel(), ranks * count, 0), Window.make(dst.data_ptr(), dst.numel(), planes, planes - 1), ranks, count)
+
+
+@pytest.mark.parametrize("world,n,name,poison", [(2, 96, "bunny.obj", None), (4, 128, "torus.obj", 0xA5), (8, 128, "d20.obj", None), (8, 256, "bunny.obj", None),
+                                                 (2, 512, "bimba.obj", None), (8, 512, "bunny.obj", 0xFF), (4, 160, "sphere.obj", None), (4, 1152, "bimba.obj", None),
+                                                 (8, 1280, "bunny.obj", 0x5A)])
+def test_transpose_slabs_equal_whole_grid(engine, world, n, name, poison):
+    """TransposeSlabPipeline with the real kernels, all emulated ranks at once: cyclic planes for the steps that are multiples of the rank
+    count, one all_to_all_single (in-process loopback), the weave, the remaining steps on the widened slab.  `poison`: the word planes of
+    every fresh window are overwritten with an arbitrary byte -- planes nobody produces must not matter."""
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    xyz, tri = M.import_mesh(M.asset(name))
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    ref_w = engine.voxelize(fr, dx, dt)
+    ref_s = engine.jfa(fr, ref_w).cpu().numpy()
+    ref_w = engine.words_to_numpy(ref_w)
+    words, sdf = _run_slabs(world, fr, xyz, tri, ALGO_TILED, kind="transpose", poison=poison)
+    assert np.array_equal(words, ref_w)
+    assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
+
+
+def test_transpose_falls_back_to_ghost_planes(engine):
+    """three ranks: no cyclic distribution (not a power of two) -- the pipeline is the ghost pipeline and says so"""
+    xyz, tri = M.import_mesh(M.asset("torus.obj"))
+    n, world = 192, 3
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    ref_s = engine.jfa(fr, engine.voxelize(fr, dx, dt)).cpu().numpy()
+    parts = []
+    for r in range(world):
+        pipe = TransposeSlabPipeline(HipSlabBackend(engine), fr, r, world, None)
+        assert pipe.fallback is not None and pipe.report()["pipeline"] == "transpose->ghost"
+        pipe.voxelize(dx, dt)
+        parts.append(pipe.jfa().cpu().numpy())
+    assert np.array_equal(np.concatenate(parts).view(np.uint32), ref_s.view(np.uint32))
+
+
 def test_pipelines_refuse_grids_below_the_tile_kernels(engine):
     from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline
     fr = Frame.make(64, 0.1, (0.0, 0.0, 0.0))
@@ -229,6 +364,13 @@ def test_config4_n1024_four_slabs(engine):
     words, sdf = _run_slabs(world, fr, xyz, tri, ALGO_TILED, kind="hybrid")   # ghost planes for k = 512, 256; halos for k <= 128
     assert np.array_equal(words, engine.words_to_numpy(ref_w))
     assert np.array_equal(sdf.view(np.uint32), ref_s.cpu().numpy().view(np.uint32))
+    del words, sdf
+    for w in (4, 8):                                           # transposed: cyclic planes for k >= w, one all-to-all, slabs for k < w
+        gc.collect(); torch.cuda.empty_cache()
+        words, sdf = _run_slabs(w, fr, xyz, tri, ALGO_TILED, kind="transpose")
+        assert np.array_equal(words, engine.words_to_numpy(ref_w)), ("transpose", w)
+        assert np.array_equal(sdf.view(np.uint32), ref_s.cpu().numpy().view(np.uint32)), ("transpose", w)
+        del words, sdf
 
 
 def test_config5_n2048_eight_ghost_slabs(engine):
@@ -262,6 +404,70 @@ def test_config5_n2048_eight_ghost_slabs(engine):
         assert torch.equal(s.view(torch.int32), ref_s[r * nzv:(r + 1) * nzv].view(torch.int32)), r
         del s
     del pipe, ref_s
+    gc.collect(); torch.cuda.empty_cache()
+
+
+def test_config5_n2048_eight_transposed_ranks(engine):
+    """BASELINE config 5 (10,785,024 faces, n = 2048, 5-byte windows), eight ranks, transposed pipeline.  The ranks are walked one after
+    the other on the one GPU: the cyclic phase of every rank first (its packed send buffer is kept, 5.3 GiB each), then the exchange --
+    an all_to_all_single served from those buffers -- and the slab phase of every rank; every slab bit-identical to the one-GPU result."""
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 230 * 2**30:
+        pytest.skip("needs ~200 GiB of free HBM, %.0f GiB free" % (free / 2**30))
+    xyz, tri = M.bunny(192)
+    n, world = 2048, 8
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    dx, dt = engine.mesh_to_device(xyz, tri)
+    ref_w = engine.voxelize(fr, dx, dt)
+    ref_s = engine.jfa(fr, ref_w).clone()
+    del ref_w
+    engine._work = None
+    gc.collect(); torch.cuda.empty_cache()
+    sent = {}                                                   # (source rank, part) -> (tensor, split sizes)
+
+    class StashDist:
+        def __init__(self, rank):
+            self.rank, self.part = rank, 0
+
+        def all_to_all_single(self, output, input, output_split_sizes=None, input_split_sizes=None):
+            at = 0
+            for s_ in range(world):
+                t, splits = sent[(s_, self.part)]
+                off = sum(splits[:self.rank])
+                output[at:at + output_split_sizes[s_]].copy_(t[off:off + splits[self.rank]])
+                at += output_split_sizes[s_]
+            self.part += 1
+
+    pipes = []
+    for r in range(world):
+        pipe = TransposeSlabPipeline(HipSlabBackend(engine), fr, r, world, StashDist(r))
+        assert pipe.fallback is None and pipe.plan["cyclic"][-1] == 8
+        pipe.voxelize(dx, dt)
+        pipe.pack(pipe.phase_a())
+        pipe.release("cyc0", "cyc1")
+        send = pipe.win["send"]
+        for part, t in enumerate(pipe.be.win_spans(fr, send, 0, send.planes)):
+            per_plane = t.numel() // send.planes
+            sent[(r, part)] = (t, [(b - a) * per_plane for a, b in pipe.send_ranges])
+        pipe.words = pipe.border = None                         # 2 GiB per rank; the slab phase needs the words again: re-voxelized below
+        pipes.append(pipe)
+        gc.collect(); torch.cuda.empty_cache()
+    nzv = fr.voxels // world
+    for r, pipe in enumerate(pipes):
+        pipe.words = pipe.be.empty_u32(fr.words)
+        pipe.voxelize(dx, dt)
+        pipe.exchange()
+        s = pipe.phase_b()
+        assert torch.equal(s.view(torch.int32), ref_s[r * nzv:(r + 1) * nzv].view(torch.int32)), r
+        assert pipe.bytes_received == 7 * pipe.count * n * n * 5 <= 5.5e9        # the one exchange of the job, per rank
+        del s
+        pipe.release("staging", "ids0", "ids1")
+        pipe.words = pipe.sdf = None
+        gc.collect(); torch.cuda.empty_cache()
+    del pipes, sent, ref_s
     gc.collect(); torch.cuda.empty_cache()
 
 
