@@ -9,6 +9,10 @@ ghost planes (no exchange): every rank of a G-GPU job is run on THIS GPU with th
 hybrid (ghost planes for k > nz/2, halos of the adjacent ranks for k <= nz/2): plane-passes per rank and bytes received per side are
   exact (slab.hybrid_plan); times are a MODEL: plane-passes x the measured single-GPU time per plane-pass, + the halo bytes of one
   side at an assumed per-link rate, once fully hidden under the interior planes and once not hidden at all.
+transposed (cyclic planes for the steps that are multiples of G, one all-to-all, slabs for the rest): per-rank COMPUTE is measured on this
+  GPU with the real kernels on real data -- the cyclic phase + the pack of the send buffer, then the weave + the slab phase on a staging
+  buffer filled with exactly the planes the all-to-all would deliver (cut from the whole-grid state after the cyclic steps, computed here);
+  bytes received per rank are exact; the exchange time is a MODEL (bytes / an assumed aggregate ingest rate).
 halo exchange: bytes each rank must RECEIVE over xGMI per job (exact, from slab.halo_plan) and the time that takes at two
   assumed per-GPU ingest rates -- a model (no multi-GPU box is reachable from here); compute per rank is the measured
   single-GPU time / G at best.
@@ -19,7 +23,10 @@ import torch
 from cuda_mesh_voxelization_amd import mesh as M
 from cuda_mesh_voxelization_amd.capi import ALGO_TILED, Frame
 from cuda_mesh_voxelization_amd.pipeline import Engine
-from cuda_mesh_voxelization_amd.slab import GhostSlabPipeline, HipSlabBackend, HybridSlabPipeline, SlabPipeline, halo_plan, ghost_regions, hybrid_plan
+from cuda_mesh_voxelization_amd.capi import Window
+from cuda_mesh_voxelization_amd.slab import (GhostSlabPipeline, HipSlabBackend, HybridSlabPipeline, SlabPipeline, TransposeSlabPipeline, halo_plan, ghost_regions,
+                                             hybrid_plan, transpose_plan)
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else ["ghost", "transpose", "halo", "hybrid"]
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 refine = 24 if n <= 1024 else 192
@@ -42,7 +49,7 @@ del g, sdf; eng._work = None; torch.cuda.empty_cache()
 print("n = %d, %d faces, id bytes S = %d, %d passes; 1 GPU: %.3f ms per job" % (n, tri.shape[0], S, passes, t1))
 print("\nghost planes (measured per rank on one GPU; job = slowest rank; nothing is exchanged)")
 print("  G   job ms  speedup  efficiency  plane-passes/rank (1 GPU: %d)  pp-ratio  per-rank ms" % (n * passes))
-for world in (2, 4, 8):
+for world in ((2, 4, 8) if "ghost" in only else ()):
     ts, pp = [], []
     for r in range(world):
         pipe = GhostSlabPipeline(HipSlabBackend(eng), fr, r, world)
@@ -51,6 +58,61 @@ for world in (2, 4, 8):
         del pipe; torch.cuda.empty_cache()
     print("  %d  %7.3f  %6.2fx  %9.0f%%  %8d                        %5.2fx   %s"
           % (world, max(ts), t1 / max(ts), 100 * t1 / max(ts) / world, max(pp), n * passes / max(pp), " ".join("%.2f" % t for t in ts)))
+
+# ---------------------------------------------------------------------------------------------- transposed
+class NoDist:
+    def all_to_all_single(self, *a, **k): pass
+
+if "transpose" in only:
+    print("\ntransposed (per-rank compute measured on this GPU, real kernels, real data; exchange: exact bytes, time MODELLED)")
+    print("  G   cyclic steps   slab steps   compute ms: slowest rank (phase A + pack | weave + phase B)   <= 1.25 t1/G ?   GiB received/rank   "
+          "+ exchange @ 300 / 150 GB/s into the rank   speedup vs 1 GPU   per-rank ms")
+    ctx = eng.ctx
+    words = eng.voxelize(fr, dx, dt)
+    border = torch.empty_like(words)
+    ctx.surface(fr, words.data_ptr(), None, None, border.data_ptr())
+    for world in (2, 4, 8):
+        plan0 = transpose_plan(n, 0, world)
+        if plan0 is None:
+            print("  %d   (no cyclic distribution for this grid)" % world); continue
+        c = len(plan0["cyclic"])
+        # the whole-grid state after the cyclic steps: what the all-to-all cuts the staging buffers from
+        whole = [torch.empty(ctx.jfa_window_bytes(fr, n), dtype=torch.uint8, device=eng.device) for _ in range(2)]
+        W = lambda t: Window.make(t.data_ptr(), t.numel(), n, 0)
+        ctx.jfa_window_first_two(fr, border.data_ptr(), W(whole[0]))
+        cur, k = 0, n // 8
+        for _ in range(c - 2):
+            ctx.jfa_window_pass(fr, k, W(whole[cur]), W(whole[cur ^ 1])); cur ^= 1; k //= 2
+        state = whole[cur]; del whole
+        vox = n * n * n
+        sw = state[:vox * 4].view(n, n * n * 4); sb = state[vox * 4:vox * 5].view(n, n * n) if n > 1024 else None
+        ta, tb, rx = [], [], []
+        for r in range(world):
+            pipe = TransposeSlabPipeline(HipSlabBackend(eng), fr, r, world, NoDist())
+            def stepA(): pipe.voxelize(dx, dt); pipe.pack(pipe.phase_a())
+            ta.append(timeit(stepA, max(2, reps // 2)))
+            t0, t1_ = pipe.plan["recv"]
+            staging = pipe._w("staging")
+            parts = pipe.be.win_spans(fr, staging, 0, staging.planes)
+            for part, src in zip(parts, (sw, sb)):
+                part.view(world, pipe.count, -1).copy_(src[t0:t1_].view(pipe.count, world, -1).transpose(0, 1))
+            def stepB(): pipe.phase_b()
+            tb.append(timeit(stepB, max(2, reps // 2)))
+            pipe.exchange(); rx.append(pipe.bytes_received)      # (NoDist: only the byte count)
+            del pipe, staging, parts; torch.cuda.empty_cache()
+        tot = [a + b for a, b in zip(ta, tb)]
+        i = max(range(world), key=lambda j: tot[j])
+        b = max(rx)
+        x300, x150 = b / 300e9 * 1e3, b / 150e9 * 1e3
+        print("  %d   %-14s %-12s %8.3f (%.3f | %.3f)   %s (%.3f)   %6.3f   %8.3f / %8.3f ms   %.2fx / %.2fx (compute only: %.2fx)   %s"
+              % (world, "%d..%d" % (plan0["cyclic"][0], plan0["cyclic"][-1]), ",".join(str(k_) for k_, _, _ in plan0["regions"]), tot[i], ta[i], tb[i],
+                 "yes" if tot[i] <= 1.25 * t1 / world else "NO", 1.25 * t1 / world, b / 2**30, tot[i] + x300, tot[i] + x150,
+                 t1 / (tot[i] + x300), t1 / (tot[i] + x150), t1 / tot[i], " ".join("%.2f" % t for t in tot)))
+        del state, sw, sb; torch.cuda.empty_cache()
+    del words, border; torch.cuda.empty_cache()
+
+if "halo" not in only and "hybrid" not in only:
+    sys.exit(0)
 print("\nhalo exchange (bytes received per rank and job: exact; times: MODEL at an assumed per-GPU ingest rate)")
 print("  G   max GiB received/rank   @150 GB/s   @400 GB/s   + compute >= t1/G   vs 1 GPU")
 plane = n * n * S
