@@ -24,10 +24,11 @@ Rank 0 prints ONE JSON line (DESIGN.md "Measurement"):
 
 N > 1: strong scaling of the same n^3 job over N Z-slabs, one process per GPU (cuda_mesh_voxelization_amd/slab.py).  After the
 timed region every rank runs the ONE-GPU path on its own device and compares its slab of the bitmask and of the sdf bit for
-bit (`parity_ok`; a mismatch on any rank makes the run exit non-zero), then times the OTHER transport (`multi_alt`: RCCL halos
-when the job ran ghost planes and vice versa) over a shorter region, checked the same way -- under a watchdog
-(VP_BENCH_ALT_TIMEOUT, default 180 s): if that transport hangs, rank 0 prints the line of the timed pipeline as it stands, with the
-time-out recorded in `multi_alt`, and the job ends.
+bit (`parity_ok`; a mismatch on any rank makes the run exit non-zero), then times the OTHER pipelines over shorter regions, checked
+the same way: `multi_alt` = the transposed pipeline (cyclic planes, ONE RCCL all-to-all; ghost planes when the job itself ran
+transposed), `multi_alt_halo` = RCCL point-to-point halos before every pass -- under a watchdog (VP_BENCH_ALT_TIMEOUT, default 180 s
+each): if a transport hangs, rank 0 prints the line of the timed pipeline as it stands, with the time-out recorded in that object,
+and the job ends with exit code 2 (VP_BENCH_LENIENT=1: 0).
 """
 from __future__ import annotations
 
@@ -61,11 +62,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE config 3 block (bimba + bunny, CSG union, JFA at n = 512)")
     ap.add_argument("--no-host-totals", action="store_true", help="skip the host-in / host-out round (reference-style totals)")
     ap.add_argument("--no-copy-peak", action="store_true", help="skip the 1-GiB stream-copy measurement")
-    ap.add_argument("--multi", choices=["ghost", "halo", "hybrid"], default="ghost",
-                    help="N > 1: 'ghost' = Z-slabs with recomputed ghost planes, no data-path exchange (default: a plane costs ~1 us "
-                         "to recompute and ~20 us to move over xGMI); 'halo' = Z-slabs with RCCL point-to-point halo planes before every pass; "
-                         "'hybrid' = ghost planes for the wide passes (k > nz/2), halos of the adjacent ranks -- sent a pass ahead, under the "
-                         "interior planes -- for the narrow ones; id buffers hold only the planes a rank touches")
+    ap.add_argument("--multi", choices=["ghost", "halo", "hybrid", "transpose"], default="ghost",
+                    help="N > 1: 'ghost' = Z-slabs with recomputed ghost planes, no data-path exchange (default: the one pipeline that needs no "
+                         "transport the build could never try on hardware); 'transpose' = planes dealt cyclically for every pass whose step is a "
+                         "multiple of N (no exchange, no ghost planes), ONE RCCL all-to-all, Z-slabs for the last log2 N passes; 'halo' = Z-slabs "
+                         "with RCCL point-to-point halo planes before every pass; 'hybrid' = ghost planes for the wide passes (k > nz/2), halos of "
+                         "the adjacent ranks -- sent a pass ahead, under the interior planes -- for the narrow ones")
     return ap.parse_args(argv)
 
 
@@ -74,17 +76,15 @@ def launch_ranks(args):
     imported yet -- and starts the N ranks as a FRESH child (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
     <same arguments>`, never an exec), forwards rank 0's JSON line to its own stdout, everything else the ranks print to stderr, and
     returns the child's exit code.  The reference hard-wires device 0 (apps/cli/main.cpp:22-23); this is what replaces it for N > 1."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     argv = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--grid-n", str(args.n), "--multi", args.multi]
     for flag in ("no_cpu_baseline", "no_n1024", "no_config3", "no_host_totals", "no_copy_peak"):
         if getattr(args, flag):
             argv.append("--" + flag.replace("_", "-"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # --standalone: the launcher's own rendezvous on a port IT picks and keeps (binding one here and closing it again could lose it to another
+    # process in between, ADVICE r05)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           os.path.abspath(__file__)] + argv
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
     lines = 0
@@ -395,7 +395,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipe_report, pipe_desc, parity, multi_alt = None, None, None, None
+    pipe_report, pipe_desc, parity, multi_alt, alts_ok = None, None, None, None, True
     if world == 1:
         barrier()
         elapsed, live, table = run_single(eng, frame, d_xyz, d_tri, args.steps, args.warmup, ALGO_TILED)
@@ -457,11 +457,13 @@ def main():
                   "against": "the one-GPU path (vp_voxelize + vp_jfa of the whole grid) run on each rank's own device after the timed region"}
         # ---- the other transport in the same job, over a shorter region (so that a scaling run shows RCCL moving halos and not
         # only barriers when the default is ghost planes, and the exchange-free figure when it is not)
-        alt_kind = "halo" if args.multi != "halo" else "ghost"
+        # `multi_alt` = the transposed pipeline (ghost planes if that is what the job itself ran), then the remaining one of halo / ghost
+        alt_kinds = [k for k in ("transpose", "halo", "ghost") if k != args.multi][:2]
+        alt_keys = ["multi_alt"] + ["multi_alt_" + k for k in alt_kinds[1:]]
         alt_steps = max(2, args.steps // 4)
 
-        def alt_region():
-            """every rank: time the other pipeline, compare its slab, agree on the outcome; returns the `multi_alt` object"""
+        def alt_region(alt_kind):
+            """every rank: time another pipeline, compare its slab, agree on the outcome; returns its `multi_alt*` object"""
             alt_error, aflags = None, [False, False]
             try:
                 # the secondary measurement must not cost the primary one: an exception here (first contact of a transport with real
@@ -582,42 +584,52 @@ def main():
         if world == 1 and not args.no_cpu_baseline and n == N_GRID:
             out["cpu_baseline"] = cpu_baseline(xyz, tri, origin, vs, n)
     if world > 1:
-        # The other transport runs under a watchdog: a transport that HANGS on hardware the build never saw (a point-to-point pair that
-        # never completes cannot be cancelled) must not take the timed pipeline's line with it.  After VP_BENCH_ALT_TIMEOUT seconds
-        # (default 180) rank 0 prints the line it already has, with the time-out recorded in `multi_alt`, and every rank leaves.
+        # The other pipelines run under a watchdog: a transport that HANGS on hardware the build never saw (a collective that never completes
+        # cannot be cancelled) must not take the timed pipeline's line with it.  After VP_BENCH_ALT_TIMEOUT seconds (default 180, per
+        # pipeline) rank 0 prints the line it already has, with the time-out recorded in that pipeline's object, and every rank leaves.
         import threading
         limit = float(os.environ.get("VP_BENCH_ALT_TIMEOUT", "180"))
-        lock, finished, printed = threading.Lock(), [False], [False]
-        # exit code of a run whose OTHER transport hung: 0 -- the line's own measurement and its parity check stand and the time-out is in
-        # the line (`multi_alt.error`) -- unless VP_BENCH_STRICT=1 asks for 2
-        hang_rc = 2 if os.environ.get("VP_BENCH_STRICT") == "1" else 0
+        lock, finished, printed, current = threading.Lock(), [False], [False], [0]
+        # exit code of a run in which another transport HUNG: 2 -- the line's own measurement and its parity check stand and the time-out is in
+        # the line, but whoever only looks at the exit status must see that something never came back; VP_BENCH_LENIENT=1: 0
+        hang_rc = 0 if os.environ.get("VP_BENCH_LENIENT") == "1" else 2
+        alts = {}
 
         def give_up():
             with lock:
                 if finished[0]:
                     return
                 if rank == 0 and not printed[0]:
-                    out["multi_alt"] = {"pipeline": alt_kind, "steps": alt_steps, "ms_per_step": None, "value": None, "parity_ok": None,
-                                        "error": "no result within %.0f s (VP_BENCH_ALT_TIMEOUT): the transport hung; the timed "
-                                                 "pipeline's figures and parity above stand" % limit}
+                    out.update(alts)
+                    out[alt_keys[current[0]]] = {"pipeline": alt_kinds[current[0]], "steps": alt_steps, "ms_per_step": None, "value": None, "parity_ok": None,
+                                                 "error": "no result within %.0f s (VP_BENCH_ALT_TIMEOUT): the transport hung; the timed "
+                                                          "pipeline's figures and parity above stand" % limit}
                     print(json.dumps(out), flush=True)
                 sys.stdout.flush()
-                sys.stderr.write("bench.py: rank %d gave up on the other transport after %.0f s\n" % (rank, limit))
+                sys.stderr.write("bench.py: rank %d gave up on the %s pipeline after %.0f s\n" % (rank, alt_kinds[current[0]], limit))
                 sys.stderr.flush()
                 os._exit(hang_rc if parity["parity_ok"] else 1)
 
-        # the timer stays armed until every rank is through the LAST barrier: a rank that finished the region while another one timed out
+        # a timer stays armed until every rank is through the LAST barrier: a rank that finished the region while another one timed out
         # and left would otherwise wait in that barrier for ever
-        timer = threading.Timer(limit, give_up)
-        timer.daemon = True
-        timer.start()
-        multi_alt = alt_region()
+        for i, kind in enumerate(alt_kinds):
+            with lock:
+                current[0] = i
+            timer = threading.Timer(limit, give_up)
+            timer.daemon = True
+            timer.start()
+            alts[alt_keys[i]] = alt_region(kind)
+            if i + 1 < len(alt_kinds):
+                dist.barrier()
+                timer.cancel()
+        multi_alt = alts["multi_alt"]
         del ref_words, ref_sdf
         torch.cuda.empty_cache()
+        alts_ok = all(a["parity_ok"] is not False for a in alts.values())       # a transport that RAN and disagreed fails the line
         with lock:
             if rank == 0:
-                out["multi_alt"] = multi_alt
-                out["parity_ok"] = parity["parity_ok"] and multi_alt["parity_ok"] is not False   # a transport that RAN and disagreed fails the line
+                out.update(alts)
+                out["parity_ok"] = parity["parity_ok"] and alts_ok
                 print(json.dumps(out), flush=True)
             printed[0] = True
         dist.barrier()
@@ -628,9 +640,9 @@ def main():
     elif rank == 0:
         print(json.dumps(out), flush=True)
 
-    bad = parity is not None and not (parity["parity_ok"] and multi_alt["parity_ok"] is not False)
+    bad = parity is not None and not (parity["parity_ok"] and alts_ok)
     if bad:
-        sys.exit("bench.py: a rank's slab differs from the one-GPU result (see `parity` / `multi_alt` in the JSON line)")
+        sys.exit("bench.py: a rank's slab differs from the one-GPU result (see `parity` / `multi_alt*` in the JSON line)")
 
 
 if __name__ == "__main__":

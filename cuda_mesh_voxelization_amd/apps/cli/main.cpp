@@ -15,7 +15,7 @@
 //                            sdf-coloured cubes and point cloud -- file names as in the reference
 //     -d, --dump PREFIX      (extension) write PREFIX.grid.u32 and PREFIX.sdf.f32 raw little-endian dumps
 //     -g, --gpus G           (extension) cut the grid into G Z-slabs, one per device 0 .. G-1 (the reference pins device 0,
-//                            apps/cli/main.cpp:22-23); --multi ghost|halo|hybrid picks the JFA variant (vphip.h, vp_multi_jfa)
+//                            apps/cli/main.cpp:22-23); --multi ghost|halo|hybrid|transpose picks the JFA variant (vphip.h, vp_multi_jfa)
 //         --verify           (extension, with -g G > 1) run the job once more on device 0 alone and compare grid and sdf bit for
 //                            bit; prints "# multi-gpu ..." lines (parity, device-to-device bytes of the JFA), exit code 3 on a mismatch
 //     -h, --help
@@ -82,7 +82,9 @@ const char* kUsage =
     "                        <arg> must divide the side into slabs of a multiple of 8 planes\n"
     "      --multi arg       JFA on several devices: ghost = recomputed ghost planes, no exchange between passes (default);\n"
     "                        halo = halo planes copied device to device before every pass; hybrid = ghost planes for the\n"
-    "                        wide passes (k > slab/2), halos for the others, id volumes cut to the planes a device touches\n"
+    "                        wide passes (k > slab/2), halos for the others, id volumes cut to the planes a device touches;\n"
+    "                        transpose = planes dealt cyclically for the passes whose step is a multiple of <gpus> (no exchange),\n"
+    "                        one re-deal into slabs for the last log2 <gpus> passes (<gpus> a power of two, else ghost)\n"
     "      --surface-only    With -e: the grid meshes hold only the faces between a set voxel and an unset / outside neighbour\n"
     "                        (default: the reference's mesh -- every face of every set voxel once, interior faces included)\n"
     "      --verify          With -g > 1: run the job again on device 0 alone, compare grid and sdf bit for bit, print\n"
@@ -196,7 +198,7 @@ int main(int argc, char** argv)
     const bool EXPORT = !BENCHMARK && opt.doExport;
     const bool GPU = TYPE == Types::NAIVE || TYPE == Types::TILED;      // exports: the walk over the grid runs on the device too
     cpuAssert(opt.gpus >= 1 && opt.gpus <= 64, "Number of GPUs must be 1..64");
-    cpuAssert(opt.multi == "ghost" || opt.multi == "halo" || opt.multi == "hybrid", "--multi must be ghost, halo or hybrid");
+    cpuAssert(opt.multi == "ghost" || opt.multi == "halo" || opt.multi == "hybrid" || opt.multi == "transpose", "--multi must be ghost, halo, hybrid or transpose");
     if (GPU && opt.gpus > 1) {
         // Z-slabs over devices 0 .. G-1.  VPLIB_SHARE_GPU=1 (test rigs with fewer devices than slabs): the slabs share the devices
         // there are -- same code path, several contexts per device.
@@ -207,6 +209,7 @@ int main(int argc, char** argv)
         for (unsigned i = 0; i < opt.gpus; ++i) devices[i] = present > 0 ? static_cast<int>(i % static_cast<unsigned>(present)) : static_cast<int>(i);
         vplib::SetDevices(devices, opt.multi == "ghost");
         if (opt.multi == "hybrid") vplib::SetMultiMode(VP_MULTI_HYBRID);
+        if (opt.multi == "transpose") vplib::SetMultiMode(VP_MULTI_TRANSPOSE);
     }
 
     std::vector<Mesh> meshes(opt.filenames.size());

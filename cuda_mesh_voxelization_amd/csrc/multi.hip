@@ -14,6 +14,10 @@
 //                              the whole JFA is enqueued without a host synchronisation (jfa_halo below).
 //                  VP_MULTI_HYBRID ghost planes for the passes with k > nz/2, halo copies from the two adjacent ranks for the
 //                              others; the windows hold only the planes a rank touches (jfa_hybrid below).
+//                  VP_MULTI_TRANSPOSE the planes are dealt CYCLICALLY (plane z on rank z mod G) for every pass whose step is a multiple of G --
+//                              such a pass finds the planes z - k, z, z + k of each plane a rank owns on that rank: no exchange, no ghost
+//                              planes, 1/G of the pass per device -- then ONE re-deal (peer copies of contiguous plane ranges) into slabs
+//                              widened by the reach of the remaining steps, which run like the last ghost regions (jfa_transpose below).
 //                  VP_MULTI_GHOST  no exchange between passes: the bitmask slabs are all-gathered once (n^3/8 bytes), every
 //                              device runs pass i on its slab widened by the reach of the later passes and the regions shrink
 //                              to the bare slab at k = 1.  Costs two windows of the whole grid per device.
@@ -43,6 +47,8 @@ struct Rank {
     Buffer below, above;                       // bitmask planes z0-1 / z1
     Buffer ids[2];                             // the two id windows of the last vp_multi_jfa (ensure_windows)
     uint32_t win_n = 0, win_planes = 0;        // ... and their geometry
+    Buffer cyc[2], staging;                    // VP_MULTI_TRANSPOSE: the two windows of the cyclic phase, the chunks the re-deal delivers
+    uint32_t cyc_n = 0, cyc_planes = 0, stg_n = 0, stg_planes = 0;
     Buffer border;                             // ghost / hybrid: border mask of the whole grid
     Buffer whole_sdf;                          // n < 96 (not sharded): sdf of the whole grid
     Buffer sdf;                                // slab
@@ -82,29 +88,32 @@ int grow(Rank& r, Buffer& b, size_t bytes)
 // earlier job left in the SAME layout -- never memory nobody wrote, never bytes of another layout.
 // Test builds (-DVP_TEST_HOOKS, libvphip_hooks.so): VP_MULTI_POISON=<byte> refills the word planes with that byte before every job to
 // show that the results do not depend on what those planes hold.
-int ensure_windows(Rank& r, const vp_frame& G, uint32_t planes)
+int ensure_window_set(Rank& r, Buffer* bufs, int nbufs, uint32_t& gn, uint32_t& gplanes, const vp_frame& G, uint32_t planes)
 {
     VP_TRY(bind(r));
     const size_t bytes = vp_jfa_window_bytes(&G, planes);
-    bool fresh = r.win_n != G.n || r.win_planes != planes;
-    for (Buffer& b : r.ids) {
+    bool fresh = gn != G.n || gplanes != planes;
+    for (int i = 0; i < nbufs; ++i) {
+        Buffer& b = bufs[i];
         const void* before = b.ptr;
         VP_TRY(reserve(r.ctx, b, bytes, /*headroom=*/false));       // exact: a window must not cost more than it saves
         fresh = fresh || b.ptr != before;
     }
-    r.win_n = G.n; r.win_planes = planes;
+    gn = G.n; gplanes = planes;
 #ifdef VP_TEST_HOOKS
     const char* poison = getenv("VP_MULTI_POISON");
     fresh = fresh || poison != nullptr;
 #endif
     if (fresh)
-        for (int i = 0; i < 2; ++i) { const vp_window w{r.ids[i].ptr, r.ids[i].bytes, planes, 0}; VP_TRY(vp_jfa_window_clear(r.ctx, &G, &w)); }
+        for (int i = 0; i < nbufs; ++i) { const vp_window w{bufs[i].ptr, bufs[i].bytes, planes, 0}; VP_TRY(vp_jfa_window_clear(r.ctx, &G, &w)); }
 #ifdef VP_TEST_HOOKS
     if (poison)
-        for (Buffer& b : r.ids) VP_HIP(hipMemsetAsync(b.ptr, (int)strtol(poison, nullptr, 0) & 0xFF, (size_t)planes * G.n * G.n * 4, r.ctx->stream));
+        for (int i = 0; i < nbufs; ++i) VP_HIP(hipMemsetAsync(bufs[i].ptr, (int)strtol(poison, nullptr, 0) & 0xFF, (size_t)planes * G.n * G.n * 4, r.ctx->stream));
 #endif
     return 0;
 }
+
+int ensure_windows(Rank& r, const vp_frame& G, uint32_t planes) { return ensure_window_set(r, r.ids, 2, r.win_n, r.win_planes, G, planes); }
 
 vp_frame slab_frame(const vp_frame& g, uint32_t z0, uint32_t z1)
 {
@@ -219,14 +228,18 @@ std::vector<Region> ghost_regions(uint32_t n, uint32_t z0, uint32_t z1)
 
 // `count` id planes from index `sp` of a window of src (splanes planes) to index `dp` of a window of dst (dplanes): one or two byte ranges
 // (above n = 1024 the word planes and the byte planes: 5 bytes per voxel on the wire)
-int copy_planes(vp_multi* m, uint32_t dplanes, Rank& dst, int dwhich, uint32_t dp, uint32_t splanes, const Rank& src, int swhich, uint32_t sp, uint32_t count)
+int copy_planes_buf(vp_multi* m, uint32_t dplanes, Rank& dst, const Buffer& dbuf, uint32_t dp, uint32_t splanes, const Rank& src, const Buffer& sbuf, uint32_t sp, uint32_t count)
 {
     size_t so[2], sb[2], dof[2], db[2];
     VP_TRY(vp_jfa_window_span(&m->frame, splanes, sp, sp + count, so, sb));
     VP_TRY(vp_jfa_window_span(&m->frame, dplanes, dp, dp + count, dof, db));
     for (int i = 0; i < 2; ++i)
-        VP_TRY(peer_copy(m, dst, (char*)dst.ids[dwhich].ptr + dof[i], src, (const char*)src.ids[swhich].ptr + so[i], sb[i]));
+        VP_TRY(peer_copy(m, dst, (char*)dbuf.ptr + dof[i], src, (const char*)sbuf.ptr + so[i], sb[i]));
     return 0;
+}
+int copy_planes(vp_multi* m, uint32_t dplanes, Rank& dst, int dwhich, uint32_t dp, uint32_t splanes, const Rank& src, int swhich, uint32_t sp, uint32_t count)
+{
+    return copy_planes_buf(m, dplanes, dst, dst.ids[dwhich], dp, splanes, src, src.ids[swhich], sp, count);
 }
 
 // all-gather of the bitmask slabs: every device ends up with the whole grid (its own slab stays where it is: plane z0)
@@ -324,6 +337,7 @@ int jfa_ghost(vp_multi* m, float fill)
     const vp_frame& G = m->frame;
     const uint32_t n = G.n, world = (uint32_t)m->ranks.size(), nz = n / world;
     const size_t planeWords = (size_t)n * n / 8;
+    m->last_mode = VP_MULTI_GHOST;                                  // (also what VP_MULTI_TRANSPOSE runs where no step is a multiple of the device count)
     for (Rank& r : m->ranks) {
         VP_TRY(grow(r, r.border, (size_t)n * planeWords));
         VP_TRY(ensure_windows(r, G, n));
@@ -457,6 +471,101 @@ int jfa_hybrid(vp_multi* m, float fill)
     return 0;
 }
 
+// ---- VP_MULTI_TRANSPOSE (round 6).  The reference's pass with step k reads the planes z - k, z, z + k of a voxel's plane and nothing else
+// (jfa/sequential.cpp:72, :92-94).  Phase A: device r keeps the planes z = r (mod G) in two windows of n / G planes; every pass whose step is
+// a multiple of G (vp_jfa_cyclic_passes: all of them down to k = G on a power-of-two grid) runs there with no exchange and no ghost plane.
+// The re-deal: the planes of device t's widened slab [t0, t1) that device s holds are the CONTIGUOUS planes [t0 / G, t1 / G) of s's window:
+// one peer copy per pair of devices (two above n = 1024) into chunk s of t's staging window, straight from the window the last cyclic pass
+// wrote -- no pack.  Phase B: vp_jfa_window_interleave weaves the chunks into consecutive planes and the remaining steps run on the slab
+// widened by their reach, as the last regions of the ghost mode do.  The one-process form of slab.py's TransposeSlabPipeline.
+struct TransposePlan { uint32_t c; std::vector<Region> regs; uint32_t t0, t1, lo, hi; };
+
+TransposePlan transpose_plan(uint32_t n, uint32_t world, uint32_t z0, uint32_t z1, uint32_t c)
+{
+    TransposePlan p;
+    p.c = c;
+    const std::vector<Region> all = ghost_regions(n, z0, z1);
+    uint32_t g = 0;
+    for (size_t i = c; i < all.size(); ++i) { p.regs.push_back(all[i]); g += all[i].k; }
+    p.t0 = z0 > g ? (z0 - g) / world * world : 0;
+    p.t1 = std::min(n, (z1 + g + world - 1) / world * world);
+    p.lo = p.t0; p.hi = p.t1;
+    for (const Region& r : p.regs) { p.lo = std::min(p.lo, r.b0 > r.k ? r.b0 - r.k : 0); p.hi = std::max(p.hi, std::min(n, r.b1 + r.k)); }
+    return p;
+}
+
+int jfa_ghost(vp_multi* m, float fill);
+
+int jfa_transpose(vp_multi* m, float fill)
+{
+    const vp_frame& G = m->frame;
+    const uint32_t n = G.n, world = (uint32_t)m->ranks.size(), nz = n / world;
+    const uint32_t c = (uint32_t)vp_jfa_cyclic_passes(&G, world);
+    if (c == 0) return jfa_ghost(m, fill);                          // nothing to deal cyclically (one device, a count that is not a power of two)
+    const size_t planeWords = (size_t)n * n / 8;
+    std::vector<TransposePlan> plans;
+    m->window_lo.assign(world, 0); m->window_hi.assign(world, 0);
+    for (uint32_t r = 0; r < world; ++r) {
+        Rank& me = m->ranks[r];
+        plans.push_back(transpose_plan(n, world, me.z0, me.z1, c));
+        const TransposePlan& p = plans.back();
+        m->window_lo[r] = p.lo; m->window_hi[r] = p.hi;
+        VP_TRY(grow(me, me.border, (size_t)n * planeWords));
+        VP_TRY(ensure_window_set(me, me.cyc, 2, me.cyc_n, me.cyc_planes, G, nz));
+        VP_TRY(ensure_window_set(me, &me.staging, 1, me.stg_n, me.stg_planes, G, p.t1 - p.t0));
+        VP_TRY(ensure_windows(me, G, p.hi - p.lo));
+        VP_TRY(grow(me, me.sdf, (size_t)nz * n * n * 4));
+    }
+    // every device needs the bitmask of the whole grid: the border bits of its planes z = r (mod G) depend on the planes z -+ 1
+    VP_TRY(gather_words(m));
+    // ---- phase A: cyclic planes, no exchange
+    std::vector<int> cur(world, 0);
+    for (uint32_t r = 0; r < world; ++r) {
+        Rank& me = m->ranks[r];
+        VP_TRY(vp_surface(me.ctx, &G, (const uint32_t*)me.words.ptr, nullptr, nullptr, (uint32_t*)me.border.ptr));
+        { const vp_window w{me.cyc[0].ptr, me.cyc[0].bytes, nz, 0}; VP_TRY(vp_jfa_window_first_two_cyclic(me.ctx, &G, (const uint32_t*)me.border.ptr, &w, world, r)); }
+        uint32_t k = n / 8;
+        for (uint32_t i = 2; i < c; ++i, k /= 2) {
+            const vp_window in{me.cyc[cur[r]].ptr, me.cyc[cur[r]].bytes, nz, 0}, out{me.cyc[cur[r] ^ 1].ptr, me.cyc[cur[r] ^ 1].bytes, nz, 0};
+            VP_TRY(vp_jfa_window_pass_cyclic(me.ctx, &G, k, &in, &out, world, r));
+            cur[r] ^= 1;
+        }
+    }
+    // ---- the re-deal: chunk s of t's staging window := the planes [t0 / G, t1 / G) of s's cyclic window
+    for (Rank& r : m->ranks) VP_TRY(mark_ready(r));
+    for (uint32_t t = 0; t < world; ++t) {
+        const TransposePlan& p = plans[t];
+        const uint32_t count = (p.t1 - p.t0) / world;
+        for (uint32_t s_ = 0; s_ < world; ++s_) {
+            const uint64_t before = m->bytes_moved;
+            VP_TRY(copy_planes_buf(m, p.t1 - p.t0, m->ranks[t], m->ranks[t].staging, s_ * count, nz, m->ranks[s_], m->ranks[s_].cyc[cur[s_]], p.t0 / world, count));
+            if (s_ == t) m->bytes_moved = before;                   // a device's own planes do not travel
+        }
+    }
+    if (world > 1) VP_TRY(fence_copies(m));
+    // ---- phase B: weave, then the remaining steps on the widened slab
+    for (uint32_t r = 0; r < world; ++r) {
+        Rank& me = m->ranks[r];
+        const TransposePlan& p = plans[r];
+        const uint32_t planes = p.hi - p.lo, count = (p.t1 - p.t0) / world;
+        const uint32_t* words = (const uint32_t*)me.words.ptr;
+        int w = 0;
+        {
+            const vp_window in{me.staging.ptr, me.staging.bytes, p.t1 - p.t0, 0}, out{me.ids[0].ptr, me.ids[0].bytes, planes, p.t0 - p.lo};
+            VP_TRY(vp_jfa_window_interleave(me.ctx, &G, &in, &out, world, count));
+        }
+        for (size_t i = 0; i < p.regs.size(); ++i) {
+            const Region& g = p.regs[i];
+            const vp_frame f = slab_frame(G, g.b0, g.b1);
+            const vp_window in{me.ids[w].ptr, me.ids[w].bytes, planes, g.b0 - p.lo}, out{me.ids[w ^ 1].ptr, me.ids[w ^ 1].bytes, planes, g.b0 - p.lo};
+            if (i + 1 == p.regs.size()) VP_TRY(vp_jfa_window_last_pass(me.ctx, &f, &in, &out, 1, words + (size_t)g.b0 * (planeWords / 4), fill, (float*)me.sdf.ptr));
+            else                        VP_TRY(vp_jfa_window_pass(me.ctx, &f, g.k, &in, &out, g.k));
+            w ^= 1;
+        }
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -498,7 +607,7 @@ int vp_multi_destroy(vp_multi* m)
         if (!r.ctx) continue;
         (void)hipSetDevice(r.device);
         (void)hipStreamSynchronize(r.ctx->stream);
-        Buffer* bufs[] = {&r.mesh_xyz, &r.mesh_tri, &r.words, &r.other, &r.below, &r.above, &r.ids[0], &r.ids[1], &r.border, &r.sdf, &r.whole_sdf};
+        Buffer* bufs[] = {&r.mesh_xyz, &r.mesh_tri, &r.words, &r.other, &r.below, &r.above, &r.ids[0], &r.ids[1], &r.cyc[0], &r.cyc[1], &r.staging, &r.border, &r.sdf, &r.whole_sdf};
         for (Buffer* b : bufs) release(*b);
         if (r.ready) (void)hipEventDestroy(r.ready);
         if (r.copied) (void)hipEventDestroy(r.copied);
@@ -595,7 +704,7 @@ int vp_multi_jfa(vp_multi* m, float fill_unset, int algo, int mode)
     if (!m || !m->have_grid) return set_error(VP_ERR_INVALID, "vp_multi_jfa: no resident grid (vp_multi_voxelize / vp_multi_set_grid first)");
     if (!std::isinf(fill_unset)) return set_error(VP_ERR_INVALID, "vp_multi_jfa: fill_unset must be +-infinity");
     if (algo != VP_ALGO_NAIVE && algo != VP_ALGO_TILED) return set_error(VP_ERR_INVALID, "vp_multi_jfa: algo %d", algo);
-    if (mode != VP_MULTI_HALO && mode != VP_MULTI_GHOST && mode != VP_MULTI_HYBRID) return set_error(VP_ERR_INVALID, "vp_multi_jfa: mode %d", mode);
+    if (mode != VP_MULTI_HALO && mode != VP_MULTI_GHOST && mode != VP_MULTI_HYBRID && mode != VP_MULTI_TRANSPOSE) return set_error(VP_ERR_INVALID, "vp_multi_jfa: mode %d", mode);
     m->bytes_moved = 0;
     m->last_mode = mode;
     // The sharded forms run the tile kernels on id windows whatever `algo` says (both give the same sdf); below their range the grid is
@@ -603,6 +712,7 @@ int vp_multi_jfa(vp_multi* m, float fill_unset, int algo, int mode)
     if (m->frame.n < 96) VP_TRY(jfa_small(m, fill_unset, algo));
     else if (mode == VP_MULTI_GHOST) VP_TRY(jfa_ghost(m, fill_unset));
     else if (mode == VP_MULTI_HYBRID) VP_TRY(jfa_hybrid(m, fill_unset));
+    else if (mode == VP_MULTI_TRANSPOSE) VP_TRY(jfa_transpose(m, fill_unset));
     else VP_TRY(jfa_halo(m, fill_unset));
     m->have_sdf = true;
     return 0;
@@ -628,10 +738,14 @@ int vp_multi_window(const vp_multi* m, int rank, uint32_t* lo, uint32_t* hi, uin
     const Rank& r = m->ranks[(size_t)rank];
     uint32_t a = 0, b = n;                                          // ghost (and n < 96): whole volumes
     if (n >= 96 && m->last_mode == VP_MULTI_HALO) { a = r.z0; b = r.z1; (void)nz; }       // the slab; its windows also hold the slabs received from z -+ k
-    else if (n >= 96 && m->last_mode == VP_MULTI_HYBRID) { a = m->window_lo[(size_t)rank]; b = m->window_hi[(size_t)rank]; }
+    else if (n >= 96 && (m->last_mode == VP_MULTI_HYBRID || m->last_mode == VP_MULTI_TRANSPOSE)) { a = m->window_lo[(size_t)rank]; b = m->window_hi[(size_t)rank]; }
     if (lo) *lo = a;
     if (hi) *hi = b;
-    if (id_bytes) *id_bytes = (uint64_t)r.ids[0].bytes + r.ids[1].bytes;
+    // the id windows the mode of the last job used (buffers are grow-only and kept: those of other modes are not this job's state)
+    if (id_bytes) {
+        *id_bytes = (uint64_t)vp_jfa_window_bytes(&m->frame, r.win_planes) * 2;
+        if (n >= 96 && m->last_mode == VP_MULTI_TRANSPOSE) *id_bytes += (uint64_t)vp_jfa_window_bytes(&m->frame, r.cyc_planes) * 2 + vp_jfa_window_bytes(&m->frame, r.stg_planes);
+    }
     return 0;
 }
 

@@ -27,7 +27,7 @@ int DeviceCount();
 // The slab driver, created on first call; nullptr while fewer than two devices are set.
 vp_multi* Multi();
 int MultiMode();
-// VP_MULTI_HALO / VP_MULTI_GHOST / VP_MULTI_HYBRID (include/vphip.h) for the next JFA on several devices; call after SetDevices.
+// VP_MULTI_HALO / VP_MULTI_GHOST / VP_MULTI_HYBRID / VP_MULTI_TRANSPOSE (include/vphip.h) for the next JFA on several devices; call after SetDevices.
 void SetMultiMode(int mode);
 
 // Creates the context on first call; prints the reference-style assert line and exits on failure.

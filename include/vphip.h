@@ -296,13 +296,19 @@ int vp_extract(vp_ctx* ctx, const vp_frame* f, const uint32_t* d_words, int mode
  *                    VP_MULTI_HYBRID: ghost planes for the passes with k > nz/2 (as far as the later such passes reach), halo
  *                                    planes from the two adjacent devices for the passes with k <= nz/2; the windows hold only
  *                                    the planes a device touches (vp_multi_window): capacity, not speed
+ *                    VP_MULTI_TRANSPOSE: the planes are dealt cyclically (plane z on device z mod G) for every pass whose step is a multiple
+ *                                    of G -- no exchange, no ghost planes, 1/G of each pass per device (vp_jfa_window_*_cyclic) -- then ONE
+ *                                    re-deal into slabs widened by the reach of the remaining log2 G passes: one peer copy per pair of
+ *                                    devices, n^3 S / G + margins bytes into each device per job (0.49 GiB at n = 1024, G = 8, against
+ *                                    3.5 GiB of halos), compute per device ~ 1 / G of one device's.  G a power of two; where no step is a
+ *                                    multiple of G it is the ghost mode
  * Results are bit-identical to the single-device calls for any G.  The sharded forms run the tile kernels whatever `algo` says (both
  * algorithms give the same sdf); grids below their range (n < 96) are not sharded: every device computes the whole grid with `algo`
  * and keeps its slab.  `devices` may name one device several times (several
  * contexts on it): that is how the parity tests run on a one-GPU box.  Grid, sdf and mesh stay resident on the devices
  * between calls; host arrays are whole-grid arrays in the reference's layout. */
 typedef struct vp_multi vp_multi;
-enum { VP_MULTI_HALO = 0, VP_MULTI_GHOST = 1, VP_MULTI_HYBRID = 2 };
+enum { VP_MULTI_HALO = 0, VP_MULTI_GHOST = 1, VP_MULTI_HYBRID = 2, VP_MULTI_TRANSPOSE = 3 };
 int vp_multi_create(const int* devices, int ndev, vp_multi** out);
 int vp_multi_destroy(vp_multi* m);
 int vp_multi_count(const vp_multi* m);
@@ -325,7 +331,8 @@ int vp_multi_get_sdf(vp_multi* m, float* h_sdf);
 uint64_t vp_multi_bytes_moved(const vp_multi* m);
 /* JFA state a rank held during the last vp_multi_jfa: the global planes [lo, hi) its two id windows are addressed by -- the whole grid with
  * VP_MULTI_GHOST, the slab with VP_MULTI_HALO (its windows also hold the two slabs received from z -+ k), the planes the rank touches
- * with VP_MULTI_HYBRID -- and the bytes of device memory in its id buffers.  Any out pointer may be NULL. */
+ * with VP_MULTI_HYBRID, the widened slab of the second phase with VP_MULTI_TRANSPOSE -- and the bytes of device memory in the id windows
+ * that job used.  Any out pointer may be NULL. */
 int vp_multi_window(const vp_multi* m, int rank, uint32_t* lo, uint32_t* hi, uint64_t* id_bytes);
 
 /* ---- host-in / host-out conveniences (the reference's Compute() calling convention) -------
