@@ -1,6 +1,7 @@
 // grid_to_mesh.cpp -- see grid_to_mesh.h.  VoxelsGridToMeshCompressed emits the reference's mesh (grid_to_mesh.h:25-92,
 // grid_to_mesh.cpp:10-60: face set, vertex order, winding, normal indices; pinned face by face by tests/test_export.py);
-// the cube and point-cloud exports follow its OBJ conventions (six axis normals in the order +Z,+Y,+X,-Z,-Y,-X, :25-31; colours per vertex).
+// VoxelsGridToMesh / VoxelsGridToPointCloud emit the reference's cubes and points (:65-201: vertex order, its twelve triangles and normal slots
+// per cube, SDFToRGB colours through the 8-bit Color; pinned to oracle/oracle_export.c by tests/test_export.py).
 //
 // Every exporter is written against a stream of voxel RECORDS (linear index + exposed-face mask) in z, y, x order.
 // The host variants produce the records by walking the grid (what the reference does, grid_to_mesh.cpp:10-201); the
@@ -23,7 +24,9 @@ void AxisNormals(Mesh& mesh)
     mesh.Normals = {Normal(0, 0, 1), Normal(0, 1, 0), Normal(1, 0, 0), Normal(0, 0, -1), Normal(0, -1, 0), Normal(-1, 0, 0)};
 }
 
-float Diagonal(float side) { return std::sqrt(side * side * 3.0f); }
+// grid_to_mesh.cpp:84,182: std::sqrt(std::pow(<float side>, 2) * 3) -- std::pow(float, int) and the sqrt of its result are DOUBLE operations,
+// narrowed to float on assignment
+float Diagonal(float side) { return static_cast<float>(std::sqrt(std::pow(static_cast<double>(side), 2.0) * 3.0)); }
 
 constexpr uint64_t kIndexMask = (1ull << 40) - 1;
 
@@ -178,9 +181,10 @@ void EmitCubes(const VoxelsGrid<T>& grid, const Grid<float>& sdf, const std::vec
     const size_t n = grid.VoxelsPerSide();
     const float vs = grid.VoxelSize();
     const float max = Diagonal(n * vs);
-    // corner c = dx + 2 dy + 4 dz ; two triangles per face, outward winding ; normal index per face
-    static const uint32_t quads[6][4] = {{0, 2, 3, 1}, {4, 5, 7, 6}, {2, 6, 7, 3}, {0, 1, 5, 4}, {1, 3, 7, 5}, {0, 4, 6, 2}};
-    static const uint32_t quadNormal[6] = {3, 0, 1, 4, 2, 5};     // -Z, +Z, +Y, -Y, +X, -X
+    // corner c = dx + 2 dy + 4 dz (:92-94); the reference's twelve triangles in its order BACK, FRONT, TOP, BOTTOM, RIGHT, LEFT and the normal
+    // slot it gives each face (:107-163 -- its BACK face carries slot 0 = (0,0,1), its FRONT face slot 3: kept as they are, the files must match)
+    static const uint32_t tris[12][3] = {{0, 2, 1}, {1, 2, 3}, {4, 5, 6}, {5, 7, 6}, {6, 3, 2}, {3, 6, 7}, {0, 1, 4}, {1, 5, 4}, {1, 3, 5}, {3, 7, 5}, {0, 4, 2}, {2, 4, 6}};
+    static const uint32_t faceSlot[6] = {0, 3, 1, 4, 2, 5};
     uint32_t cubes = 0;
     for (const uint64_t rec : records) {
         const size_t idx = static_cast<size_t>(rec & kIndexMask);
@@ -193,10 +197,9 @@ void EmitCubes(const VoxelsGrid<T>& grid, const Grid<float>& sdf, const std::vec
             mesh.Colors.emplace_back(r, g, b, 1.0f);
         }
         const uint32_t base = cubes * 8;
-        for (int q = 0; q < 6; ++q) {
-            const uint32_t* p = quads[q];
-            mesh.FacesCoords.insert(mesh.FacesCoords.end(), {base + p[0], base + p[1], base + p[2], base + p[0], base + p[2], base + p[3]});
-            mesh.FacesNormals.insert(mesh.FacesNormals.end(), 6, quadNormal[q]);
+        for (int t = 0; t < 12; ++t) {
+            mesh.FacesCoords.insert(mesh.FacesCoords.end(), {base + tris[t][0], base + tris[t][1], base + tris[t][2]});
+            mesh.FacesNormals.insert(mesh.FacesNormals.end(), 3, faceSlot[t / 2]);
         }
         ++cubes;
     }

@@ -55,6 +55,12 @@ def lib():
         L.vpo_grid_to_mesh_compressed.restype = ctypes.c_int
         L.vpo_grid_to_mesh_compressed.argtypes = [_u32p, ctypes.c_uint, ctypes.c_float, _f32p, ctypes.POINTER(_f32p), ctypes.POINTER(ctypes.c_size_t),
                                                   ctypes.POINTER(_u32p), ctypes.POINTER(_u32p), ctypes.POINTER(ctypes.c_size_t)]
+        _u8p = ctypes.POINTER(ctypes.c_ubyte)
+        L.vpo_grid_to_mesh_cubes.restype = ctypes.c_int
+        L.vpo_grid_to_mesh_cubes.argtypes = [_u32p, _f32p, ctypes.c_uint, ctypes.c_float, _f32p, ctypes.POINTER(_f32p), ctypes.POINTER(_u8p),
+                                             ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(_u32p), ctypes.POINTER(_u32p), ctypes.POINTER(ctypes.c_size_t)]
+        L.vpo_grid_to_point_cloud.restype = ctypes.c_int
+        L.vpo_grid_to_point_cloud.argtypes = [_u32p, _f32p, ctypes.c_uint, ctypes.c_float, _f32p, ctypes.POINTER(_f32p), ctypes.POINTER(_u8p), ctypes.POINTER(ctypes.c_size_t)]
         L.vpo_free.restype = None
         L.vpo_free.argtypes = [ctypes.c_void_p]
         _lib = L
@@ -161,3 +167,41 @@ def grid_to_mesh_compressed(words, n: int, voxel_size, origin):
     finally:
         lib().vpo_free(pc); lib().vpo_free(pf); lib().vpo_free(pn)
     return coords, faces, normals
+
+
+def grid_to_mesh_cubes(words, sdf, n: int, voxel_size, origin):
+    """The reference's VoxelsGridToMesh (oracle_export.c): (coords float32 [V, 3], rgb uint8 [V, 3] = R(), G(), B() of the vertex colours,
+    faces uint32 [F, 3], face normal slots uint32 [F, 3]) -- 8 vertices and 12 triangles per set voxel with a finite sdf."""
+    words, sdf, origin = _u32(words), _f32(sdf), _f32(origin)
+    u8p = ctypes.POINTER(ctypes.c_ubyte)
+    pc, pr, pf, pn = _f32p(), u8p(), _u32p(), _u32p()
+    nv, ni = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = lib().vpo_grid_to_mesh_cubes(_pu(words), _pf(sdf), n, float(voxel_size), _pf(origin), ctypes.byref(pc), ctypes.byref(pr), ctypes.byref(nv),
+                                      ctypes.byref(pf), ctypes.byref(pn), ctypes.byref(ni))
+    if rc != 0:
+        raise MemoryError("vpo_grid_to_mesh_cubes allocation failed")
+    try:
+        coords = np.ctypeslib.as_array(pc, shape=(max(nv.value, 1) * 3,)).copy()[:nv.value * 3].reshape(-1, 3)
+        rgb = np.ctypeslib.as_array(pr, shape=(max(nv.value, 1) * 3,)).copy()[:nv.value * 3].reshape(-1, 3)
+        faces = np.ctypeslib.as_array(pf, shape=(max(ni.value, 1),)).copy()[:ni.value].reshape(-1, 3)
+        normals = np.ctypeslib.as_array(pn, shape=(max(ni.value, 1),)).copy()[:ni.value].reshape(-1, 3)
+    finally:
+        lib().vpo_free(pc); lib().vpo_free(pr); lib().vpo_free(pf); lib().vpo_free(pn)
+    return coords, rgb, faces, normals
+
+
+def grid_to_point_cloud(words, sdf, n: int, voxel_size, origin):
+    """The reference's VoxelsGridToPointCloud (oracle_export.c): (coords float32 [V, 3], rgb uint8 [V, 3]), one vertex per set voxel."""
+    words, sdf, origin = _u32(words), _f32(sdf), _f32(origin)
+    u8p = ctypes.POINTER(ctypes.c_ubyte)
+    pc, pr = _f32p(), u8p()
+    nv = ctypes.c_size_t()
+    rc = lib().vpo_grid_to_point_cloud(_pu(words), _pf(sdf), n, float(voxel_size), _pf(origin), ctypes.byref(pc), ctypes.byref(pr), ctypes.byref(nv))
+    if rc != 0:
+        raise MemoryError("vpo_grid_to_point_cloud allocation failed")
+    try:
+        coords = np.ctypeslib.as_array(pc, shape=(max(nv.value, 1) * 3,)).copy()[:nv.value * 3].reshape(-1, 3)
+        rgb = np.ctypeslib.as_array(pr, shape=(max(nv.value, 1) * 3,)).copy()[:nv.value * 3].reshape(-1, 3)
+    finally:
+        lib().vpo_free(pc); lib().vpo_free(pr)
+    return coords, rgb

@@ -1,5 +1,6 @@
 /*
- * oracle_export.c -- CPU restatement of the reference's VoxelsGridToMeshCompressed (the `-e` grid export).
+ * oracle_export.c -- CPU restatement of the reference's three grid exporters (the `-e` outputs): VoxelsGridToMeshCompressed,
+ * VoxelsGridToMesh (sdf-coloured cubes) and VoxelsGridToPointCloud, with SDFToRGB and the Color quantisation ExportMesh prints.
  *
  * TEST INFRASTRUCTURE ONLY (see vp_oracle.h): loaded by tests/test_export.py as the checker of
  * cuda_mesh_voxelization_amd/vplib/src/grid_to_mesh.cpp and of the vp_extract front end; never by the product.
@@ -9,9 +10,15 @@
  *   /root/reference/vplib/src/mesh/grid_to_mesh.h:25-92     AddFacesVertex: plane_index (:31), face_index and the faces_marked test
  *                                                           (:34-43), the four vertices in (v, u) order through vertices_marked
  *                                                           (:46-65), the two triangles per plane / side (:67-85), normals (:87)
+ *   /root/reference/vplib/src/mesh/grid_to_mesh.cpp:65-173  VoxelsGridToMesh: 8 vertices (dz, dy, dx order, :92-105) and 12 triangles (:107-163) per set
+ *                                                           voxel with a finite sdf (:89), the normal slots of :76-82
+ *   /root/reference/vplib/src/mesh/grid_to_mesh.cpp:175-201 VoxelsGridToPointCloud: one vertex at the centre of every set voxel
+ *   /root/reference/vplib/src/mesh/grid_to_mesh.h:15-22     SDFToRGB;  mesh/mesh.h:19-33 Color::SetColor / R() G() B();  mesh/mesh_io.cpp:99-104
+ *                                                           ExportMesh prints R() / 255.0f: the colour arrays below hold R(), G(), B()
  * The reference keeps its marks in three std::vector<bool> and an unordered_map keyed by the lattice-point index; here they are three
  * byte arrays and one direct-index array -- the same decisions in the same order.
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -112,6 +119,104 @@ int vpo_grid_to_mesh_compressed(const uint32_t* words, unsigned n, float voxel_s
     free(c.vertex_of);
     if (c.failed) { free(c.coords); free(c.faces); free(c.normals); return -1; }
     *coords = c.coords; *nverts = c.nverts; *faces = c.faces; *face_normals = c.normals; *nindices = c.nidx;
+    return 0;
+}
+
+/* grid_to_mesh.h:15-22  SDFToRGB(float v, float max).  std::min / std::max return their FIRST argument when the
+ * comparison is false: a NaN v (the sqrt of a negative sdf -- never a set voxel's) passes std::min and is replaced by 0 in std::max;
+ * fminf / fmaxf decide differently, so both are spelled out */
+static float min_ref(float a, float b) { return (b < a) ? b : a; }
+static float max_ref(float a, float b) { return (a < b) ? b : a; }
+static void sdf_to_rgb_ref(float v, float max, float* r, float* g, float* b)
+{
+    float t = max_ref(0.0f, min_ref(v, max)) / max;
+    t = cbrtf(t);
+    *r = t; *g = 0.0f; *b = 1.0f - t;
+}
+/* mesh.h:19-24 (Color::SetColor: static_cast<uint32_t>(std::round(c * 255)) into one byte lane) and :26-33 (R(), G(), B(): & 0xFF) */
+static unsigned char quantise(float c) { return (unsigned char)(((uint32_t)roundf(c * 255)) & 0xFFu); }
+/* grid_to_mesh.cpp:84 / :181  float max = std::sqrt(std::pow(grid.VoxelsPerSide() * grid.VoxelSize(), 2) * 3): the product is a float,
+ * std::pow(float, int) computes in double, so does the sqrt; the result is narrowed to float */
+static float colour_range(unsigned n, float vs) { return (float)sqrt(pow((double)((float)n * vs), 2.0) * 3.0); }
+
+/* grid_to_mesh.cpp:65-173.  coords [nverts * 3], rgb [nverts * 3] (R(), G(), B() of each vertex colour), faces / face normals [nindices].
+ * Returns 0 and malloc'd arrays (vpo_free), -1 if an allocation failed. */
+int vpo_grid_to_mesh_cubes(const uint32_t* words, const float* sdf, unsigned n, float voxel_size, const float origin[3],
+                           float** coords, unsigned char** rgb, size_t* nverts, uint32_t** faces, uint32_t** face_normals, size_t* nindices)
+{
+    Ctx c; memset(&c, 0, sizeof c);
+    c.n = n; c.words = words;
+    const float vs = voxel_size, ox = origin[0], oy = origin[1], oz = origin[2];
+    const float max = colour_range(n, vs);                                                    /* :84 */
+    size_t cubes = 0;
+    for (unsigned z = 0; z < n; ++z) for (unsigned y = 0; y < n; ++y) for (unsigned x = 0; x < n; ++x) {
+        const size_t i = (size_t)x + (size_t)n * ((size_t)y + (size_t)n * z);
+        if (voxel(&c, x, y, z) && !(fabsf(sdf[i]) == INFINITY)) ++cubes;
+    }
+    float* co = (float*)malloc((cubes ? cubes : 1) * 8 * 3 * sizeof(float));
+    unsigned char* col = (unsigned char*)malloc((cubes ? cubes : 1) * 8 * 3);
+    uint32_t* fa = (uint32_t*)malloc((cubes ? cubes : 1) * 36 * 4);
+    uint32_t* fn = (uint32_t*)malloc((cubes ? cubes : 1) * 36 * 4);
+    if (!co || !col || !fa || !fn) { free(co); free(col); free(fa); free(fn); return -1; }
+    /* the twelve triangles of a cube and the normal slot of each face, in the order of :107-163 (BACK, FRONT, TOP, BOTTOM, RIGHT, LEFT) */
+    static const uint32_t tri[12][3] = {{0, 2, 1}, {1, 2, 3}, {4, 5, 6}, {5, 7, 6}, {6, 3, 2}, {3, 6, 7}, {0, 1, 4}, {1, 5, 4}, {1, 3, 5}, {3, 7, 5}, {0, 4, 2}, {2, 4, 6}};
+    static const uint32_t slot[6] = {0, 3, 1, 4, 2, 5};
+    uint32_t numberVoxelInsert = 0;
+    size_t v = 0, k = 0;
+    for (unsigned z = 0; z < n; ++z)
+        for (unsigned y = 0; y < n; ++y)
+            for (unsigned x = 0; x < n; ++x) {
+                const size_t i = (size_t)x + (size_t)n * ((size_t)y + (size_t)n * z);
+                if (!voxel(&c, x, y, z) || fabsf(sdf[i]) == INFINITY) continue;               /* :89-90 */
+                for (int dz = 0; dz <= 1; ++dz)
+                    for (int dy = 0; dy <= 1; ++dy)
+                        for (int dx = 0; dx <= 1; ++dx) {
+                            co[v * 3 + 0] = ox + (x * vs) + (vs * dx);                         /* :95-99 */
+                            co[v * 3 + 1] = oy + (y * vs) + (vs * dy);
+                            co[v * 3 + 2] = oz + (z * vs) + (vs * dz);
+                            float r, g, b;
+                            sdf_to_rgb_ref(sqrtf(sdf[i]), max, &r, &g, &b);                   /* :100 */
+                            col[v * 3 + 0] = quantise(r); col[v * 3 + 1] = quantise(g); col[v * 3 + 2] = quantise(b);   /* :102, alpha 1.0f */
+                            ++v;
+                        }
+                for (int t = 0; t < 12; ++t) {
+                    for (int j = 0; j < 3; ++j) { fa[k + j] = (numberVoxelInsert * 8) + tri[t][j]; fn[k + j] = slot[t / 2]; }
+                    k += 3;
+                }
+                numberVoxelInsert++;
+            }
+    *coords = co; *rgb = col; *nverts = v; *faces = fa; *face_normals = fn; *nindices = k;
+    return 0;
+}
+
+/* grid_to_mesh.cpp:175-201: every set voxel (an infinite sdf included: no test), its centre, the same colouring */
+int vpo_grid_to_point_cloud(const uint32_t* words, const float* sdf, unsigned n, float voxel_size, const float origin[3],
+                            float** coords, unsigned char** rgb, size_t* nverts)
+{
+    Ctx c; memset(&c, 0, sizeof c);
+    c.n = n; c.words = words;
+    const float vs = voxel_size, ox = origin[0], oy = origin[1], oz = origin[2];
+    const float max = colour_range(n, vs);                                                    /* :182 */
+    size_t count = 0;
+    for (unsigned z = 0; z < n; ++z) for (unsigned y = 0; y < n; ++y) for (unsigned x = 0; x < n; ++x) count += (size_t)voxel(&c, x, y, z);
+    float* co = (float*)malloc((count ? count : 1) * 3 * sizeof(float));
+    unsigned char* col = (unsigned char*)malloc((count ? count : 1) * 3);
+    if (!co || !col) { free(co); free(col); return -1; }
+    size_t v = 0;
+    for (unsigned z = 0; z < n; ++z)
+        for (unsigned y = 0; y < n; ++y)
+            for (unsigned x = 0; x < n; ++x) {
+                if (!voxel(&c, x, y, z)) continue;                                             /* :186-187 */
+                const size_t i = (size_t)x + (size_t)n * ((size_t)y + (size_t)n * z);
+                co[v * 3 + 0] = ox + (x * vs) + (vs / 2);                                      /* :189-193 */
+                co[v * 3 + 1] = oy + (y * vs) + (vs / 2);
+                co[v * 3 + 2] = oz + (z * vs) + (vs / 2);
+                float r, g, b;
+                sdf_to_rgb_ref(sqrtf(sdf[i]), max, &r, &g, &b);                               /* :194-195 */
+                col[v * 3 + 0] = quantise(r); col[v * 3 + 1] = quantise(g); col[v * 3 + 2] = quantise(b);
+                ++v;
+            }
+    *coords = co; *rgb = col; *nverts = v;
     return 0;
 }
 

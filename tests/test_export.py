@@ -21,11 +21,13 @@ def cli():
     return build.build_cli()
 
 
-def _parse_obj(path):
+def _parse_obj(path, colours=None):
     v, f, fn = [], [], []
     for line in open(path):
         if line.startswith("v "):
             v.append(line.split()[1:4])
+            if colours is not None:
+                colours.append(line.split()[4:7])
         elif line.startswith("f "):
             parts = [p.split("//") for p in line.split()[1:4]]
             f.append([int(p[0]) - 1 for p in parts])
@@ -73,6 +75,85 @@ def test_cli_export_is_the_reference_mesh(cli, tmp_path, name, n, t):
     assert p.returncode == 0, p.stdout + p.stderr
     (out,) = list((tmp_path / "out").iterdir())
     _check_file(str(out), coords, faces, normals)
+
+
+# ---------------------------------------------------------------------------------------------- sdf cubes and point cloud (-s -e)
+def _expect_sdf_exports(name, n):
+    """oracle: bitmask, sdf, VoxelsGridToMesh and VoxelsGridToPointCloud of a mesh in its own frame (what `vpcli <mesh> -n n -s -e` exports)"""
+    xyz, tri = M.import_mesh(M.asset(name))
+    origin, vs = O.frame([xyz], n)
+    words = O.voxelize(xyz, tri, n, vs, origin)
+    sdf = O.jfa(words, n, vs, origin)
+    return words, sdf, O.grid_to_mesh_cubes(words, sdf, n, vs, origin), O.grid_to_point_cloud(words, sdf, n, vs, origin)
+
+
+def _colour_strings(rgb):
+    # ExportMesh (mesh_io.cpp:99-104): static_cast<float>(R()) / 255.0f through std::fixed << std::setprecision(6)
+    return [["%.6f" % float(np.float32(c) / np.float32(255.0)) for c in row] for row in rgb]
+
+
+def _check_sdf_files(out, typename, cubes, cloud):
+    coords, rgb, faces, normals = cubes
+    col = []
+    v, f, fn = _parse_obj(str(out / ("sdf_%s_out.obj" % typename)), col)
+    assert f.shape == faces.shape and np.array_equal(f, faces) and np.array_equal(fn, normals)      # the reference's twelve triangles per cube, its normal slots
+    assert v == [["%.6f" % float(c) for c in row] for row in coords]                             # 8 corners per cube in (dz, dy, dx) order
+    assert col == _colour_strings(rgb)
+    pc, prgb = cloud
+    col = []
+    v, f, _ = _parse_obj(str(out / ("sdf_point_cloud_%s_out.obj" % typename)), col)
+    assert f.shape[0] == 0
+    assert v == [["%.6f" % float(c) for c in row] for row in pc] and col == _colour_strings(prgb)
+
+
+@pytest.mark.parametrize("name,n", [("d20.obj", 32), ("torus.obj", 32)])
+def test_oracle_sdf_exports_from_first_principles(name, n):
+    """What the two restatements must produce whatever their code looks like: a cube (8 corners, 12 triangles over exactly those corners,
+    two per normal slot pair) per set voxel with a finite sdf, a point at the centre of every set voxel; colours r = round(255 cbrt(d /
+    diag)), g = 0, b = round(255 (1 - cbrt(d / diag))) with d = sqrt(sdf) -- zero distance is pure blue.  Hashes of the oracle's own outputs
+    are recorded (tests/golden/export_oracle.json: not reference outputs) so that a change of the restatement shows."""
+    words, sdf, (coords, rgb, faces, normals), (pc, prgb) = _expect_sdf_exports(name, n)
+    xyz, _ = M.import_mesh(M.asset(name))
+    origin, vs = O.frame([xyz], n)
+    occ = np.unpackbits(words.view(np.uint8), bitorder="little").reshape(-1).astype(bool)
+    live = occ & np.isfinite(sdf)
+    assert coords.shape[0] == 8 * int(live.sum()) and faces.shape[0] == 12 * int(live.sum()) and pc.shape[0] == int(occ.sum())
+    cube = faces.reshape(-1, 12, 3)
+    assert np.array_equal(cube.min(axis=(1, 2)), np.arange(cube.shape[0]) * 8) and np.array_equal(cube.max(axis=(1, 2)), np.arange(cube.shape[0]) * 8 + 7)
+    assert np.array_equal(normals.reshape(-1, 12, 3)[0, :, 0], [0, 0, 3, 3, 1, 1, 4, 4, 2, 2, 5, 5])
+    idx = np.flatnonzero(occ)
+    x, y, z = idx % n, (idx // n) % n, idx // (n * n)
+    f32 = np.float32
+    centre = np.stack([f32(origin[a]) + c.astype(f32) * f32(vs) + f32(vs) / f32(2) for a, c in enumerate((x, y, z))], 1)
+    assert np.array_equal(pc, centre)
+    d = np.sqrt(sdf[idx].astype(np.float64))
+    t = np.cbrt(np.minimum(d, n * float(vs) * 3 ** 0.5) / (n * float(vs) * 3 ** 0.5))
+    assert np.abs(prgb[:, 0].astype(int) - np.round(255 * t)).max() <= 1 and np.all(prgb[:, 1] == 0)
+    assert np.abs(prgb[:, 2].astype(int) - np.round(255 * (1 - t))).max() <= 1
+    assert np.all(prgb[sdf[idx] == 0] == [0, 0, 255])
+    rec = json.load(open(GOLDEN))["%s@%d:sdf" % (name, n)]
+    assert [coords.shape[0], faces.shape[0], O.fnv(faces), O.fnv(coords), O.fnv(rgb), pc.shape[0], O.fnv(pc), O.fnv(prgb)] == rec
+
+
+@pytest.mark.parametrize("t,typename", [(0, "sequential"), (3, "openmp")])
+@pytest.mark.parametrize("name,n", [("d20.obj", 32), ("torus.obj", 32)])
+def test_cli_sdf_exports_are_the_reference_files(cli, tmp_path, name, n, t, typename):
+    """`-s -e`: VoxelsGridToMesh and VoxelsGridToPointCloud as the CLI writes them (apps/cli/main.cpp:220-230) against the oracle's restatement
+    of grid_to_mesh.cpp:65-201: vertex order, `v x y z r g b` to six decimals, the face indices and normal slots."""
+    _, _, cubes, cloud = _expect_sdf_exports(name, n)
+    p = subprocess.run([cli, M.asset(name), "-n", str(n), "-t", str(t), "-s", "-e"], capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    _check_sdf_files(tmp_path / "out", typename, cubes, cloud)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n", [("torus.obj", 32), ("bunny.obj", 128)])
+def test_cli_device_front_end_sdf_exports_are_the_reference_files(cli, tmp_path, name, n):
+    """-t 2 -s -e: the set voxels come from vp_extract (VP_EXTRACT_SET records) and the sdf from the GPU JFA; the files are the oracle's"""
+    _, _, cubes, cloud = _expect_sdf_exports(name, n)
+    p = subprocess.run([cli, M.asset(name), "-n", str(n), "-t", "2", "-s", "-e"], capture_output=True, text=True, cwd=tmp_path, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    _check_sdf_files(tmp_path / "out", "tiled", cubes, cloud)
 
 
 def test_cli_surface_only_is_the_visible_surface(cli, tmp_path):
