@@ -535,6 +535,8 @@ def main():
                          # the irreducible instructions and the two streams, nothing else); measured on the builder's box, not in this run
                          "formulation_floor_frac": (fl.get("n%d" % n) or {}).get("formulation_floor_frac"),
                          "formulation_floor_source": fl.get("source") if fl.get("n%d" % n) else None,
+                         # which round's files the quoted (not live) figures of this object come from
+                         "quoted_from": {"profiles/formulation_floor.json": "round %s" % fl.get("round", "?"), "profiles/jfa_dense_traffic.json": "round %s" % tj.get("round", "?")},
                          "timing": "hipEvents on the kernel's stream around each of its launches inside the timed region; the other "
                                    "kernels of `kernels` are timed over %d further steps outside it" % TABLE_STEPS,
                          "note": "bytes = 2*S*n^2*planes (SURVEY.md 8(d)); 27 exact candidate evaluations per voxel (DESIGN.md section 4)"},
@@ -574,6 +576,11 @@ def main():
                                      "distance_only_floor_frac": (fl.get("n1024") or {}).get("distance_only_floor_frac"),
                                      "formulation_floor_source": fl.get("source"),
                                      "timing": "hipEvents on the kernel's stream, 3 steps after the timed region of the headline workload"}
+            # the number the north star targets, inside the object the driver parses: the dense pass at n = 1024 beside the headline's
+            out["roofline"]["frac_n1024"] = kd2.get("frac_of_peak")
+            out["roofline"]["n1024"] = {"achieved": kd2.get("GB/s"), "avg_launch_ms": kd2.get("avg_ms"), "bytes_per_launch": kd2.get("bytes"),
+                                        "jfa_all_passes_frac": out["n1024"]["jfa_frac_of_peak"], "target_frac": 0.70,
+                                        "formulation_floor_frac": (fl.get("n1024") or {}).get("formulation_floor_frac")}
         if world == 1 and n == N_GRID and not args.no_config3:
             out["config3"] = run_config3(eng)
             if "csg_words" in out["config3"]["kernels"]:

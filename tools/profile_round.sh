@@ -36,6 +36,8 @@ pmc 2048 fetch FETCH_SIZE
 pmc 2048 write WRITE_SIZE
 pmc 2048 sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY
 pmc 2048 sq2 GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-[ -x $R/tools/exp/floor ] && { $R/tools/exp/floor 1024 > $O/floor_n1024.txt 2>&1; $R/tools/exp/floor 512 > $O/floor_n512.txt 2>&1; }
+[ -x $R/tools/exp/floor ] || { mkdir -p $R/tools/exp; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off $R/tools/ubench/floor.hip -o $R/tools/exp/floor; }
+[ -x $R/tools/exp/floor ] && { $R/tools/exp/floor 1024 > $O/floor_n1024.txt 2>&1; $R/tools/exp/floor 512 > $O/floor_n512.txt 2>&1;
+                               python3 $R/tools/floor_json.py $O ${round#r} > $O/formulation_floor.json; }
 rm -rf $O/pmc_*/ $O/*.log
 ls $O
