@@ -71,7 +71,9 @@ def build_lib(force: bool = False, verbose: bool = False, hooks: bool = False) -
             objs += [os.path.join(objdir, "jfa_dense.hip.part%d.o" % part) for part in range(1, DENSE_PARTS + 1)]
         else:
             objs.append(os.path.join(objdir, base + ".o"))
-    if force or _newer(LIB, deps):
+    # (the objects may be gone while the library is current -- a shipped .so, a cleaned build/: the hooks library below links them, so a
+    # missing one forces the compile step)
+    if force or _newer(LIB, deps) or (hooks and (force or _newer(HOOKS_LIB, deps + [LIB])) and not all(os.path.exists(o) for o in objs)):
         # one hipcc per source, side by side (the tile kernel alone is over a minute of template instantiations per id format), then one link
         from concurrent.futures import ThreadPoolExecutor
         os.makedirs(objdir, exist_ok=True)

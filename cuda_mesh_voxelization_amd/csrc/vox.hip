@@ -501,12 +501,17 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
             ctx->vox_total_seen = std::max<uint64_t>(ctx->vox_total_seen, ctx->vox_total_host[0]);
             ctx->vox_nbig_seen = std::max<uint64_t>(ctx->vox_nbig_seen, ctx->vox_total_host[1]);
             ctx->vox_counts_known = true;
+            if (ctx->vox_total_host[1] == 0) ctx->vox_nolist_job = ctx->vox_pending_job;          // that job has no large triangle
+            else if (ctx->vox_nolist_job == ctx->vox_pending_job) ctx->vox_nolist_job = vp_ctx::VoxJob{};
         }
-        // A context that has never met a large triangle (every count read back so far was zero: fine meshes, like the benchmark's) gives the
-        // record list no room and leaves the three list kernels out -- they would find nothing to do and cost their launches (0.02 ms of a
-        // 0.07-ms voxelization at n = 512).  Should a large triangle turn up all the same, vox_setup walks it in place (slow for that one call,
-        // correct: the path of a full record list), its count comes back, and every later call takes the tile stage again.
-        const bool noLists = ctx->vox_counts_known && ctx->vox_nbig_seen == 0;
+        const vp_ctx::VoxJob job{d_tri, ntris, f.n, f.z0, f.z1};
+        // A job whose large-triangle count came back as zero (a fine mesh, like the benchmark's) and that is repeated -- the same triangle
+        // buffer, count, grid side and slab -- gives the record list no room and leaves the three list kernels out: they would find nothing to do
+        // and cost their launches (0.02 ms of a 0.07-ms voxelization at n = 512).  Any other job on the context takes the tile stage (a coarse
+        // mesh walked triangle by triangle in vox_setup would cost milliseconds per triangle).  Should the buffer have been refilled in place
+        // with large triangles, vox_setup walks them in place (slow for that one call, correct: the path of a full record list), the count
+        // comes back non-zero and the job takes the tile stage again.
+        const bool noLists = ctx->vox_nolist_job == job && ctx->vox_nolist_job.tri != nullptr;
         const size_t want = std::max<size_t>((size_t)1 << 20, (size_t)ctx->vox_total_seen + ctx->vox_total_seen / 4);
         VP_TRY(reserve(ctx, ctx->pairs, want * 4));
         // record list: 64 Ki records (5 MiB) or what earlier calls needed + 25 %, never more than one per triangle
@@ -542,6 +547,7 @@ int launch_voxelize(vp_ctx* ctx, const Frame& f, uint32_t* d_words, const float*
             VP_HIP(hipMemcpyAsync(ctx->vox_total_host + 1, d_nbig, 4, hipMemcpyDeviceToHost, st));
             VP_HIP(hipEventRecord(ctx->vox_total_event, st));
             ctx->vox_total_pending = true;
+            ctx->vox_pending_job = job;
         }
         if (!noLists) {
             ProfScope p(ctx, VP_K_VOX_SCATTER);

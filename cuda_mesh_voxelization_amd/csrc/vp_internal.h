@@ -74,6 +74,11 @@ struct vp_ctx {
     uint64_t vox_total_seen = 0;
     uint64_t vox_nbig_seen = 0;                // large triangles an earlier call counted (sizes the record list)
     bool vox_counts_known = false;             // at least one such count has come back
+    // the job (triangle buffer, count, grid side, slab) whose large-triangle count last came back as ZERO: only that very job leaves the
+    // list kernels out (a coarse mesh that follows a fine one on the same context must not be walked triangle by triangle)
+    struct VoxJob { const void* tri = nullptr; size_t ntris = 0; uint32_t n = 0, z0 = 0, z1 = 0;
+                    bool operator==(const VoxJob& o) const { return tri == o.tri && ntris == o.ntris && n == o.n && z0 == o.z0 && z1 == o.z1; } };
+    VoxJob vox_pending_job, vox_nolist_job;
     // profiling
     bool prof_on = false;
     uint64_t prof_mask = ~0ull;                                    // timing keys that get events (vp_prof_select)

@@ -168,22 +168,26 @@ def test_voxelize_record_list_overflow_path(engine):
 
 
 def test_voxelize_without_list_kernels_and_the_first_large_triangle(engine):
-    """A context that has only ever counted zero large triangles leaves the three list kernels out (the record list gets no room).  The
-    first mesh WITH large triangles after that is walked in place by the setup kernel -- correct, slow once --, its count comes back, and
-    the tile stage runs again from the next call on.  Fresh context; bitmasks against the oracle at every step."""
+    """A job whose large-triangle count came back as zero leaves the three list kernels out when it is REPEATED (same triangle buffer, count,
+    grid side and slab: the record list gets no room).  Any other job on the context -- a coarse mesh after the fine one -- takes
+    the tile stage.  A buffer refilled in place with large triangles is walked in place by the setup kernel -- correct, slow once --, its count
+    comes back, and the tile stage runs again from the next call on.  Fresh context; bitmasks against the oracle at every step."""
     ctx = capi.Context(0)
     try:
         ctx.set_stream(torch.cuda.current_stream(engine.device).cuda_stream, external=True)
         n = 256
         fine = M.import_mesh(M.asset("bunny.obj"))
-        coarse = M.import_mesh(M.asset("d20.obj"))                    # 20 grid-spanning triangles
+        cx, ct = M.import_mesh(M.asset("d20.obj"))                    # 20 grid-spanning triangles, fitted into the fine mesh's box
+        lo, hi = fine[0].min(0), fine[0].max(0)
+        coarse = ((lo + ((cx - cx.min(0)) / (cx.max(0) - cx.min(0)) * np.float32(0.9) + np.float32(0.05)) * (hi - lo)).astype(np.float32), ct)
+        origin, vs = M.frame([fine[0]], n)                             # one frame for every step (the vertices moved below stay inside it)
+        fr = Frame.make(n, vs, origin)
+        dev = {id(m): engine.mesh_to_device(*m) for m in (fine, coarse)}          # resident meshes: the job identity includes the buffer
+        g = engine.new_grid(fr)
 
-        def run(mesh, prof=False):
-            xyz, tri = mesh
-            origin, vs = M.frame([xyz], n)
-            fr = Frame.make(n, vs, origin)
-            dx, dt = engine.mesh_to_device(xyz, tri)
-            g = engine.new_grid(fr)
+        def run(mesh, prof=False, xyz=None):
+            dx, dt = dev[id(mesh)]
+            xyz = mesh[0] if xyz is None else xyz
             if prof:
                 ctx.prof_reset(); ctx.prof_enable(True)
             ctx.voxelize(fr, g.data_ptr(), dx.data_ptr(), dx.shape[0], dt.data_ptr(), dt.shape[0], ALGO_TILED, False)
@@ -191,18 +195,28 @@ def test_voxelize_without_list_kernels_and_the_first_large_triangle(engine):
             keys = set()
             if prof:
                 ctx.prof_enable(False); keys = set(ctx.prof())
-            assert np.array_equal(engine.words_to_numpy(g), O.voxelize(xyz, tri, n, vs, origin))
+            assert np.array_equal(engine.words_to_numpy(g), O.voxelize(xyz, mesh[1], n, vs, origin))
             return keys
 
+        lists = {"vox_scan", "vox_scatter", "vox_tile"}
         assert "vox_tile" in run(fine, prof=True)                      # first call: nothing known yet, the whole sequence
-        run(fine)                                                     # its counts (zero large triangles) have landed by now ...
+        run(fine)                                                     # its count (zero large triangles) has landed by now ...
         keys = run(fine, prof=True)
-        assert "vox_setup" in keys and not ({"vox_scan", "vox_scatter", "vox_tile"} & keys)      # ... so the list kernels stay out
-        keys = run(coarse, prof=True)                                 # large triangles all the same: walked in place by vox_setup
-        assert not ({"vox_scan", "vox_scatter", "vox_tile"} & keys)
+        assert "vox_setup" in keys and not (lists & keys)              # ... so the repeated job leaves the list kernels out
+        assert lists <= run(coarse, prof=True)                         # ANOTHER job on the context: the tile stage, at once
         run(coarse)
-        assert "vox_tile" in run(coarse, prof=True)                    # the count came back: the tile stage is on again, for good
-        assert "vox_tile" in run(fine, prof=True)
+        assert lists <= run(coarse, prof=True)
+        assert not (lists & run(fine, prof=True))                      # ... and the fine job is still known to need none
+        # the fine mesh's vertex buffer refilled in place: a few vertices dragged to the corners of the frame make their triangles grid-spanning
+        xyz2 = fine[0].copy()
+        for j, i in enumerate(range(0, xyz2.shape[0], xyz2.shape[0] // 6)):
+            corner = np.array([lo[0] if j & 1 else hi[0], lo[1] if j & 2 else hi[1], lo[2] if j & 4 else hi[2]], np.float32)
+            xyz2[i] = corner * np.float32(0.98) + (lo + hi) * np.float32(0.01)
+        dev[id(fine)][0].copy_(torch.from_numpy(xyz2))
+        keys = run(fine, prof=True, xyz=xyz2)                          # same job identity: walked in place by vox_setup -- and still exact
+        assert not (lists & keys)
+        run(fine, xyz=xyz2)                                           # the count (non-zero now) has landed ...
+        assert lists <= run(fine, prof=True, xyz=xyz2)                 # ... the tile stage is on again for this job
     finally:
         ctx.close()
 
