@@ -116,6 +116,12 @@ __device__ __forceinline__ void ft_store(uint2* p, uint2 v)
 {
     __builtin_nontemporal_store(__builtin_bit_cast(unsigned long long, v), reinterpret_cast<unsigned long long*>(p));
 }
+// Row store through a buffer resource (32-bit ids): the row base -- uniform -- in SGPRs, the lane's column as the 32-bit offset, nt policy:
+// no 64-bit vector address per store (VP_EXP_FT_BUF, round 6 experiment: see profiles/r06/ab_ft_bufstore.txt).
+__device__ __forceinline__ void ft_store_row(uint32_t* row, uint32_t bytes, uint32_t byte_off, uint32_t v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(v, row_resource(row, bytes), (int)byte_off, 0, 2);
+}
 // CPT (n > 1024): the result leaves in the compact layout of IdC -- `out` = the word planes, `outB` = the byte planes of the window --
 // instead of ID's own; inside the kernel the ids stay ID's (Id64).
 constexpr int kTilesPerWg = 2;    // tiles per workgroup.  Round 3, without the census fast path (profiles/r03/ab_tpw_*.txt): 1 / 2 / 4 / 8 tiles = 0.371 /
@@ -245,7 +251,11 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
                         ft_store(reinterpret_cast<uint32_t*>(out) + vox, c.x);
                         ft_store(outB + vox, (unsigned char)c.y);
                     } else {
+#ifdef VP_EXP_FT_BUF
+                        ft_store_row(reinterpret_cast<uint32_t*>(out) + (size_t)((rz + (rp >> 2) * kzl) * N + (ry + (rp & 3u) * k)) * N, N * 4u, myx * 4u, id);
+#else
                         ft_store(out + vox, id);
+#endif
                     }
                 }
                 continue;                                              // next tile of the workgroup (uniform)
@@ -320,7 +330,11 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
                 ft_store(reinterpret_cast<uint32_t*>(out) + vox, c.x);
                 ft_store(outB + vox, (unsigned char)c.y);
             } else {
+#ifdef VP_EXP_FT_BUF
+                ft_store_row(reinterpret_cast<uint32_t*>(out) + (size_t)((rz + (rp >> 2) * kzl) * N + (ry + (rp & 3u) * k)) * N, N * 4u, myx * 4u, id);
+#else
                 ft_store(out + vox, id);
+#endif
             }
         }
     }
