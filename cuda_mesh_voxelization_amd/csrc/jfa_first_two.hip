@@ -116,12 +116,10 @@ __device__ __forceinline__ void ft_store(uint2* p, uint2 v)
 {
     __builtin_nontemporal_store(__builtin_bit_cast(unsigned long long, v), reinterpret_cast<unsigned long long*>(p));
 }
-// Row store through a buffer resource (32-bit ids): the row base -- uniform -- in SGPRs, the lane's column as the 32-bit offset, nt policy:
-// no 64-bit vector address per store (VP_EXP_FT_BUF, round 6 experiment: see profiles/r06/ab_ft_bufstore.txt).
-__device__ __forceinline__ void ft_store_row(uint32_t* row, uint32_t bytes, uint32_t byte_off, uint32_t v)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(v, row_resource(row, bytes), (int)byte_off, 0, 2);
-}
+// (Round 6, measured and dropped: the id stores through a buffer resource per row -- the uniform row base in SGPRs, the lane's column as the
+// 32-bit offset, no 64-bit vector address per store -- ran +2.5 % at n = 512 and +4.7 % at n = 1024, profiles/r06/ab_ft_bufstore.txt.  The kernel
+// issues ~930 vector instructions per tile, four clocks each on a SIMD: 512 tiles per SIMD x 233 per wave x 4 = 199 of its 217 us at n = 512;
+// its ~1,160 scalar instructions per tile run beside them on the scalar unit and are not what bounds it.)
 // CPT (n > 1024): the result leaves in the compact layout of IdC -- `out` = the word planes, `outB` = the byte planes of the window --
 // instead of ID's own; inside the kernel the ids stay ID's (Id64).
 constexpr int kTilesPerWg = 2;    // tiles per workgroup.  Round 3, without the census fast path (profiles/r03/ab_tpw_*.txt): 1 / 2 / 4 / 8 tiles = 0.371 /
@@ -251,11 +249,7 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
                         ft_store(reinterpret_cast<uint32_t*>(out) + vox, c.x);
                         ft_store(outB + vox, (unsigned char)c.y);
                     } else {
-#ifdef VP_EXP_FT_BUF
-                        ft_store_row(reinterpret_cast<uint32_t*>(out) + (size_t)((rz + (rp >> 2) * kzl) * N + (ry + (rp & 3u) * k)) * N, N * 4u, myx * 4u, id);
-#else
                         ft_store(out + vox, id);
-#endif
                     }
                 }
                 continue;                                              // next tile of the workgroup (uniform)
@@ -330,11 +324,7 @@ jfa_first_two(Frame f, const uint32_t* __restrict__ border, typename ID::T* __re
                 ft_store(reinterpret_cast<uint32_t*>(out) + vox, c.x);
                 ft_store(outB + vox, (unsigned char)c.y);
             } else {
-#ifdef VP_EXP_FT_BUF
-                ft_store_row(reinterpret_cast<uint32_t*>(out) + (size_t)((rz + (rp >> 2) * kzl) * N + (ry + (rp & 3u) * k)) * N, N * 4u, myx * 4u, id);
-#else
                 ft_store(out + vox, id);
-#endif
             }
         }
     }
