@@ -19,6 +19,8 @@ Rank 0 prints ONE JSON line (DESIGN.md "Measurement"):
   copy_peak             (N = 1) vp_stream_copy over 1 GiB on this box: roofline.measured_copy_GBs / frac_of_measured
   config3               (N = 1, default size) BASELINE config 3 as a pipeline: bimba + bunny voxelize, CSG union, JFA at n = 512,
                         device-resident; kernels.csg_words against 3 n^3/8 bytes; checked against the reference's golden row
+  vox_large_triangles   (N = 1, default size) the LDS tile rasteriser on a mesh of large triangles (vox_scan / vox_scatter / vox_tile per step),
+                        checked against the naive voxelizer
   totals_incl_transfers (N = 1, default size) one host-in / host-out round (vp_voxelize_host + vp_jfa_host) = what the
                         reference's Compute() calls time as Memory + Processing (38.6 + 829.6 ms)
 
@@ -257,6 +259,42 @@ def run_config3(eng, steps=10, warmup=2):
                     "note": "3 n^3/8 = 48 MiB at n = 512: a ~10 us kernel, launch- and ramp-bound rather than HBM-bound; the reference's "
                             "kernel takes 1.59 ms (benchmarks_v2/bunny_1348128/bunny_1348128_naive_csg.csv:82-101)"},
             "checks": got, "golden": "tests/golden/survey_table.json (bimba + bunny, n = 512, union)", "parity_ok": ok}
+
+
+def run_large_triangles(eng, steps=20, warmup=3):
+    """The LDS tile rasteriser on its own: the headline mesh has no large triangle, so its voxelizer is vox_zero +
+    vox_setup + vox_fill.  sphere.obj (1,280 faces) at n = 512 is the opposite case: every triangle spans dozens of 8 x 8-column tiles, all of
+    them go through the record list, the tile histogram scan, the per-tile lists and the ds_xor tile kernel.  Checked bit for bit against the
+    naive voxelizer (one thread per triangle, word-mask atomicXor) on the same device."""
+    from cuda_mesh_voxelization_amd import mesh as M
+    from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, Frame
+    n = 512
+    xyz, tri = M.import_mesh(M.asset("sphere.obj"))
+    origin, vs = M.frame([xyz], n)
+    fr = Frame.make(n, vs, origin)
+    d = eng.mesh_to_device(xyz, tri)
+    g, h = eng.new_grid(fr), eng.new_grid(fr)
+    for _ in range(warmup):
+        eng.voxelize(fr, d[0], d[1], out=g, algo=ALGO_TILED)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.voxelize(fr, d[0], d[1], out=g, algo=ALGO_TILED)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.ctx.prof_reset(); eng.ctx.prof_select(None); eng.ctx.prof_enable(True)
+    for _ in range(TABLE_STEPS):
+        eng.voxelize(fr, d[0], d[1], out=g, algo=ALGO_TILED)
+    torch.cuda.synchronize()
+    eng.ctx.prof_enable(False)
+    table = eng.ctx.prof()
+    eng.voxelize(fr, d[0], d[1], out=h, algo=ALGO_NAIVE)
+    torch.cuda.synchronize()
+    return {"workload": "sphere.obj (%d faces, every one of them large), tiled solid voxelize into a bit-packed %d^3 grid, device-resident" % (tri.shape[0], n),
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "Mvoxels/s": round(n ** 3 / (elapsed / steps) / 1e6, 1), "steps": steps,
+            "kernels_ms_per_step": {k: round(v["ms"] / TABLE_STEPS, 4) for k, v in table.items()},
+            "set_voxels": popcount_words(g), "equal_to_naive_voxelizer": bool(torch.equal(g, h)),
+            "reference_ms": {"tiled_processing_kernel_n512_1.35M_faces": 2.0, "source": "SURVEY.md 8(a) a-10 (benchmarks_v2, unstated NVIDIA GPU); a different mesh: for scale only"}}
 
 
 def host_totals(eng, frame, xyz, tri, algo):
@@ -585,6 +623,8 @@ def main():
             out["config3"] = run_config3(eng)
             if "csg_words" in out["config3"]["kernels"]:
                 out["kernels"]["csg_words"] = dict(out["config3"]["kernels"]["csg_words"], measured_in="config3 (the headline step has no CSG)")
+        if world == 1 and n == N_GRID and not args.no_config3:
+            out["vox_large_triangles"] = run_large_triangles(eng)
         if world == 1 and n == N_GRID and not args.no_host_totals:
             out["totals_incl_transfers"] = host_totals(eng, frame, xyz, tri, ALGO_TILED)
             out["totals_incl_transfers_ms"] = out["totals_incl_transfers"]["total_ms"]

@@ -1,5 +1,5 @@
 """Dev tool (GPU box): randomized campaign for the Python Z-slab pipelines (slab.py: what `bench.py --gpus N` runs): random mesh (asset
-under a random similarity, or a triangle soup), grid side, rank count and pipeline (ghost planes; RCCL-halo and hybrid
+under a random similarity, or a triangle soup), grid side, rank count and pipeline (ghost planes; RCCL-halo, hybrid and transposed
 with ranks emulated by threads over the loopback of tests/test_slab_gpu.py), all on id windows, now and then above n = 1024 (5-byte layout); every rank's slab of the bitmask and of
 the sdf against the whole-grid run, bit for bit.
   python tools/fuzz_pipelines.py [--seconds 600] [--seed0 20000]"""
@@ -23,7 +23,7 @@ while time.time() < t_end:
     rng = np.random.default_rng(seed)
     n = int(rng.choice([96, 128, 192, 256, 288, 384, 512, 1152] if rng.random() < 0.9 else [1152, 1280]))
     world = int(rng.choice([g for g in (2, 3, 4, 6, 8) if n % g == 0 and (n // g) % 8 == 0]))
-    kind = str(rng.choice(["ghost", "halo", "hybrid"]))
+    kind = str(rng.choice(["ghost", "halo", "hybrid", "transpose", "transpose"]))     # (3 and 6 ranks: transpose runs its ghost fallback)
     algo = ALGO_TILED if (n > 512 or rng.random() < 0.8) else ALGO_NAIVE          # the voxelizer's and the reference run's algorithm
     if rng.random() < 0.6:                                        # an asset, rotated about z by a multiple of 90 degrees, scaled, moved
         xyz, tri = assets[int(rng.integers(len(assets)))]

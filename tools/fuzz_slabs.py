@@ -1,11 +1,11 @@
 """Dev tool (GPU box): randomized campaign for the Z-slab driver (vp_multi_*, several contexts on device 0): random grid, slab count,
-transport (halo / ghost / hybrid) and algorithm; the concatenated slabs against the single-context vp_jfa, bit for bit.
+transport (halo / ghost / hybrid / transpose) and algorithm; the concatenated slabs against the single-context vp_jfa, bit for bit.
   python tools/fuzz_slabs.py [--seconds 600] [--seed0 5000]"""
 import argparse, math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from cuda_mesh_voxelization_amd import capi
-from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, MULTI_GHOST, MULTI_HALO, MULTI_HYBRID, Frame
+from cuda_mesh_voxelization_amd.capi import ALGO_NAIVE, ALGO_TILED, MULTI_GHOST, MULTI_HALO, MULTI_HYBRID, MULTI_TRANSPOSE, Frame
 from cuda_mesh_voxelization_amd.pipeline import Engine
 
 ap = argparse.ArgumentParser()
@@ -17,7 +17,7 @@ while time.time() < t_end:
     rng = np.random.default_rng(seed)
     n = int(rng.choice([64, 128, 192, 256, 320, 384, 512]))
     world = int(rng.choice([g for g in (2, 3, 4, 5, 6, 8) if n % g == 0 and (n // g) % 8 == 0]))
-    mode = int(rng.choice([MULTI_HALO, MULTI_GHOST, MULTI_HYBRID]))
+    mode = int(rng.choice([MULTI_HALO, MULTI_GHOST, MULTI_HYBRID, MULTI_TRANSPOSE, MULTI_TRANSPOSE]))
     algo = ALGO_TILED if rng.random() < 0.8 else ALGO_NAIVE
     fill = -math.inf if rng.random() < 0.7 else math.inf
     vs = float(np.float32(10.0 ** rng.uniform(-2.5, 0.5)))
