@@ -401,6 +401,22 @@ def main():
     from cuda_mesh_voxelization_amd.capi import ALGO_TILED, Frame
     from cuda_mesh_voxelization_amd.pipeline import Engine
 
+    # N > 1: libraries write to stdout on their own -- RCCL prints its version banner there with plain printf under NCCL_DEBUG=VERSION (set on
+    # the pool's boxes), C-buffered, i.e. AFTER everything this process prints.  The one JSON line is what stdout is for: file descriptor 1
+    # is pointed at stderr for the life of the rank and the line goes out through a duplicate of the original descriptor.
+    json_fd = None
+    if world > 1:
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(obj):
+        line = json.dumps(obj)
+        if json_fd is None:
+            print(line, flush=True)
+        else:
+            os.write(json_fd, (line + "\n").encode())
+
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -651,7 +667,7 @@ def main():
                     out[alt_keys[current[0]]] = {"pipeline": alt_kinds[current[0]], "steps": alt_steps, "ms_per_step": None, "value": None, "parity_ok": None,
                                                  "error": "no result within %.0f s (VP_BENCH_ALT_TIMEOUT): the transport hung; the timed "
                                                           "pipeline's figures and parity above stand" % limit}
-                    print(json.dumps(out), flush=True)
+                    emit(out)
                 sys.stdout.flush()
                 sys.stderr.write("bench.py: rank %d gave up on the %s pipeline after %.0f s\n" % (rank, alt_kinds[current[0]], limit))
                 sys.stderr.flush()
@@ -677,7 +693,7 @@ def main():
             if rank == 0:
                 out.update(alts)
                 out["parity_ok"] = parity["parity_ok"] and alts_ok
-                print(json.dumps(out), flush=True)
+                emit(out)
             printed[0] = True
         dist.barrier()
         with lock:
@@ -685,7 +701,7 @@ def main():
         timer.cancel()
         dist.destroy_process_group()
     elif rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
 
     bad = parity is not None and not (parity["parity_ok"] and alts_ok)
     if bad:

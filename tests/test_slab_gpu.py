@@ -489,6 +489,9 @@ def test_bench_multi_process_launch_on_shared_gpu(world, multi):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]                        # rank 0 prints ONE line
+    # ... and the ranks' stdout carries nothing else: descriptor 1 of every rank points at stderr (RCCL prints a version banner with plain
+    # printf under NCCL_DEBUG=VERSION, after the JSON line), the line leaves through a duplicate of the original descriptor
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == world and out["steps"] == 3 and out["scaling"] == "strong"
     assert out["config"]["world_size_seen"] == world and out["config"]["n"] == 256
@@ -559,3 +562,52 @@ def test_bench_other_transport_hang_does_not_take_the_line_with_it():
     # VP_BENCH_LENIENT=1: the same, exit code 0
     r = subprocess.run(cmd, cwd=root, env=dict(env, VP_BENCH_LENIENT="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_rccl_first_contact_with_one_rank(tmp_path):
+    """What of the RCCL path CAN be exercised on a one-GPU box: a one-rank `nccl` process group (backend "nccl" IS RCCL on ROCm) running the
+    exact calls of the transposed pipeline's exchange -- all_to_all_single on uint8 device tensors with explicit split sizes, between a
+    kernel of this library that produces the send window and one that consumes the staging window on torch's current stream -- plus the
+    barrier / all_reduce / all_gather the bench line uses.  With one rank the collective is a copy onto itself: the data path through the
+    library's windows, the dtype and size handling and the stream ordering are real, the wire is not."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
+        torch.cuda.set_device(0)
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        except Exception as e:
+            print("SKIP", type(e).__name__, e); sys.exit(0)
+        from cuda_mesh_voxelization_amd.capi import Frame, Window
+        from cuda_mesh_voxelization_amd.pipeline import Engine
+        eng = Engine(0)
+        ok = True
+        for n, planes in ((256, 24), (1056, 6)):                      # 4-byte ids; the 5-byte layout (two parts: two collectives)
+            fr = Frame.make(n, 0.01, (0.0, 0.0, 0.0))
+            nb = eng.ctx.jfa_window_bytes(fr, planes)
+            send = torch.randint(0, 255, (nb,), dtype=torch.uint8, device="cuda")
+            stag = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            out = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+            for off, cnt in eng.ctx.jfa_window_span(fr, planes, 0, planes):
+                dist.all_to_all_single(stag[off:off + cnt], send[off:off + cnt], [cnt], [cnt])
+            eng.ctx.jfa_window_interleave(fr, Window.make(stag.data_ptr(), nb, planes, 0), Window.make(out.data_ptr(), nb, planes, 0), 1, planes)
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.equal(out, send))
+        dist.barrier()
+        t = torch.tensor([3.0], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g = [torch.zeros(2, dtype=torch.int32, device="cuda")]; dist.all_gather(g, torch.tensor([1, 1], dtype=torch.int32, device="cuda"))
+        ok = ok and t.item() == 3.0 and g[0].tolist() == [1, 1]
+        dist.destroy_process_group()
+        print("OK" if ok else "MISMATCH")
+    """ % root)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    lines = [ln.strip() for ln in r.stdout.splitlines()]              # (RCCL prints a version banner of its own on stdout)
+    skipped = [ln for ln in lines if ln.startswith("SKIP")]
+    if skipped:
+        pytest.skip("no RCCL process group on this box: " + skipped[0])
+    assert r.returncode == 0 and "OK" in lines and "MISMATCH" not in lines, r.stdout[-2000:] + r.stderr[-3000:]
