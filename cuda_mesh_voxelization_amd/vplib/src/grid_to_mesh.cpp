@@ -1,7 +1,7 @@
 // grid_to_mesh.cpp -- see grid_to_mesh.h.  VoxelsGridToMeshCompressed emits the reference's mesh (grid_to_mesh.h:25-92,
 // grid_to_mesh.cpp:10-60: face set, vertex order, winding, normal indices; pinned face by face by tests/test_export.py);
 // VoxelsGridToMesh / VoxelsGridToPointCloud emit the reference's cubes and points (:65-201: vertex order, its twelve triangles and normal slots
-// per cube, SDFToRGB colours through the 8-bit Color; pinned to oracle/oracle_export.c by tests/test_export.py).
+// per cube, SDFToRGB colours through the 8-bit Color; pinned line by line by tests/test_export.py).
 //
 // Every exporter is written against a stream of voxel RECORDS (linear index + exposed-face mask) in z, y, x order.
 // The host variants produce the records by walking the grid (what the reference does, grid_to_mesh.cpp:10-201); the
