@@ -81,6 +81,11 @@ def test_cli_usage_and_errors(cli, tmp_path):
     assert p.returncode != 0 and "CPU Assert" in p.stdout            # debug_utils.h:52-60 behaviour
     p = subprocess.run([cli, M.asset("d20.obj"), "-b", "24"], capture_output=True, text=True)
     assert p.returncode != 0 and "multiple of 16" in p.stdout         # main.cpp:60
+    # a legal -b is accepted and SAID to have no effect (a `#` line: the benchmark script reads only `[Label]: ms` lines); silent without -b
+    p = subprocess.run([cli, M.asset("d20.obj"), "-t", "0", "-b", "64"], capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 0 and "# note: -b/--block-size 64" in p.stdout and "no effect" in p.stdout
+    p = subprocess.run([cli, M.asset("d20.obj"), "-t", "0"], capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 0 and "# note" not in p.stdout
     p = subprocess.run([cli, str(tmp_path / "missing.obj"), "-t", "0"], capture_output=True, text=True)
     assert p.returncode != 0
 
