@@ -27,9 +27,9 @@ Rank 0 prints ONE JSON line (DESIGN.md "Measurement"):
 N > 1: strong scaling of the same n^3 job over N Z-slabs, one process per GPU (cuda_mesh_voxelization_amd/slab.py).  After the
 timed region every rank runs the ONE-GPU path on its own device and compares its slab of the bitmask and of the sdf bit for
 bit (`parity_ok`; a mismatch on any rank makes the run exit non-zero), then times the OTHER pipelines over shorter regions, checked
-the same way: `multi_alt` = the transposed pipeline (cyclic planes, ONE RCCL all-to-all; ghost planes when the job itself ran
-transposed), `multi_alt_halo` = RCCL point-to-point halos before every pass -- under a watchdog (VP_BENCH_ALT_TIMEOUT, default 180 s
-each): if a transport hangs, rank 0 prints the line of the timed pipeline as it stands, with the time-out recorded in that object,
+the same way: `multi_alt` = the transposed pipeline (cyclic planes, ONE RCCL all-to-all), `multi_alt_halo` = RCCL point-to-point halos
+before every pass, `multi_alt_transpose_p2p` = the transposed pipeline with its planes sent point to point and placed directly -- under a
+watchdog (VP_BENCH_ALT_TIMEOUT, default 180 s each): if a transport hangs, rank 0 prints the line of the timed pipeline as it stands, with the time-out recorded in that object,
 and the job ends with exit code 2 (VP_BENCH_LENIENT=1: 0).
 """
 from __future__ import annotations
@@ -64,10 +64,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE config 3 block (bimba + bunny, CSG union, JFA at n = 512)")
     ap.add_argument("--no-host-totals", action="store_true", help="skip the host-in / host-out round (reference-style totals)")
     ap.add_argument("--no-copy-peak", action="store_true", help="skip the 1-GiB stream-copy measurement")
-    ap.add_argument("--multi", choices=["ghost", "halo", "hybrid", "transpose"], default="ghost",
+    ap.add_argument("--multi", choices=["ghost", "halo", "hybrid", "transpose", "transpose-p2p"], default="ghost",
                     help="N > 1: 'ghost' = Z-slabs with recomputed ghost planes, no data-path exchange (default: the one pipeline that needs no "
                          "transport the build could never try on hardware); 'transpose' = planes dealt cyclically for every pass whose step is a "
-                         "multiple of N (no exchange, no ghost planes), ONE RCCL all-to-all, Z-slabs for the last log2 N passes; 'halo' = Z-slabs "
+                         "multiple of N (no exchange, no ghost planes), ONE RCCL all-to-all, Z-slabs for the last log2 N passes ('transpose-p2p': the same "
+                         "planes as one batch of point-to-point messages placed directly: no send / staging buffer, no weave); 'halo' = Z-slabs "
                          "with RCCL point-to-point halo planes before every pass; 'hybrid' = ghost planes for the wide passes (k > nz/2), halos of "
                          "the adjacent ranks -- sent a pass ahead, under the interior planes -- for the narrow ones")
     return ap.parse_args(argv)
@@ -511,9 +512,10 @@ def main():
                   "against": "the one-GPU path (vp_voxelize + vp_jfa of the whole grid) run on each rank's own device after the timed region"}
         # ---- the other transport in the same job, over a shorter region (so that a scaling run shows RCCL moving halos and not
         # only barriers when the default is ghost planes, and the exchange-free figure when it is not)
-        # `multi_alt` = the transposed pipeline (ghost planes if that is what the job itself ran), then the remaining one of halo / ghost
-        alt_kinds = [k for k in ("transpose", "halo", "ghost") if k != args.multi][:2]
-        alt_keys = ["multi_alt"] + ["multi_alt_" + k for k in alt_kinds[1:]]
+        # `multi_alt` = the transposed pipeline (one all-to-all), then RCCL halos, then the transposed pipeline with its planes sent point to
+        # point -- each of them a transport the build could never try on hardware, each verified against the one-GPU result and time-boxed
+        alt_kinds = [k for k in ("transpose", "halo", "transpose-p2p", "ghost") if k != args.multi][:3]
+        alt_keys = ["multi_alt"] + ["multi_alt_" + k.replace("-", "_") for k in alt_kinds[1:]]
         alt_steps = max(2, args.steps // 4)
 
         def alt_region(alt_kind):

@@ -639,8 +639,13 @@ class TransposeSlabPipeline:
     state 2 x 0.5 + 3 x 0.6 GiB.  Grids whose step sequence leaves the multiples of world early (sides that are not powers of two) simply
     switch to the slab phase earlier, with a wider margin; where fewer than two passes qualify the pipeline IS the ghost pipeline."""
 
-    def __init__(self, backend, frame: Frame, rank: int, world: int, dist):
-        self.be, self.dist = backend, dist
+    def __init__(self, backend, frame: Frame, rank: int, world: int, dist, exchange: str = "a2a"):
+        """exchange: "a2a" = one all_to_all_single of packed chunks + the weave (the default); "p2p" = every plane sent point to point
+        straight from the window of the cyclic phase to its final place in the receiver's slab window (one batch of isend / irecv: no send
+        buffer, no staging buffer, no weave -- at the price of (world - 1) x count messages per rank instead of one collective)"""
+        if exchange not in ("a2a", "p2p"):
+            raise ValueError("exchange must be 'a2a' or 'p2p'")
+        self.be, self.dist, self.exchange_kind = backend, dist, exchange
         self.rank, self.world = rank, world
         self.global_frame = frame
         self.be.check_frame(frame)
@@ -688,14 +693,15 @@ class TransposeSlabPipeline:
     def describe(self):
         if self.fallback is not None:
             return self.fallback.describe() + " (no step of this grid is a multiple of the rank count twice: transposed = ghost)"
-        return "x%d transposed: planes dealt cyclically for the %d passes k >= %d (no exchange), one RCCL all-to-all, z-slabs for k < %d" % (
-            self.world, len(self.plan["cyclic"]), self.plan["cyclic"][-1], self.plan["cyclic"][-1])
+        how = "one RCCL all-to-all" if self.exchange_kind == "a2a" else "one batch of RCCL point-to-point planes, placed directly"
+        return "x%d transposed: planes dealt cyclically for the %d passes k >= %d (no exchange), %s, z-slabs for k < %d" % (
+            self.world, len(self.plan["cyclic"]), self.plan["cyclic"][-1], how, self.plan["cyclic"][-1])
 
     def report(self):
         if self.fallback is not None:
             return dict(self.fallback.report(), pipeline="transpose->ghost")
         n, passes = self.global_frame.n, len(self.plan["cyclic"]) + len(self.plan["regions"])
-        return {"pipeline": "transpose", "slab_planes": self.z1 - self.z0, "cyclic_steps": list(self.plan["cyclic"]),
+        return {"pipeline": "transpose", "exchange": self.exchange_kind, "slab_planes": self.z1 - self.z0, "cyclic_steps": list(self.plan["cyclic"]),
                 "slab_regions": [[k, b0, b1] for k, b0, b1 in self.plan["regions"]], "recv_planes": list(self.plan["recv"]),
                 "window_planes": list(self.plan["window"]), "plane_passes_this_rank": int(self.planes_computed),
                 "plane_passes_one_gpu": n * passes, "plane_pass_ratio": round(n * passes / self.planes_computed, 3),
@@ -747,14 +753,46 @@ class TransposeSlabPipeline:
             self.dist.all_to_all_single(o, i, [self.count * per_plane] * w, [(b - a) * per_plane for a, b in self.send_ranges])
             self.bytes_received += (w - 1) * self.count * per_plane * o.element_size()
 
-    def phase_b(self, fill=-math.inf, out=None):
-        """the weave into consecutive planes, then the remaining steps on the widened slab (as the last regions of the ghost pipeline)"""
+    def exchange_p2p(self, src):
+        """the re-deal without a send buffer, a staging buffer or a weave: plane t0 + s + j world of my widened slab is received from rank s
+        straight into its place in the slab window, my planes of every other rank's slab are sent straight from the window of the cyclic
+        phase -- one batch of point-to-point operations (posted in the same plane order on both sides); my own planes: one strided copy"""
+        G, be, w, r = self.global_frame, self.be, self.world, self.rank
+        d, P = self.dist, self.dist.P2POp
+        lo, _ = self.plan["window"]
+        dst = self._w("ids0")
+        at = self.plan["recv"][0] - lo
+        ops = []
+        for t in range(w):                                           # sends: to rank t its planes [a, b) of my window, in order
+            if t == r:
+                continue
+            a, b = self.send_ranges[t]
+            for l in range(a, b):
+                ops += [P(d.isend, piece, t) for piece in be.win_spans(G, src, l, l + 1)]
+        for s_ in range(w):                                          # receives: chunk s = the planes at + s, at + s + world, ...
+            if s_ == r:
+                continue
+            for j in range(self.count):
+                for piece in be.win_spans(G, dst, at + s_ + j * w, at + s_ + j * w + 1):
+                    ops.append(P(d.irecv, piece, s_))
+                    self.bytes_received += piece.numel() * piece.element_size()
+        reqs = d.batch_isend_irecv(ops) if ops else []
+        a, b = self.send_ranges[r]                                   # my own planes of my own slab
+        for dpart, spart in zip(be.win_spans(G, dst, 0, dst.planes), be.win_spans(G, src, 0, src.planes)):
+            dpart.view(dst.planes, -1)[at + r:at + r + w * self.count:w].copy_(spart.view(src.planes, -1)[a:b])
+        for q in reqs:
+            q.wait()
+
+    def phase_b(self, fill=-math.inf, out=None, weave=True):
+        """the weave into consecutive planes (exchange "a2a"), then the remaining steps on the widened slab (as the last regions of the ghost
+        pipeline)"""
         out = self.sdf if out is None else out
         G, be = self.global_frame, self.be
         pw = G.n * G.n // 32
         lo, _ = self.plan["window"]
         a, b = self._w("ids0"), self._w("ids1")
-        be.win_interleave(G, self._w("staging"), a, self.plan["recv"][0] - lo, self.world, self.count)
+        if weave:
+            be.win_interleave(G, self._w("staging"), a, self.plan["recv"][0] - lo, self.world, self.count)
         regs = self.plan["regions"]
         for i, (k, b0, b1) in enumerate(regs):
             region = G.slab(b0, b1)
@@ -768,6 +806,9 @@ class TransposeSlabPipeline:
     def jfa(self, fill=-math.inf, out=None):
         if self.fallback is not None:
             return self.fallback.jfa(fill, out)
+        if self.exchange_kind == "p2p":
+            self.exchange_p2p(self.phase_a())
+            return self.phase_b(fill, out, weave=False)
         self.pack(self.phase_a())
         self.exchange()
         return self.phase_b(fill, out)
@@ -786,4 +827,6 @@ def make_pipeline(kind: str, engine, frame: Frame, rank: int, world: int, dist):
         return HybridSlabPipeline(be, frame, rank, world, dist)
     if kind == "transpose":
         return TransposeSlabPipeline(be, frame, rank, world, dist)
+    if kind == "transpose-p2p":
+        return TransposeSlabPipeline(be, frame, rank, world, dist, exchange="p2p")
     raise ValueError("unknown multi-GPU pipeline %r" % kind)

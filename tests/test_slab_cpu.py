@@ -249,7 +249,7 @@ def test_hybrid_plan_feeds_itself():
 
 
 # ---------------------------------------------------------------------------------------------- transposed pipeline
-def _transpose_worker(rank, world, port, n, asset, outdir, poison=None):
+def _transpose_worker(rank, world, port, n, asset, outdir, poison=None, exchange="a2a"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -262,7 +262,7 @@ def _transpose_worker(rank, world, port, n, asset, outdir, poison=None):
         from slab_cpu_backend import CpuSlabBackend
         mesh = M.import_mesh(M.asset(asset))
         origin, vs = M.frame([mesh[0]], n)
-        pipe = TransposeSlabPipeline(CpuSlabBackend(mesh, poison=poison), Frame.make(n, vs, origin), rank, world, dist)
+        pipe = TransposeSlabPipeline(CpuSlabBackend(mesh, poison=poison), Frame.make(n, vs, origin), rank, world, dist, exchange=exchange)
         pipe.voxelize(None, None)
         sdf = pipe.jfa()
         dist.barrier()
@@ -272,19 +272,21 @@ def _transpose_worker(rank, world, port, n, asset, outdir, poison=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,asset,poison", [(2, 32, "sphere.obj", None), (4, 64, "torus.obj", None), (2, 64, "bunny.obj", 777), (4, 64, "d20.obj", 0),
-                                                  (2, 96, "torus.obj", None)])
-def test_transpose_pipeline_matches_single_domain_oracle(tmp_path, world, n, asset, poison):
+@pytest.mark.parametrize("world,n,asset,poison,exchange", [(2, 32, "sphere.obj", None, "a2a"), (4, 64, "torus.obj", None, "a2a"), (2, 64, "bunny.obj", 777, "a2a"),
+                                                           (4, 64, "d20.obj", 0, "a2a"), (2, 96, "torus.obj", None, "a2a"),
+                                                           (4, 64, "torus.obj", 777, "p2p"), (2, 32, "sphere.obj", None, "p2p")])
+def test_transpose_pipeline_matches_single_domain_oracle(tmp_path, world, n, asset, poison, exchange):
     """Planes dealt cyclically for the passes whose step is a multiple of the rank count (the numpy backend asserts that such a pass
     reads nothing but planes of its own rank), ONE all_to_all_single over gloo, the weave into consecutive planes, the remaining passes on
-    the widened slab (the backend asserts that no pass reads outside the window).  `poison`: what the planes of a fresh window that
+    the widened slab (the backend asserts that no pass reads outside the window).  exchange "p2p": the same planes as one batch of isend /
+    irecv, each received straight into its place in the slab window (no send buffer, no staging buffer, no weave).  `poison`: what the planes of a fresh window that
     nobody ever produces hold -- the result must not depend on it.  n = 96: the step sequence 48, 24, 12, 6, 3, 1 leaves the multiples
     of two after four passes."""
     sys.path.insert(0, ROOT)
     from cuda_mesh_voxelization_amd import mesh as M
     from cuda_mesh_voxelization_amd.slab import transpose_plan
     from oracle import oracle as O
-    mp.spawn(_transpose_worker, args=(world, _free_port(), n, asset, str(tmp_path), poison), nprocs=world, join=True)
+    mp.spawn(_transpose_worker, args=(world, _free_port(), n, asset, str(tmp_path), poison, exchange), nprocs=world, join=True)
     xyz, tri = M.import_mesh(M.asset(asset))
     origin, vs = M.frame([xyz], n)
     exp = O.jfa(O.voxelize(xyz, tri, n, vs, origin), n, vs, origin)

@@ -65,8 +65,9 @@ def _run_slabs(world, frame, xyz, tri, algo, kind="halo", poison=None):
     engines = [Engine(0) for _ in range(world)]
     pipes, errors = [], []
     for r in range(world):
-        cls = {"halo": SlabPipeline, "hybrid": HybridSlabPipeline, "transpose": TransposeSlabPipeline}[kind]
-        pipes.append(cls(HipSlabBackend(engines[r], poison=poison), frame, r, world, LoopbackDist(r, queues)))
+        cls = {"halo": SlabPipeline, "hybrid": HybridSlabPipeline, "transpose": TransposeSlabPipeline, "transpose-p2p": TransposeSlabPipeline}[kind]
+        extra = {"exchange": "p2p"} if kind == "transpose-p2p" else {}
+        pipes.append(cls(HipSlabBackend(engines[r], poison=poison), frame, r, world, LoopbackDist(r, queues), **extra))
     meshes = [engines[r].mesh_to_device(xyz, tri) for r in range(world)]
 
     def work(r):
@@ -84,7 +85,7 @@ def _run_slabs(world, frame, xyz, tri, algo, kind="halo", poison=None):
     for t in threads:
         t.join(600)
     assert not errors, errors
-    if kind in ("hybrid", "transpose"):                          # every rank holds the whole bitmask there
+    if kind in ("hybrid", "transpose", "transpose-p2p"):         # every rank holds the whole bitmask there
         pw = frame.n * frame.n // 32
         words = np.concatenate([Engine.words_to_numpy(p.words[p.z0 * pw:p.z1 * pw]) for p in pipes])
     else:
@@ -272,12 +273,15 @@ def test_window_interleave(engine):
             ctx.jfa_window_interleave(fr, Window.make(src.data_ptr(), src.numel(), ranks * count, 0), Window.make(dst.data_ptr(), dst.numel(), planes, planes - 1), ranks, count)
 
 
-@pytest.mark.parametrize("world,n,name,poison", [(2, 96, "bunny.obj", None), (4, 128, "torus.obj", 0xA5), (8, 128, "d20.obj", None), (8, 256, "bunny.obj", None),
-                                                 (2, 512, "bimba.obj", None), (8, 512, "bunny.obj", 0xFF), (4, 160, "sphere.obj", None), (4, 1152, "bimba.obj", None),
-                                                 (8, 1280, "bunny.obj", 0x5A)])
-def test_transpose_slabs_equal_whole_grid(engine, world, n, name, poison):
+@pytest.mark.parametrize("world,n,name,poison,kind", [(2, 96, "bunny.obj", None, "transpose"), (4, 128, "torus.obj", 0xA5, "transpose"), (8, 128, "d20.obj", None, "transpose"),
+                                                      (8, 256, "bunny.obj", None, "transpose"), (2, 512, "bimba.obj", None, "transpose"), (8, 512, "bunny.obj", 0xFF, "transpose"),
+                                                      (4, 160, "sphere.obj", None, "transpose"), (4, 1152, "bimba.obj", None, "transpose"), (8, 1280, "bunny.obj", 0x5A, "transpose"),
+                                                      (4, 128, "torus.obj", 0xA5, "transpose-p2p"), (8, 512, "bunny.obj", None, "transpose-p2p"), (2, 96, "d20.obj", None, "transpose-p2p"),
+                                                      (8, 1280, "bimba.obj", 0x5A, "transpose-p2p")])
+def test_transpose_slabs_equal_whole_grid(engine, world, n, name, poison, kind):
     """TransposeSlabPipeline with the real kernels, all emulated ranks at once: cyclic planes for the steps that are multiples of the rank
-    count, one all_to_all_single (in-process loopback), the weave, the remaining steps on the widened slab.  `poison`: the word planes of
+    count, one all_to_all_single (in-process loopback), the weave, the remaining steps on the widened slab; "transpose-p2p": the planes as one
+    batch of point-to-point operations, received straight into the slab window.  `poison`: the word planes of
     every fresh window are overwritten with an arbitrary byte -- planes nobody produces must not matter."""
     import gc
     gc.collect(); torch.cuda.empty_cache()
@@ -288,7 +292,7 @@ def test_transpose_slabs_equal_whole_grid(engine, world, n, name, poison):
     ref_w = engine.voxelize(fr, dx, dt)
     ref_s = engine.jfa(fr, ref_w).cpu().numpy()
     ref_w = engine.words_to_numpy(ref_w)
-    words, sdf = _run_slabs(world, fr, xyz, tri, ALGO_TILED, kind="transpose", poison=poison)
+    words, sdf = _run_slabs(world, fr, xyz, tri, ALGO_TILED, kind=kind, poison=poison)
     assert np.array_equal(words, ref_w)
     assert np.array_equal(sdf.view(np.uint32), ref_s.view(np.uint32))
 
@@ -471,7 +475,7 @@ def test_config5_n2048_eight_transposed_ranks(engine):
     gc.collect(); torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("world,multi", [(2, "ghost"), (4, "ghost"), (4, "hybrid"), (2, "halo"), (2, "transpose"), (4, "transpose")])
+@pytest.mark.parametrize("world,multi", [(2, "ghost"), (4, "ghost"), (4, "hybrid"), (2, "halo"), (2, "transpose"), (4, "transpose"), (4, "transpose-p2p")])
 def test_bench_multi_process_launch_on_shared_gpu(world, multi):
     """The driver's multi-GPU invocation (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) end to end
     with one process per rank and the real kernels.  A one-GPU box cannot give every rank a device, so the ranks share it and
@@ -496,7 +500,7 @@ def test_bench_multi_process_launch_on_shared_gpu(world, multi):
     assert out["n_gpus"] == world and out["steps"] == 3 and out["scaling"] == "strong"
     assert out["config"]["world_size_seen"] == world and out["config"]["n"] == 256
     assert out["value"] > 0 and out["ms_per_step"] > 0
-    assert out["multi"]["pipeline"] == multi
+    assert out["multi"]["pipeline"] == multi.split("-")[0] and out["multi"].get("exchange", "a2a") == ("p2p" if multi.endswith("p2p") else "a2a")
     assert out["roofline"]["kernel"] == "jfa_dense" and out["roofline"]["launches"] > 0
     # the line verifies itself: every rank compared its slab with the one-GPU result on its own device, for the timed pipeline ...
     assert out["parity_ok"] is True and out["parity"]["parity_ok"] is True
@@ -504,8 +508,8 @@ def test_bench_multi_process_launch_on_shared_gpu(world, multi):
     assert all(r["bitmask_slab_equal"] and r["sdf_slab_equal"] for r in out["parity"]["per_rank"])
     # ... and for the OTHER pipelines, timed in the same job over shorter regions: `multi_alt` = the transposed one (one all_to_all_single --
     # here over gloo through HostStagedDist), then the remaining one of halo / ghost
-    kinds = [k for k in ("transpose", "halo", "ghost") if k != multi][:2]
-    for key, kind in zip(["multi_alt", "multi_alt_" + kinds[1]], kinds):
+    kinds = [k for k in ("transpose", "halo", "transpose-p2p", "ghost") if k != multi][:3]
+    for key, kind in zip(["multi_alt"] + ["multi_alt_" + k.replace("-", "_") for k in kinds[1:]], kinds):
         alt = out[key]
         assert alt["pipeline"] == kind and alt["parity_ok"] is True, (key, alt.get("error"))
         assert alt["ms_per_step"] > 0 and alt["value"] > 0 and len(alt["per_rank"]) == world
@@ -513,8 +517,9 @@ def test_bench_multi_process_launch_on_shared_gpu(world, multi):
             assert alt["bytes_received_per_step_all_ranks"] == 0
         else:
             assert alt["bytes_received_per_step_all_ranks"] > 0       # ids really moved between the ranks
-        if kind == "transpose":
+        if kind.startswith("transpose"):
             assert alt["report_rank0"]["pipeline"] == "transpose" and alt["report_rank0"]["cyclic_steps"][-1] % world == 0
+            assert alt["report_rank0"]["exchange"] == ("p2p" if kind.endswith("p2p") else "a2a")
     assert out["multi"].get("hbm_bytes_this_rank", 0) > 0              # per-rank HBM footprint of the pipeline
 
 
@@ -537,7 +542,7 @@ def test_bench_bare_invocation_launches_its_own_ranks(world):
     assert out["value"] > 0 and out["steps"] == 3
     if world > 1:
         assert out["parity_ok"] is True and out["multi_alt"]["parity_ok"] is True and out["multi_alt"]["pipeline"] == "transpose"
-        assert out["multi_alt_halo"]["parity_ok"] is True
+        assert out["multi_alt_halo"]["parity_ok"] is True and out["multi_alt_transpose_p2p"]["parity_ok"] is True
 
 
 def test_bench_other_transport_hang_does_not_take_the_line_with_it():

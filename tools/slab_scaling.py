@@ -86,7 +86,7 @@ if "transpose" in only:
         state = whole[cur]; del whole
         vox = n * n * n
         sw = state[:vox * 4].view(n, n * n * 4); sb = state[vox * 4:vox * 5].view(n, n * n) if n > 1024 else None
-        ta, tb, rx = [], [], []
+        ta, tb, rx, ta2, tb2 = [], [], [], [], []
         for r in range(world):
             pipe = TransposeSlabPipeline(HipSlabBackend(eng), fr, r, world, NoDist())
             def stepA(): pipe.voxelize(dx, dt); pipe.pack(pipe.phase_a())
@@ -99,7 +99,15 @@ if "transpose" in only:
             def stepB(): pipe.phase_b()
             tb.append(timeit(stepB, max(2, reps // 2)))
             pipe.exchange(); rx.append(pipe.bytes_received)      # (NoDist: only the byte count)
-            del pipe, staging, parts; torch.cuda.empty_cache()
+            # the point-to-point form of the exchange: no pack, no weave -- the slab window filled with the same planes, directly
+            def stepA2(): pipe.voxelize(dx, dt); pipe.phase_a()
+            ta2.append(timeit(stepA2, max(2, reps // 2)))
+            ids0 = pipe._w("ids0"); at = t0 - pipe.plan["window"][0]
+            for part, src in zip(pipe.be.win_spans(fr, ids0, 0, ids0.planes), (sw, sb)):
+                part.view(ids0.planes, -1)[at:at + (t1_ - t0)].copy_(src[t0:t1_])
+            def stepB2(): pipe.phase_b(weave=False)
+            tb2.append(timeit(stepB2, max(2, reps // 2)))
+            del pipe, staging, parts, ids0; torch.cuda.empty_cache()
         tot = [a + b for a, b in zip(ta, tb)]
         i = max(range(world), key=lambda j: tot[j])
         b = max(rx)
@@ -108,6 +116,10 @@ if "transpose" in only:
               % (world, "%d..%d" % (plan0["cyclic"][0], plan0["cyclic"][-1]), ",".join(str(k_) for k_, _, _ in plan0["regions"]), tot[i], ta[i], tb[i],
                  "yes" if tot[i] <= 1.25 * t1 / world else "NO", 1.25 * t1 / world, b / 2**30, tot[i] + x300, tot[i] + x150,
                  t1 / (tot[i] + x300), t1 / (tot[i] + x150), t1 / tot[i], " ".join("%.2f" % t for t in tot)))
+        tot2 = [a + b for a, b in zip(ta2, tb2)]
+        i2 = max(range(world), key=lambda j: tot2[j])
+        print("      exchange \"p2p\" (planes placed directly: no pack, no weave): compute %8.3f (%.3f | %.3f)   %s   compute only: %.2fx   %s"
+              % (tot2[i2], ta2[i2], tb2[i2], "yes" if tot2[i2] <= 1.25 * t1 / world else "NO", t1 / tot2[i2], " ".join("%.2f" % t for t in tot2)))
         del state, sw, sb; torch.cuda.empty_cache()
     del words, border; torch.cuda.empty_cache()
 
