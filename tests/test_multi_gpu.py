@@ -151,7 +151,8 @@ def test_multi_ghost_ignores_unproduced_planes(engine, poison):
     before it never produced.  In the hooks build (libvphip_hooks.so, VP_MULTI_POISON) the word planes of the id windows are refilled
     with a poison byte before every vp_multi_jfa: the slabs must not depend on it.  n = 256 over 8 ranks: slabs of 32 planes, every pass
     with k < 8 has rounding excess on both sides; n = 1152 over 4: the 5-byte window layout, the windows re-used by another mode (another
-    geometry: cleared) in between."""
+    geometry: cleared) in between.  VP_MULTI_TRANSPOSE: the planes around the received range of the slab windows are never written
+    (the rounded regions of the last passes read them), its cyclic and staging windows are poisoned too."""
     import os, subprocess, sys
     from cuda_mesh_voxelization_amd import build
     build.build_lib(hooks=True)
@@ -160,7 +161,7 @@ def test_multi_ghost_ignores_unproduced_planes(engine, poison):
         "import sys, numpy as np\n"
         "sys.path.insert(0, %r)\n"
         "from cuda_mesh_voxelization_amd import capi, mesh as M\n"
-        "from cuda_mesh_voxelization_amd.capi import Frame, MULTI_GHOST, MULTI_HALO, MULTI_HYBRID\n"
+        "from cuda_mesh_voxelization_amd.capi import Frame, MULTI_GHOST, MULTI_HALO, MULTI_HYBRID, MULTI_TRANSPOSE\n"
         "from cuda_mesh_voxelization_amd.pipeline import Engine\n"
         "eng = Engine(0)\n"
         "xyz, tri = M.import_mesh(M.asset('bunny.obj'))\n"
@@ -170,7 +171,7 @@ def test_multi_ghost_ignores_unproduced_planes(engine, poison):
         "    ref = eng.jfa(fr, eng.voxelize(fr, dx, dt)).cpu().numpy(); eng._work = None\n"
         "    m = capi.Multi([0] * world)\n"
         "    m.set_mesh(xyz, tri); m.voxelize(fr)\n"
-        "    for mode in (MULTI_GHOST, MULTI_HYBRID, MULTI_GHOST, MULTI_HALO):\n"
+        "    for mode in (MULTI_GHOST, MULTI_TRANSPOSE, MULTI_HYBRID, MULTI_GHOST, MULTI_HALO, MULTI_TRANSPOSE):\n"
         "        m.jfa(mode=mode)\n"
         "        assert np.array_equal(m.get_sdf().view(np.uint32), ref.view(np.uint32)), (n, mode)\n"
         "    m.close()\n"

@@ -195,11 +195,13 @@ def _window_parts(t, n, planes):
 
 
 @pytest.mark.parametrize("world,n,name", [(2, 96, "bunny.obj"), (4, 128, "torus.obj"), (8, 128, "d20.obj"), (8, 256, "bunny.obj"), (2, 512, "bimba.obj"),
-                                          (8, 512, "bunny.obj"), (4, 160, "sphere.obj"), (8, 1024, "bimba.obj"), (8, 1152, "bunny.obj"), (4, 1280, "bimba.obj")])
+                                          (8, 512, "bunny.obj"), (4, 160, "sphere.obj"), (8, 1024, "bimba.obj"), (8, 1152, "bunny.obj"), (4, 1280, "bimba.obj"),
+                                          (8, 768, "bunny.obj"), (2, 544, "torus.obj"), (4, 640, "bimba.obj"), (16, 256, "d20.obj")])
 def test_cyclic_passes_equal_whole_grid_passes(engine, world, n, name):
     """Every pass of the cyclic phase, id for id: the window of rank r after the fused start and after each vp_jfa_window_pass_cyclic must
     hold exactly the planes r, r + world, ... of the whole-grid window after the same pass (vp_jfa_window_first_two / vp_jfa_window_pass:
-    closed tiles at k = n/8, pair mode, compact ids above n = 1024, steps that are not powers of two at n = 96 / 160 / 1152 / 1280)."""
+    closed tiles at k = n/8, pair mode, compact ids above n = 1024, steps that are not powers of two at n = 96 / 160 / 1152 / 1280, the 4-KB
+    tables off the powers of two at n = 544 / 640 / 768, sixteen ranks)."""
     import gc
     from cuda_mesh_voxelization_amd.capi import Window
     from cuda_mesh_voxelization_amd.slab import cyclic_passes
