@@ -477,7 +477,7 @@ def test_config5_n2048_eight_transposed_ranks(engine):
     gc.collect(); torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("world,multi", [(2, "ghost"), (4, "ghost"), (4, "hybrid"), (2, "halo"), (2, "transpose"), (4, "transpose"), (4, "transpose-p2p")])
+@pytest.mark.parametrize("world,multi", [(2, "ghost"), (4, "ghost"), (4, "hybrid"), (2, "halo"), (2, "transpose"), (4, "transpose"), (4, "transpose-p2p"), (8, "ghost")])
 def test_bench_multi_process_launch_on_shared_gpu(world, multi):
     """The driver's multi-GPU invocation (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) end to end
     with one process per rank and the real kernels.  A one-GPU box cannot give every rank a device, so the ranks share it and
