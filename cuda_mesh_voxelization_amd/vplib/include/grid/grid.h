@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <type_traits>
 #include <cstddef>
 #include <cstdio>
 #include <memory>
@@ -43,6 +44,25 @@ public:
     size_t Index(size_t x, size_t y, size_t z) const { return x + (y * mSizeX) + (z * mSizeX * mSizeY); }
     T* Data() { return mGrid.data(); }
     const T* Data() const { return mGrid.data(); }
+
+    // debug dump (grid.h:74-86,98-109 of the reference): "%.2f " per float, "%d " per int, "(x, y, z) " per position, "error" for any other type
+    void PrintValue(T value) const
+    {
+        if constexpr (std::is_same_v<T, float>) std::printf("%.2f ", value);
+        else if constexpr (std::is_same_v<T, int>) std::printf("%d ", value);
+        else if constexpr (requires { value.X; value.Y; value.Z; }) std::printf("(%.2f, %.2f, %.2f) ", value.X, value.Y, value.Z);
+        else std::printf("error");
+    }
+    void Print() const
+    {
+        for (size_t z = 0; z < mSizeZ; ++z) {
+            for (size_t y = 0; y < mSizeY; ++y) {
+                for (size_t x = 0; x < mSizeX; ++x) PrintValue((*this)(x, y, z));
+                std::printf("\n");
+            }
+            std::printf("\n");
+        }
+    }
 
     friend class HostGrid<T>;
     friend class DeviceGrid<T>;

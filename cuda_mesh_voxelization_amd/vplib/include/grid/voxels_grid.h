@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <cstdio>
 #include <cstddef>
 #include <cstdint>
 #include <memory>
@@ -77,6 +78,18 @@ public:
     float OriginX() const { return mOriginX; }
     float OriginY() const { return mOriginY; }
     float OriginZ() const { return mOriginZ; }
+
+    // debug dump, one row of voxels per line, a blank line between planes (voxels_grid.h:171-183 of the reference)
+    void Print() const requires (!device)
+    {
+        for (size_t z = 0; z < mSizeZ; ++z) {
+            for (size_t y = 0; y < mSizeY; ++y) {
+                for (size_t x = 0; x < mSizeX; ++x) std::printf("%d ", static_cast<int>(Voxel(x, y, z)));
+                std::printf("\n");
+            }
+            std::printf("\n");
+        }
+    }
 
     T* Data() { return mGrid.data(); }
     const T* Data() const { return mGrid.data(); }

@@ -24,6 +24,12 @@ struct Color {
     uint8_t G() const { return (mColor >> 16) & 0xFF; }
     uint8_t B() const { return (mColor >> 8) & 0xFF; }
     uint8_t A() const { return mColor & 0xFF; }
+    // the reference's one-channel setters (mesh.h:27-36) re-quantise the OTHER channels from their bytes as if they were fractions -- i.e.
+    // SetColor(r, G(), B(), A()) with G() = 0 .. 255: kept as written there (such a channel spills into the lanes above it)
+    void R(float r) { SetColor(r, G(), B(), A()); }
+    void G(float g) { SetColor(R(), g, B(), A()); }
+    void B(float b) { SetColor(R(), G(), b, A()); }
+    void A(float a) { SetColor(R(), G(), B(), a); }
 
 private:
     uint32_t mColor = 0xFFFFFFFFu;

@@ -86,3 +86,17 @@ def test_device_types_run(device_types_check):
     p = subprocess.run([device_types_check, M.asset("bunny.obj"), "64"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "FAIL" not in p.stdout and p.stdout.strip().endswith("done"), p.stdout + p.stderr
     assert p.stdout.count("ok ") >= 20
+
+
+def test_host_only_api_members(tmp_path_factory):
+    """Debug dumps and colour setters of the mirror (reference: grid/voxels_grid.h:171-183, grid/grid.h:74-109, mesh/mesh.h:19-36): the text
+    they print.  Host code only: runs without a GPU."""
+    exe = _compile(tmp_path_factory, "host_api_check")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    want = ("0 1 \n0 0 \n\n0 0 \n1 0 \n\n--\n"
+            "0.50 0.50 \n0.50 -2.25 \n\n0.50 0.50 \n0.50 0.50 \n\n--\n"
+            "7 \n7 \n\n--\n"
+            "(1.00, 2.00, 3.50) \n\n--\n"
+            "51 102 153 255\n255 0 0 0\n")
+    assert out.stdout == want, repr(out.stdout)
