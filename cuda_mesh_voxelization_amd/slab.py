@@ -635,8 +635,8 @@ class TransposeSlabPipeline:
     all-to-all -- the planes of rank t's widened slab that rank s holds are a CONTIGUOUS range of s's local planes -- re-deals the state
     into slabs widened by the reach of the remaining steps (world - 1 planes: 7 for 8 ranks, rounded to 8), a local kernel weaves the
     received chunks into consecutive planes, and the passes k < world run on the widened slab exactly like the last regions of the ghost
-    pipeline.  Per rank at n = 1024 x 8: 1,280 + 3 x 16 plane-passes against 3,220 (ghost), 0.56 GiB received against 3.5 GiB (halo), id
-    state 2 x 0.5 + 3 x 0.6 GiB.  Grids whose step sequence leaves the multiples of world early (sides that are not powers of two) simply
+    pipeline.  Per rank at n = 1024 x 8: 1,280 + 2 x 16 extra plane-passes against 3,216 (ghost), 0.49 GiB received against 3.5 GiB (halo),
+    id state 2 x 0.5 (cyclic) + 2 x 0.56 (send, staging: not with exchange = "p2p") + 2 x 0.6 GiB (slab phase).  Grids whose step sequence leaves the multiples of world early (sides that are not powers of two) simply
     switch to the slab phase earlier, with a wider margin; where fewer than two passes qualify the pipeline IS the ghost pipeline."""
 
     def __init__(self, backend, frame: Frame, rank: int, world: int, dist, exchange: str = "a2a"):
