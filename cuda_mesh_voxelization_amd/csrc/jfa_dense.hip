@@ -602,11 +602,13 @@ void launch_shape(const DenseArgs& a, bool pairsOk, bool wholeChains)
     constexpr bool canFull = CH >= 8 && (ID::kTab != 1024 || F);
     auto go = [&](auto pm) {
         constexpr int PM = decltype(pm)::value;
-        if constexpr (ALWAYS_FULL || (CYC && canFull)) { launch_tile<ID, RY, CH, NT, F, PM, 0, true, CYC>(a); return; }
-        else if constexpr (canFull) {
-            if (wholeChains && a.ylen % RY == 0) { launch_tile<ID, RY, CH, NT, F, PM, 0, true>(a); return; }
+        if constexpr (ALWAYS_FULL || (CYC && canFull)) launch_tile<ID, RY, CH, NT, F, PM, 0, true, CYC>(a);
+        else {                                                     // (an else branch: the form not taken is not instantiated at all)
+            if constexpr (canFull) {
+                if (wholeChains && a.ylen % RY == 0) { launch_tile<ID, RY, CH, NT, F, PM, 0, true>(a); return; }
+            }
+            launch_tile<ID, RY, CH, NT, F, PM, 0, false, CYC>(a);
         }
-        launch_tile<ID, RY, CH, NT, F, PM, 0, false, CYC>(a);
     };
     if constexpr (CH >= 8) {
         if (pairsOk && a.f.n % NT == 0) {
