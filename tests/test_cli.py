@@ -275,7 +275,7 @@ def test_cli_gpu_types_reject_unsupported_sizes_loudly(cli, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("g,multi", [(2, "halo"), (4, "halo"), (4, "ghost"), (2, "transpose"), (4, "transpose")])
+@pytest.mark.parametrize("g,multi", [(2, "halo"), (4, "halo"), (4, "ghost"), (2, "transpose"), (4, "transpose"), (8, "transpose")])
 def test_cli_gpus_flag_matches_golden(cli, golden_rows, tmp_path, g, multi):
     """`vpcli -g G` (the multi-GPU extension of the CLI; the reference pins device 0, apps/cli/main.cpp:22-23): the
     grid is cut into G Z-slabs behind the same VOX / CSG / JFA::Compute calls (vplib::SetDevices -> vp_multi_*).  On a one-GPU box
