@@ -205,3 +205,69 @@ def grid_to_point_cloud(words, sdf, n: int, voxel_size, origin):
     finally:
         lib().vpo_free(pc); lib().vpo_free(pr)
     return coords, rgb
+
+
+# ---------------------------------------------------------------------------------------------- oracle/_ref: parts of the reference itself
+# oracle/_ref/vpref (+ libvpref.so) = the reference's own mesh_io.cpp, grid_to_mesh.cpp, csg/sequential.cpp, voxels_grid.cu and
+# bounding_box.h behind oracle/ref_driver.cpp, built by `make -C oracle _ref` from /root/reference where it lies (see oracle/Makefile for
+# what can and what cannot be built in this image).  Built here (build container); on the GPU box only the prebuilt files are used.
+_REF_DIR = os.path.join(_HERE, "_ref")
+_REF_BIN = os.path.join(_REF_DIR, "vpref")
+REFERENCE_ROOT = "/root/reference"
+
+
+def build_ref(force: bool = False):
+    """oracle/_ref/vpref, or None where it neither exists nor can be built (no /root/reference, no CUDA toolkit headers in the image)"""
+    have = os.path.exists(_REF_BIN) and os.path.exists(os.path.join(_REF_DIR, "libvpref.so"))
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "vplib", "src")):
+        srcs = [os.path.join(_HERE, "ref_driver.cpp"), os.path.join(_HERE, "Makefile")]
+        stale = have and os.path.getmtime(_REF_BIN) < max(os.path.getmtime(f) for f in srcs)
+        if force or stale or not have:
+            r = subprocess.run(["make", "-C", _HERE] + (["-B"] if (force or stale) else []) + ["_ref"], capture_output=True, text=True)
+            if r.returncode != 0:
+                if have:
+                    return _REF_BIN
+                return None
+            have = True
+    return _REF_BIN if have else None
+
+
+def _ref(*args, cwd=None):
+    exe = build_ref()
+    if exe is None:
+        raise RuntimeError("oracle/_ref is not built (needs /root/reference and the CUDA toolkit headers of the image: make -C oracle _ref)")
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, cwd=cwd, timeout=1800)
+    if r.returncode != 0:
+        raise RuntimeError("vpref %s failed (%d): %s%s" % (args[0], r.returncode, r.stdout[-500:], r.stderr[-500:]))
+    return r.stdout
+
+
+def ref_import(path, workdir):
+    """the reference's ImportMesh (mesh/mesh_io.cpp:15-81): (Coords float32 [V, 3], FacesCoords uint32 [T, 3])"""
+    prefix = os.path.join(workdir, "ref_import")
+    _ref("import", path, prefix)
+    return (np.fromfile(prefix + ".xyz.f32", np.float32).reshape(-1, 3), np.fromfile(prefix + ".tri.u32", np.uint32).reshape(-1, 3))
+
+
+def ref_frame(paths, n):
+    """the frame of a CLI run (apps/cli/main.cpp:65-87) through the reference's ImportMesh + CalculateBoundingBox: (origin float32 [3], voxel size float32)"""
+    v = np.array([float(t) for t in _ref("frame", n, *paths).split()], np.float32)
+    return v[:3].copy(), np.float32(v[3])
+
+
+def ref_export(words, sdf, n, voxel_size, origin, workdir):
+    """the reference's three exporters + ExportMesh: paths of <compressed>.obj, <cubes>.obj, <points>.obj (the last two None without an sdf)"""
+    wp, sp, prefix = os.path.join(workdir, "ref_w.u32"), os.path.join(workdir, "ref_s.f32"), os.path.join(workdir, "ref")
+    _u32(words).tofile(wp)
+    if sdf is not None:
+        _f32(sdf).tofile(sp)
+    _ref("export", wp, sp if sdf is not None else "-", n, "%.9g" % float(voxel_size), *["%.9g" % float(c) for c in origin], prefix)
+    return prefix + ".compressed.obj", (prefix + ".cubes.obj") if sdf is not None else None, (prefix + ".points.obj") if sdf is not None else None
+
+
+def ref_csg(a, b, n, op, workdir):
+    """the reference's CSG::Compute<Types::SEQUENTIAL> (csg/sequential.cpp:7-30): a op b as a new word array"""
+    ap, bp, cp = (os.path.join(workdir, "ref_%s.u32" % k) for k in "abc")
+    _u32(a).tofile(ap); _u32(b).tofile(bp)
+    _ref("csg", ap, bp, n, op, cp)
+    return np.fromfile(cp, np.uint32)

@@ -4,8 +4,9 @@
  *
  * TEST INFRASTRUCTURE ONLY (see vp_oracle.h): loaded by tests/test_export.py as the checker of
  * cuda_mesh_voxelization_amd/vplib/src/grid_to_mesh.cpp and of the vp_extract front end; never by the product.
- * Parity status: unpinned in the formal sense, like the rest of the oracle -- the reference holds no golden mesh and
- * oracle/_ref cannot be built here; this file follows the reference line by line instead of restructuring it:
+ * Parity status: PINNED (round 6) -- the reference's own grid_to_mesh.cpp and mesh_io.cpp build in this image (oracle/_ref, oracle/Makefile) and
+ * tests/test_reference_build.py compares the three restatements below with the files the reference's exporters write, line by line.  The
+ * file follows the reference line by line instead of restructuring it:
  *   /root/reference/vplib/src/mesh/grid_to_mesh.cpp:10-60   the z, y, x walk, six AddFacesVertex* calls per set voxel (:37-44)
  *   /root/reference/vplib/src/mesh/grid_to_mesh.h:25-92     AddFacesVertex: plane_index (:31), face_index and the faces_marked test
  *                                                           (:34-43), the four vertices in (v, u) order through vertices_marked

@@ -6,13 +6,18 @@
  * only as the checker / the timed CPU baseline.  The product path (libvphip.so) never
  * links, loads or calls it.
  *
- * Parity status: PARITY UNPINNED in the formal sense.  Every function below is checked in
- * tests/test_oracle_golden.py against tests/golden/survey_table.json -- the popcount / FNV-1a-64 /
- * SDF-sum table the survey captured by running the reference's own sequential sources in this
- * container -- but that run needed stand-in CUDA headers, has no committed
- * recipe, and the reference itself holds no golden vectors; oracle/_ref cannot be built here
- * (oracle/Makefile).  tests/golden/own_oracle_runs.json holds outputs of THIS
- * oracle for sizes the reference cannot run; they pin the GPU path to the oracle, not the oracle.
+ * Parity status, per function (round 6):
+ *   PINNED by the reference itself (oracle/_ref: its own mesh_io.cpp, grid_to_mesh.cpp, csg/sequential.cpp, voxels_grid.cu and
+ *   bounding_box.h compiled from /root/reference where they lie, oracle/Makefile; tests/test_reference_build.py):
+ *       vpo_bounding_box / vpo_frame, vpo_csg, the bit layout, and the three exporters of oracle_export.c.
+ *   PARITY UNPINNED in the formal sense: vpo_voxelize and vpo_jfa.  They are checked in tests/test_oracle_golden.py against
+ *   tests/golden/survey_table.json -- the popcount / FNV-1a-64 / SDF-sum table the survey captured by running the reference's own
+ *   sequential sources in this container -- but that run needed stand-in CUDA headers and has no committed
+ *   recipe, the reference itself holds no golden vectors, and those two units cannot be part of oracle/_ref (vox/vox.h needs
+ *   <cub/cub.cuh>, which the image lacks; jfa/sequential.cpp allocates through cudaMalloc at run time).  What _ref adds for them: the
+ *   table's CSG column is reproduced by the reference's own CSG on the oracle's grids, hash for hash.
+ *   tests/golden/own_oracle_runs.json holds outputs of THIS oracle for sizes the reference cannot run; they pin the GPU path to the
+ *   oracle, not the oracle.
  *
  * All citations are file:line under /root/reference.
  */
