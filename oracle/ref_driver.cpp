@@ -16,6 +16,11 @@
 //   vpref export <words.u32> <sdf.f32|-> <n> <vs> <ox> <oy> <oz> <out_prefix>
 //                                                           -> <prefix>.compressed.obj [, <prefix>.cubes.obj, <prefix>.points.obj] through ExportMesh
 //   vpref csg    <a.u32> <b.u32> <n> <op 1|2|3> <out.u32>   -> CSG::Compute<SEQUENTIAL> (result in the first grid, csg/sequential.cpp:7-30)
+//   vpref distance <pairs.f32> <out.f32>                    -> JFA::CalculateDistance (jfa/jfa.h:19-20) of every pair of positions (6 floats each)
+//   vpref vec    <pairs.f32> <out.f32>                      -> Vec3::Cross and Vec3::Dot (mesh/mesh.h:114-126) of every pair: 4 floats each
+//   vpref misc   [paths ...]                                -> GetTypesString(0..3), NextPow2 samples, GetFilename of every path (proc_utils.h:11-40)
+//   vpref profile <label>                                   -> one Profiling scope (profiling.h:8-26): the timer line the benchmark script parses
+//   vpref assert <message>                                  -> cpuAssert(false, message) (debug_utils.h:52-64)
 //
 // Two build parts (oracle/Makefile): the reference units + everything below as oracle/_ref/libvpref.so (undefined CUDA runtime symbols are
 // legal in a shared object), and -DVPREF_LOADER: a main() that loads it with dlopen(RTLD_LAZY) -- lazy binding: a function that is never
@@ -50,6 +55,10 @@ int main(int argc, char** argv)
 
 #include <bounding_box.h>
 #include <csg/csg.h>
+#include <jfa/jfa.h>
+#include <profiling.h>
+#include <proc_utils.h>
+#include <debug_utils.h>
 #include <grid/grid.h>
 #include <grid/voxels_grid.h>
 #include <mesh/grid_to_mesh.h>
@@ -142,6 +151,38 @@ int Csg(const std::string& aPath, const std::string& bPath, size_t n, int op, co
     return 0;
 }
 
+int Distance(const std::string& in, const std::string& out)
+{
+    const std::vector<float> p = ReadAll<float>(in);
+    std::vector<float> d(p.size() / 6);
+    for (size_t i = 0; i < d.size(); ++i)
+        d[i] = JFA::CalculateDistance(Position(p[i * 6], p[i * 6 + 1], p[i * 6 + 2]), Position(p[i * 6 + 3], p[i * 6 + 4], p[i * 6 + 5]));
+    WriteAll(out, d.data(), d.size());
+    return 0;
+}
+
+int VecOps(const std::string& in, const std::string& out)
+{
+    const std::vector<float> p = ReadAll<float>(in);
+    std::vector<float> r(p.size() / 6 * 4);
+    for (size_t i = 0; i < p.size() / 6; ++i) {
+        const Position a(p[i * 6], p[i * 6 + 1], p[i * 6 + 2]), b(p[i * 6 + 3], p[i * 6 + 4], p[i * 6 + 5]);
+        const Position c = Position::Cross(a, b);
+        r[i * 4] = c.X; r[i * 4 + 1] = c.Y; r[i * 4 + 2] = c.Z; r[i * 4 + 3] = Position::Dot(a, b);
+    }
+    WriteAll(out, r.data(), r.size());
+    return 0;
+}
+
+int Misc(int argc, char** argv)
+{
+    for (int t = 0; t < 4; ++t) std::printf("type %d %s\n", t, GetTypesString(static_cast<Types>(t)).c_str());
+    const unsigned long ns[] = {0, 1, 2, 3, 31, 32, 33, 500, 512, 513, 1000, 100000};
+    for (unsigned long n : ns) std::printf("nextpow2 %lu %lu %lu\n", n, NextPow2(n, 512), NextPow2(n, 1 << 20));
+    for (int i = 0; i < argc; ++i) std::printf("filename %s\n", GetFilename(argv[i]).c_str());
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int vpref_main(int argc, char** argv)
@@ -153,6 +194,11 @@ extern "C" int vpref_main(int argc, char** argv)
         return Export(argv[2], argv[3], std::strtoull(argv[4], nullptr, 10), std::strtof(argv[5], nullptr), std::strtof(argv[6], nullptr),
                       std::strtof(argv[7], nullptr), std::strtof(argv[8], nullptr), argv[9]);
     if (cmd == "csg" && argc == 7) return Csg(argv[2], argv[3], std::strtoull(argv[4], nullptr, 10), std::atoi(argv[5]), argv[6]);
+    if (cmd == "distance" && argc == 4) return Distance(argv[2], argv[3]);
+    if (cmd == "vec" && argc == 4) return VecOps(argv[2], argv[3]);
+    if (cmd == "misc") return Misc(argc - 2, argv + 2);
+    if (cmd == "profile" && argc == 3) { { Profiling scope(argv[2]); } std::fflush(stdout); return 0; }
+    if (cmd == "assert" && argc == 3) { cpuAssert(false, argv[2]); return 0; }
     std::fprintf(stderr, "usage: vpref import | frame | export | csg ... (see oracle/ref_driver.cpp)\n");
     return 2;
 }

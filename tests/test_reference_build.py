@@ -177,3 +177,62 @@ def test_gpu_csg_is_the_references_csg(engine, tmp_path, op):
     engine.csg(da, db, op)
     engine.sync()
     assert np.array_equal(engine.words_to_numpy(da), O.ref_csg(a, b, n, op, str(tmp_path)))
+
+
+# ---------------------------------------------------------------------------------------------- header-level functions of the mirror
+@pytest.fixture(scope="module")
+def host_api_check(tmp_path_factory):
+    """tests/cpp/host_api_check.cpp: the same commands answered by THIS repository's vplib mirror"""
+    exe = str(tmp_path_factory.mktemp("cpp") / "host_api_check")
+    pkg = os.path.join(ROOT, "cuda_mesh_voxelization_amd")
+    build.build_lib()
+    srcs = [os.path.join(pkg, "vplib", "src", f) for f in sorted(os.listdir(os.path.join(pkg, "vplib", "src"))) if f.endswith(".cpp")]
+    subprocess.check_call(["g++", "-std=c++23", "-O2", "-ffp-contract=off", "-fopenmp", "-I", os.path.join(pkg, "vplib", "include"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "host_api_check.cpp")] + srcs + ["-o", exe, "-L", pkg, "-lvphip", "-Wl,-rpath," + pkg])
+    return exe
+
+
+def _pairs(seed, m=20000):
+    """pairs of positions as the JFA sees them: grid corners o + i vs of random frames (incl. far origins: cancellation), and free floats"""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    o = ((rng.random(3) - 0.5) * 200).astype(f32)
+    vs = f32(10.0 ** rng.uniform(-3, 0))
+    i, j = rng.integers(0, 2048, (m, 3)), rng.integers(0, 2048, (m, 3))
+    grid = np.concatenate([o + i.astype(f32) * vs, o + j.astype(f32) * vs], 1).astype(f32)
+    free = ((rng.random((m, 6)) - 0.5) * 10.0 ** rng.uniform(-3, 3, (m, 1))).astype(f32)
+    return np.concatenate([grid, free], 0)
+
+
+def test_distance_and_vector_ops_are_the_references(tmp_path, host_api_check):
+    """JFA::CalculateDistance (jfa/jfa.h:19-20) and Vec3::Cross / Dot (mesh/mesh.h:114-126): the reference's header functions, this
+    repository's mirror and the float32 expression the numpy test backend uses -- bit for bit on 40,000 pairs (grid corners of random
+    frames, where the subtraction cancels, and free floats over six decades)"""
+    p = _pairs(7)
+    p.tofile(str(tmp_path / "pairs.f32"))
+    for cmd, width in (("distance", 1), ("vec", 4)):
+        O._ref(cmd, str(tmp_path / "pairs.f32"), str(tmp_path / ("ref_%s.f32" % cmd)))
+        subprocess.check_call([host_api_check, cmd, str(tmp_path / "pairs.f32"), str(tmp_path / ("own_%s.f32" % cmd))])
+        ref = np.fromfile(str(tmp_path / ("ref_%s.f32" % cmd)), np.float32)
+        own = np.fromfile(str(tmp_path / ("own_%s.f32" % cmd)), np.float32)
+        assert ref.size == p.shape[0] * width and np.array_equal(ref.view(np.uint32), own.view(np.uint32)), cmd
+    a, b = p[:, :3], p[:, 3:]
+    d = b - a
+    want = ((d[:, 0] * d[:, 0]) + (d[:, 1] * d[:, 1])) + (d[:, 2] * d[:, 2])                   # float32 throughout, no contraction
+    assert np.array_equal(np.fromfile(str(tmp_path / "ref_distance.f32"), np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32))
+
+
+def test_helpers_timer_grammar_and_assert_line_are_the_references(host_api_check):
+    """GetTypesString / NextPow2 / GetFilename (proc_utils.h:11-40); the `[Label]: <ms> ms` line of a Profiling scope (profiling.h:8-26: what
+    scripts/benchmarks.py parses); the `[file:line] CPU Assert: message` line and exit code of cpuAssert (debug_utils.h:52-64)"""
+    import re
+    args = ["misc", "/a/b/c.obj", "plain.obj", "dir/"]
+    assert O._ref(*args) == subprocess.run([host_api_check] + args, capture_output=True, text=True).stdout
+    line = re.compile(r"^\[TiledJFA::Processing\]: \d+\.\d{6} ms\n$")
+    assert line.match(O._ref("profile", "TiledJFA::Processing"))
+    assert line.match(subprocess.run([host_api_check, "profile", "TiledJFA::Processing"], capture_output=True, text=True).stdout)
+    exe = O.build_ref()
+    r = subprocess.run([exe, "assert", "Number of GPUs must be 1..64"], capture_output=True, text=True)
+    m = subprocess.run([host_api_check, "assert", "Number of GPUs must be 1..64"], capture_output=True, text=True)
+    shape = re.compile(r"^\[[^\]:]+:\d+\] CPU Assert: Number of GPUs must be 1\.\.64$")
+    assert r.returncode == m.returncode == 255 and shape.match(r.stdout) and shape.match(m.stdout)
